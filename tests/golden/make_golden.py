@@ -1,0 +1,457 @@
+#!/usr/bin/env python3
+"""Golden-vector generator. Runs ONLY in the build container (needs /root/reference).
+
+It imports the reference's own Python (run_nerf_helpers.py, run_nerf.py, run_nerf_view.py,
+run_nerf_view_test.py) with the IO-only third-party modules stubbed, drives the reference
+functions on seeded inputs built by `_inputs.py`, and stores the *outputs* (arrays only) as
+.npz fixtures next to this file. No reference source, bytecode or pickled reference object
+is written anywhere. The tests rebuild the same inputs from `_inputs.py` and compare.
+
+Determinism: the reference's own `pytest=True` hooks (run_nerf.py:376-380,
+run_nerf_helpers.py:220-229, run_nerf.py:290-294) replace torch RNG with
+`np.random.seed(0); np.random.rand(...)`.
+
+usage:  python tests/golden/make_golden.py [--only NAME ...]
+"""
+import argparse
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+REF = "/root/reference/nerf-pytorch-master"
+
+import torch  # noqa: E402
+
+import _inputs as I  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+# ----------------------------------------------------------------------------- reference import
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def import_reference():
+    """Stubs per SURVEY.md §0: only loaders / logging / perceptual nets touch these modules."""
+    for n in ("imageio", "cv2", "ipdb"):
+        _stub(n)
+    _stub("tensorboardX", SummaryWriter=object)
+    _stub("pytorch_msssim", ssim=None, ms_ssim=None)
+
+    class _LPIPS:  # instantiated at import time at run_nerf_view.py:39-40
+        def __init__(self, *a, **k):
+            pass
+
+        def to(self, *a, **k):
+            return self
+
+    _stub("lpips", LPIPS=_LPIPS)
+    # run_nerf_view.py hard-codes CUDA placement in the warp (V:596,622-624); identity on CPU.
+    torch.cuda.current_device = lambda: 0
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.cuda.LongTensor = torch.LongTensor
+    sys.path.insert(0, REF)
+    import run_nerf_helpers as H
+    import run_nerf as R
+    import run_nerf_view as V
+    import run_nerf_view_test as VT
+    return H, R, V, VT
+
+
+H, R, V, VT = import_reference()
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"  wrote {name}.npz  ({os.path.getsize(path)/1024:.1f} KiB)  nkeys={len(out)}")
+
+
+def make_model(Hmod, D, W, use_viewdirs=True, output_ch=4, seed=0, multires=10, multires_views=4):
+    sd = I.nerf_state_dict(D, W, multires, multires_views, output_ch, use_viewdirs, seed)
+    input_ch = I.embed_channels(multires)
+    input_ch_views = I.embed_channels(multires_views) if use_viewdirs else 0
+    m = Hmod.NeRF(D=D, W=W, input_ch=input_ch, output_ch=output_ch, skips=[4],
+                  input_ch_views=input_ch_views, use_viewdirs=use_viewdirs)
+    m.load_state_dict({k: T(v) for k, v in sd.items()}, strict=True)
+    return m
+
+
+def grad_summary(model, prefix):
+    """Compact pin of a gradient set: per-tensor sum, abs-sum, and every 61st element."""
+    out = {}
+    for k, p in model.named_parameters():
+        g = p.grad
+        if g is None:
+            g = torch.zeros_like(p)
+        g = g.detach().double().reshape(-1)
+        out[f"{prefix}{k}.sum"] = g.sum().numpy()
+        out[f"{prefix}{k}.abssum"] = g.abs().sum().numpy()
+        out[f"{prefix}{k}.sub"] = g[::61].float().numpy()
+    return out
+
+
+def full_grads(model, prefix):
+    return {f"{prefix}{k}": (p.grad if p.grad is not None else torch.zeros_like(p)).detach().numpy()
+            for k, p in model.named_parameters()}
+
+
+# ----------------------------------------------------------------------------- fixtures
+def fx_embed():
+    rs = np.random.RandomState(0)
+    x = rs.uniform(-4, 4, size=(257, 3)).astype(np.float32)
+    e10, n10 = H.get_embedder(10, 0)
+    e4, n4 = H.get_embedder(4, 0)
+    assert (n10, n4) == (63, 27)
+    save("embed", x=x, L10=e10(T(x)), L4=e4(T(x)))
+
+
+def fx_mlp():
+    """a4+a5+a6: run_network on raw points/dirs, and NeRF.forward on a pre-embedded batch."""
+    for tag, D, W, vd, och in (("D8W256_vd", 8, 256, True, 5), ("D4W128_vd", 4, 128, True, 4),
+                               ("D4W128_novd", 4, 128, False, 5), ("D8W128_vd", 8, 128, True, 5)):
+        model = make_model(H, D, W, vd, och, seed=11)
+        rs = np.random.RandomState(5)
+        B, S = 24, 16
+        pts = rs.uniform(-3, 3, size=(B, S, 3)).astype(np.float32)
+        dirs = rs.normal(size=(B, 3)).astype(np.float32)
+        dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+        embed_fn, _ = H.get_embedder(10, 0)
+        embeddirs_fn = H.get_embedder(4, 0)[0] if vd else None
+        raw = R.run_network(T(pts), T(dirs) if vd else None, model, embed_fn, embeddirs_fn, netchunk=100)
+        G = rs.normal(size=tuple(raw.shape)).astype(np.float32)
+        (raw * T(G)).sum().backward()
+        arrays = dict(pts=pts, dirs=dirs, raw=raw, G=G)
+        arrays.update(full_grads(model, "grad.") if W == 128 and D == 4 else grad_summary(model, "gs."))
+        save(f"mlp_{tag}", **arrays)
+
+
+def fx_raw2outputs():
+    for tag, S, white, noise in (("S64", 64, False, 0.0), ("S192", 192, False, 0.0),
+                                 ("S64_white", 64, True, 0.0), ("S192_white_noise", 192, True, 1.0)):
+        raw, z, d = I.raw2outputs_inputs(32, S, seed=S + int(white))
+        rawt = T(raw).requires_grad_(True)
+        rgb, disp, acc, weights, depth = R.raw2outputs(rawt, T(z), T(d), noise, white, pytest=True)
+        rs = np.random.RandomState(99)
+        g_rgb = rs.normal(size=(32, 3)).astype(np.float32)
+        g_depth = rs.normal(size=(32,)).astype(np.float32)
+        g_acc = rs.normal(size=(32,)).astype(np.float32)
+        g_disp = rs.normal(size=(32,)).astype(np.float32)
+        loss = (rgb * T(g_rgb)).sum() + (depth * T(g_depth)).sum() + (acc * T(g_acc)).sum()
+        (d_raw,) = torch.autograd.grad(loss, rawt, retain_graph=True)
+        # disparity gradient only over rays with acc>0 (rows 0,1 are acc==0 -> NaN by design)
+        (d_raw_disp,) = torch.autograd.grad((disp[2:] * T(g_disp[2:])).sum(), rawt)
+        save(f"raw2outputs_{tag}", rgb_map=rgb, disp_map=disp, acc_map=acc, weights=weights,
+             depth_map=depth, g_rgb=g_rgb, g_depth=g_depth, g_acc=g_acc, g_disp=g_disp,
+             d_raw=d_raw, d_raw_disp=d_raw_disp)
+
+
+def fx_sample_pdf():
+    captured = {}
+    real = torch.searchsorted
+
+    def spy(cdf, u, right=False, **kw):
+        inds = real(cdf, u, right=right, **kw)
+        captured.update(cdf=cdf.clone(), u=u.clone(), inds=inds.clone())
+        return inds
+
+    for tag, det in (("det", True), ("rand", False)):
+        bins, weights = I.sample_pdf_inputs(256, 64, seed=7)
+        torch.searchsorted = spy
+        try:
+            samples = H.sample_pdf(T(bins), T(weights), 128, det=det, pytest=True)
+        finally:
+            torch.searchsorted = real
+        cdf, u, inds = captured["cdf"], captured["u"], captured["inds"]
+        margin = (u[..., None].double() - cdf[:, None, :].double()).abs().min(-1).values
+        save(f"sample_pdf_{tag}", samples=samples, cdf=cdf, u=u, inds=inds, margin=margin.float())
+
+
+def _render_kwargs(Rmod, coarse, fine, Nc, Nf, perturb, white, noise, lindisp=False):
+    embed_fn, _ = H.get_embedder(10, 0)
+    embeddirs_fn, _ = H.get_embedder(4, 0)
+    q = lambda inputs, viewdirs, network_fn: Rmod.run_network(  # noqa: E731
+        inputs, viewdirs, network_fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn, netchunk=1024 * 64)
+    return dict(network_query_fn=q, perturb=perturb, N_importance=Nf, network_fine=fine,
+                N_samples=Nc, network_fn=coarse, white_bkgd=white, raw_noise_std=noise,
+                lindisp=lindisp)
+
+
+def fx_render_rays():
+    cases = (
+        # tag,     D, W,  Nc, Nf,  perturb, white, noise, lindisp, B
+        ("C1",      4, 128, 64, 0,   1.0, True, 0.0, False, 64),
+        ("C1_noise", 4, 128, 64, 0,  1.0, True, 1.0, False, 32),
+        ("C2",      8, 256, 64, 128, 1.0, False, 0.0, False, 64),
+        ("C2_det",  8, 256, 64, 128, 0.0, False, 0.0, False, 16),
+        ("small_lindisp", 4, 128, 32, 32, 1.0, False, 0.0, True, 32),
+    )
+    for tag, D, W, Nc, Nf, perturb, white, noise, lindisp, B in cases:
+        och = 5 if Nf > 0 else 4
+        coarse = make_model(H, D, W, True, och, seed=21)
+        fine = make_model(H, D, W, True, och, seed=22) if Nf > 0 else None
+        rays = I.ray_batch(B, seed=3)
+        rs = np.random.RandomState(17)
+        target = rs.uniform(size=(B, 3)).astype(np.float32)
+        prior = rs.uniform(2.5, 5.5, size=(B,)).astype(np.float32)
+        far = 6.0
+        kw = _render_kwargs(V, coarse, fine, Nc, Nf, perturb, white, noise, lindisp)
+        ret = V.render_rays(T(rays), retraw=True, pytest=True, **kw)
+        loss = H.img2mse(ret["rgb_map"], T(target)) + H.img2mse(ret["depth_map"] / far, T(prior) / far)
+        if Nf > 0:
+            loss = loss + H.img2mse(ret["rgb0"], T(target)) + H.img2mse(ret["depth0"] / far, T(prior) / far)
+        loss.backward()
+        arrays = {k: v for k, v in ret.items()}
+        arrays.update(target=target, prior=prior, loss=loss.detach())
+        summ = full_grads if W == 128 else grad_summary
+        arrays.update(summ(coarse, "gc."))
+        if fine is not None:
+            arrays.update(summ(fine, "gf."))
+        # the vanilla surface (run_nerf.py) must give the same maps minus the depth keys
+        ret_r = R.render_rays(T(rays), retraw=True, pytest=True,
+                              **_render_kwargs(R, coarse, fine, Nc, Nf, perturb, white, noise, lindisp))
+        assert set(ret_r) == set(ret) - {"depth_map", "depth0"}
+        for k in ret_r:
+            assert torch.equal(torch.nan_to_num(ret_r[k]), torch.nan_to_num(ret[k])), k
+        save(f"render_rays_{tag}", **arrays)
+
+
+def fx_render_full():
+    Hh = Ww = 16
+    K = I.intrinsics(Hh, Ww, 20.0)
+    c2w = I.camera_pose(25.0, -20.0, 4.0)
+    coarse = make_model(H, 4, 128, True, 5, seed=31)
+    fine = make_model(H, 4, 128, True, 5, seed=32)
+    out = {}
+    for ndc in (False, True):
+        kw = _render_kwargs(V, coarse, fine, 16, 16, 0.0, False, 0.0)
+        kw.pop("lindisp")
+        if not ndc:
+            kw["lindisp"] = False
+        with torch.no_grad():
+            near, far = (0.0, 1.0) if ndc else (2.0, 6.0)
+            rgb, disp, acc, depth, extras = V.render(Hh, Ww, K, chunk=100, c2w=T(c2w), ndc=ndc, near=near,
+                                                     far=far, use_viewdirs=True, **kw)
+        sfx = "_ndc" if ndc else ""
+        out.update({f"rgb{sfx}": rgb, f"disp{sfx}": disp, f"acc{sfx}": acc, f"depth{sfx}": depth})
+        out.update({f"{k}{sfx}": v for k, v in extras.items()})
+    ro, rd = H.get_rays(Hh, Ww, K, T(c2w))
+    ro_np, rd_np = H.get_rays_np(Hh, Ww, K, c2w)
+    no, nd = H.ndc_rays(Hh, Ww, float(K[0][0]), 1.0, ro, rd)
+    save("render_full_tiny", K=K, c2w=c2w, rays_o=ro, rays_d=rd, rays_o_np=ro_np, rays_d_np=rd_np,
+         ndc_o=no, ndc_d=nd, **out)
+
+
+def _two_view_scene(Hh, Ww, focal, poses):
+    K = I.intrinsics(Hh, Ww, focal)
+    depths, images = [], []
+    for c2w in poses:
+        d, rgb = I.analytic_scene(Hh, Ww, K, c2w)
+        depths.append(d)
+        images.append(rgb)
+    return K, np.stack(depths), np.stack(images)
+
+
+def fx_warp():
+    Hh, Ww = 32, 40
+    poses = [I.camera_pose(0.0, -15.0, 4.0), I.camera_pose(18.0, -10.0, 4.2)]
+    K, depths, images = _two_view_scene(Hh, Ww, 45.0, poses)
+    tgt, ref = 0, 1
+    ro, rd = H.get_rays(Hh, Ww, K, T(poses[tgt]))
+    P = ro.reshape(-1, 3) + T(depths[tgt]).reshape(-1, 1) * rd.reshape(-1, 3)
+    c2w_ref = torch.eye(4)
+    c2w_ref[:3, :4] = T(poses[ref])
+    w2c_ref = torch.inverse(c2w_ref)
+    img = T(images[ref]).unsqueeze(0).permute(0, 3, 1, 2)
+    dep = T(depths[ref]).unsqueeze(0)
+    Kt = T(K).unsqueeze(0)
+    out = dict(K=K, poses=np.stack(poses), depths=depths, images=images, P=P, w2c_ref=w2c_ref)
+    for tag, mod in (("V", V), ("VT", VT)):
+        rgb_ref, depth_ref, Xc, rays_o, rays_d, mask = mod.get_ref_rays(
+            w2c_ref.unsqueeze(0), c2w_ref.unsqueeze(0), Kt, P[None, :, None, :], img, dep)
+        out.update({f"{tag}.rgb_ref": rgb_ref, f"{tag}.depth_ref": depth_ref, f"{tag}.Xc": Xc,
+                    f"{tag}.rays_o": rays_o, f"{tag}.rays_d": rays_d, f"{tag}.mask": mask})
+    y, x, mask, z = V.get_test_label(w2c_ref.unsqueeze(0), c2w_ref.unsqueeze(0), Kt, P[None, :, None, :], img)
+    out.update({"label.y": y, "label.x": x, "label.mask": mask, "label.z": z})
+    save("warp", **out)
+
+
+def reference_hard_masks(Hh, Ww, K, poses, depths, images, i_train, thr0, chunk=5120):
+    """Drives the reference's own get_ref_rays (run_nerf_view.py:576-627) with the control flow of the
+    mask precompute at run_nerf_view.py:994-1046 (per-5120-pixel chunk, threshold doubled until some
+    pixel of the chunk passes, OR over reference views). Also records the final threshold per
+    (tgt, ref, chunk)."""
+    N = len(poses)
+    masks, thr_log = [], []
+    for t in range(N):
+        if t not in i_train:
+            masks.append(np.zeros((Hh, Ww), bool))
+            continue
+        ro, rd = H.get_rays(Hh, Ww, K, T(poses[t]))
+        ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+        dt = T(depths[t]).reshape(-1)
+        acc = torch.zeros_like(dt)
+        for r in i_train:
+            if r == t:
+                continue
+            mid = torch.zeros_like(dt)
+            c2w = torch.eye(4)
+            c2w[:3, :4] = T(poses[r])
+            w2c = torch.inverse(c2w)
+            nchunks = (dt.shape[0] + chunk - 1) // chunk
+            for c in range(nchunks):
+                sl = slice(c * chunk, (c + 1) * chunk)
+                Pw = ro[sl] + dt[sl, None] * rd[sl]
+                rgb_ref, dep_ref, Xc, _, _, mb = V.get_ref_rays(
+                    w2c.unsqueeze(0), c2w.unsqueeze(0), T(K).unsqueeze(0), Pw[None, :, None, :],
+                    T(images[r]).unsqueeze(0).permute(0, 3, 1, 2), T(depths[r]).unsqueeze(0))
+                thr = float("nan")
+                if mb.sum() != 0:
+                    thr = thr0
+                    while True:
+                        diff = Xc[mb][..., -1].unsqueeze(-1) - dep_ref.squeeze(0).squeeze(0)[:, None]
+                        ok = diff.abs() < thr
+                        if ok.sum() != 0:
+                            break
+                        thr = 2 * thr
+                    new = mb.clone()
+                    new[mb] = ok.squeeze(-1)
+                    mid[sl] = new.squeeze(0).float()
+                thr_log.append((t, r, c, thr))
+            acc += mid
+        masks.append((acc > 0).reshape(Hh, Ww).numpy())
+    return np.stack(masks), np.array(thr_log, np.float64)
+
+
+def fx_hardmask():
+    Hh, Ww = 96, 128
+    poses = [I.camera_pose(0.0, -15.0, 4.0), I.camera_pose(14.0, -12.0, 4.1),
+             I.camera_pose(-16.0, -18.0, 3.9), I.camera_pose(40.0, -10.0, 4.0)]
+    K, depths, images = _two_view_scene(Hh, Ww, 140.0, poses)
+    # view 2's prior is deliberately biased so that some chunks need >= 1 threshold doubling
+    depths[2] = depths[2] + 0.35
+    i_train = [0, 1, 2]   # view 3 is a held-out view -> all-zero mask (V:1043)
+    masks, thr = reference_hard_masks(Hh, Ww, K, poses, depths, images, i_train, 0.1)
+    assert (thr[:, 3] > 0.1).any(), "fixture must exercise the doubling loop"
+    save("hardmask_tiny", K=K, poses=np.stack(poses), depths=depths, images=images,
+         i_train=np.array(i_train), masks=masks, thr=thr)
+
+
+def fx_losses():
+    rs = np.random.RandomState(23)
+    B, far, c = 512, 6.0, 0.2
+    rgb = rs.uniform(size=(B, 3)).astype(np.float32)
+    tgt = rs.uniform(size=(B, 3)).astype(np.float32)
+    dep = rs.uniform(2, 6, size=(B,)).astype(np.float32)
+    pri = rs.uniform(2, 6, size=(B,)).astype(np.float32)
+    m = (rs.uniform(size=(B,)) < 0.6).astype(np.float32)
+    out = dict(rgb=rgb, target=tgt, depth=dep, prior=pri, mask=m, far=far, coef=c)
+    for tag, mm in (("mixed", m), ("allone", np.ones_like(m))):
+        r = T(rgb).requires_grad_(True)
+        d = T(dep).requires_grad_(True)
+        mt = T(mm)
+        # run_nerf_view.py:1645-1648 / 1737 (masked MSEs built from the reference's img2mse)
+        l_rgb = V.img2mse(r[mt == 1], T(tgt)[mt == 1])
+        if mt.sum() != B:
+            l_rgb = l_rgb + c * V.img2mse(r[mt == 0], T(tgt)[mt == 0])
+        l_dep = V.img2mse(d[mt == 1] / far, T(pri)[mt == 1] / far)
+        (l_rgb + l_dep).backward()
+        out.update({f"{tag}.l_rgb": l_rgb.detach(), f"{tag}.l_depth": l_dep.detach(),
+                    f"{tag}.d_rgb": r.grad, f"{tag}.d_depth": d.grad})
+    out["psnr"] = V.mse2psnr(V.img2mse(T(rgb), T(tgt)))
+    save("losses_mask", **out)
+
+
+def fx_train():
+    """10 optimiser steps of the vanilla loop (run_nerf.py:764-788) at C1 shapes, pytest RNG."""
+    with tempfile.TemporaryDirectory() as tmp:
+        os.makedirs(os.path.join(tmp, "exp"))
+        args = argparse.Namespace(
+            multires=10, i_embed=0, use_viewdirs=True, multires_views=4, N_importance=0, netdepth=4,
+            netwidth=128, netdepth_fine=4, netwidth_fine=128, netchunk=1024 * 64, lrate=5e-4,
+            basedir=tmp, expname="exp", ft_path=None, no_reload=True, perturb=1.0, N_samples=64,
+            white_bkgd=True, raw_noise_std=0.0, dataset_type="blender", no_ndc=False, lindisp=False)
+        kw_train, kw_test, start, grad_vars, optimizer = R.create_nerf(args)
+    sd = I.nerf_state_dict(4, 128, 10, 4, 4, True, seed=41)
+    kw_train["network_fn"].load_state_dict({k: T(v) for k, v in sd.items()})
+    kw_train.update(near=2.0, far=6.0)
+    Hh = Ww = 100
+    K = I.intrinsics(Hh, Ww, 138.0)
+    losses, psnrs = [], []
+    lrate_decay, global_step = 250, start
+    for i in range(10):
+        rays = I.ray_batch(256, seed=100 + i)
+        rs = np.random.RandomState(200 + i)
+        target = T(rs.uniform(size=(256, 3)).astype(np.float32))
+        batch_rays = torch.stack([T(rays[:, 0:3]), T(rays[:, 3:6])], 0)
+        rgb, disp, acc, extras = R.render(Hh, Ww, K, chunk=32768, rays=batch_rays, retraw=True,
+                                          pytest=True, **kw_train)
+        optimizer.zero_grad()
+        loss = H.img2mse(rgb, target)
+        losses.append(loss.item())
+        psnrs.append(H.mse2psnr(loss.detach()).item())
+        loss.backward()
+        optimizer.step()
+        new_lrate = args.lrate * (0.1 ** (global_step / (lrate_decay * 1000)))
+        for g in optimizer.param_groups:
+            g["lr"] = new_lrate
+        global_step += 1
+    final = {f"final.{k}": v for k, v in kw_train["network_fn"].state_dict().items()}
+    save("train_10steps_C1", losses=np.array(losses), psnrs=np.array(psnrs),
+         test_perturb=np.array(float(kw_test["perturb"])), **final)
+
+
+def fx_pairs():
+    """Decoded split lists of configs/pairs.th (numpy-only pickle)."""
+    import pickle
+    import zipfile
+    p = os.path.join(REF, "configs", "pairs.th")
+    with zipfile.ZipFile(p) as zf:
+        name = [n for n in zf.namelist() if n.endswith("data.pkl")][0]
+        raw = zf.read(name)
+
+    class U(pickle.Unpickler):
+        def find_class(self, module, name):
+            if module.split(".")[0] in ("numpy", "collections", "_codecs"):
+                return super().find_class(module, name)
+            raise pickle.UnpicklingError(f"blocked {module}.{name}")
+
+        def persistent_load(self, pid):
+            raise pickle.UnpicklingError("no tensors expected")
+    import io
+    d = U(io.BytesIO(raw)).load()
+    save("pairs", **{k: np.asarray(v) for k, v in d.items()})
+
+
+ALL = dict(embed=fx_embed, mlp=fx_mlp, raw2outputs=fx_raw2outputs, sample_pdf=fx_sample_pdf,
+           render_rays=fx_render_rays, render_full=fx_render_full, warp=fx_warp, hardmask=fx_hardmask,
+           losses=fx_losses, train=fx_train, pairs=fx_pairs)
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", nargs="*", default=None)
+    a = ap.parse_args()
+    for name, fn in ALL.items():
+        if a.only and name not in a.only:
+            continue
+        print(f"[{name}]")
+        fn()
