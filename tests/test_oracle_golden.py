@@ -1,0 +1,213 @@
+"""Pins oracle/nerf_oracle.py against the golden vectors captured from the reference
+(tests/golden/make_golden.py).  CPU only.  Where the oracle repeats the reference's ATen op
+sequence the comparison is bit-exact; gradients go through a differently-shaped autograd graph and
+get a 1e-6-relative bound."""
+import numpy as np
+import pytest
+import torch
+
+import _inputs as I
+from conftest import golden
+from oracle import nerf_oracle as O
+
+torch.set_num_threads(4)
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def eq(a, b, name=""):
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    assert a.shape == b.shape, (name, a.shape, b.shape)
+    assert np.array_equal(a, b, equal_nan=True), f"{name}: max|d|={np.nanmax(np.abs(a.astype(np.float64)-b))}"
+
+
+def close(a, b, rtol=2e-6, atol=1e-7, name=""):
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, err_msg=name, equal_nan=True)
+
+
+def test_embed():
+    g = golden("embed")
+    eq(O.embed(T(g["x"]), 10), g["L10"])
+    eq(O.embed(T(g["x"]), 4), g["L4"])
+
+
+MLP_CASES = [("D8W256_vd", 8, 256, True, 5), ("D4W128_vd", 4, 128, True, 4),
+             ("D4W128_novd", 4, 128, False, 5), ("D8W128_vd", 8, 128, True, 5)]
+
+
+def check_grads(g, prefix_full, prefix_sum, sd, rtol=2e-5):
+    for k, p in sd.items():
+        gr = p.grad if p.grad is not None else torch.zeros_like(p)
+        if prefix_full + k in g:
+            ref = g[prefix_full + k]
+            scale = max(np.abs(ref).max(), 1e-30)
+            assert np.abs(gr.numpy() - ref).max() <= rtol * scale + 1e-9, k
+        else:
+            ref = g[prefix_sum + k + ".sub"]
+            scale = max(np.abs(ref).max(), 1e-30)
+            assert np.abs(gr.reshape(-1)[::61].numpy() - ref).max() <= rtol * scale + 1e-9, k
+            a = g[prefix_sum + k + ".abssum"]
+            assert abs(gr.double().abs().sum().item() - a) <= 1e-5 * max(a, 1e-30) + 1e-9, k
+
+
+@pytest.mark.parametrize("tag,D,W,vd,och", MLP_CASES)
+def test_query(tag, D, W, vd, och):
+    g = golden("mlp_" + tag)
+    sd = O.as_tensors(I.nerf_state_dict(D, W, 10, 4, och, vd, seed=11), requires_grad=True)
+    cfg = O.NetCfg(D=D, W=W, use_viewdirs=vd, output_ch=och)
+    raw = O.query(sd, T(g["pts"]), T(g["dirs"]) if vd else None, cfg)
+    # GEMM blocking differs with the reference's netchunk / thread count -> ulp-level differences
+    close(raw, g["raw"], rtol=1e-5, atol=3e-6, name="raw")
+    (raw * T(g["G"])).sum().backward()
+    check_grads(g, "grad.", "gs.", sd)
+
+
+R2O = [("S64", 64, False, 0.0), ("S192", 192, False, 0.0), ("S64_white", 64, True, 0.0),
+       ("S192_white_noise", 192, True, 1.0)]
+
+
+@pytest.mark.parametrize("tag,S,white,noise", R2O)
+def test_composite(tag, S, white, noise):
+    g = golden("raw2outputs_" + tag)
+    raw, z, d = I.raw2outputs_inputs(32, S, seed=S + int(white))
+    rawt = T(raw).requires_grad_(True)
+    nz = O.pytest_uniform((32, S)) * noise if noise > 0 else None
+    rgb, disp, acc, w, depth = O.composite(rawt, T(z), T(d), nz, white)
+    for a, k in ((rgb, "rgb_map"), (disp, "disp_map"), (acc, "acc_map"), (w, "weights"), (depth, "depth_map")):
+        eq(a, g[k], k)
+    if noise == 0:
+        assert np.isnan(g["disp_map"][:2]).all()      # acc==0 rows: reference returns NaN
+    loss = (rgb * T(g["g_rgb"])).sum() + (depth * T(g["g_depth"])).sum() + (acc * T(g["g_acc"])).sum()
+    (d_raw,) = torch.autograd.grad(loss, rawt, retain_graph=True)
+    close(d_raw, g["d_raw"], rtol=1e-5, atol=1e-7)
+    (dd,) = torch.autograd.grad((disp[2:] * T(g["g_disp"][2:])).sum(), rawt)
+    close(dd, g["d_raw_disp"], rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("tag", ["det", "rand"])
+def test_sample_pdf(tag):
+    g = golden("sample_pdf_" + tag)
+    bins, weights = I.sample_pdf_inputs(256, 64, seed=7)
+    samples, inds = O.sample_pdf(T(bins), T(weights), T(g["u"]))
+    eq(inds, g["inds"], "inds")            # the bit-exact target
+    eq(samples, g["samples"], "samples")
+    if tag == "rand":
+        eq(O.pytest_uniform((256, 128)), g["u"], "u stream")
+
+
+RR = [("C1", 4, 128, 64, 0, 1.0, True, 0.0, False, 64), ("C1_noise", 4, 128, 64, 0, 1.0, True, 1.0, False, 32),
+      ("C2", 8, 256, 64, 128, 1.0, False, 0.0, False, 64), ("C2_det", 8, 256, 64, 128, 0.0, False, 0.0, False, 16),
+      ("small_lindisp", 4, 128, 32, 32, 1.0, False, 0.0, True, 32)]
+
+
+@pytest.mark.parametrize("tag,D,W,Nc,Nf,perturb,white,noise,lindisp,B", RR)
+def test_render_rays(tag, D, W, Nc, Nf, perturb, white, noise, lindisp, B):
+    g = golden("render_rays_" + tag)
+    och = 5 if Nf > 0 else 4
+    sdc = O.as_tensors(I.nerf_state_dict(D, W, 10, 4, och, True, seed=21), True)
+    sdf = O.as_tensors(I.nerf_state_dict(D, W, 10, 4, och, True, seed=22), True) if Nf > 0 else None
+    net = O.NetCfg(D=D, W=W, output_ch=och)
+    cfg = O.RenderCfg(Nc, Nf, perturb, lindisp, white, noise)
+    out = O.render_rays_pytest(T(I.ray_batch(B, seed=3)), sdc, sdf, net, cfg)
+    keys = ["rgb_map", "disp_map", "acc_map", "depth_map", "raw"] + (
+        ["rgb0", "disp0", "acc0", "depth0", "z_std"] if Nf > 0 else [])
+    for k in keys:
+        close(out[k], g[k], rtol=2e-5, atol=5e-6, name=k)
+    far = 6.0
+    loss = O.mse(out["rgb_map"], T(g["target"])) + O.mse(out["depth_map"] / far, T(g["prior"]) / far)
+    if Nf > 0:
+        loss = loss + O.mse(out["rgb0"], T(g["target"])) + O.mse(out["depth0"] / far, T(g["prior"]) / far)
+    close(loss, g["loss"], rtol=1e-5, name="loss")
+    loss.backward()
+    check_grads(g, "gc.", "gc.", sdc)
+    if sdf is not None:
+        check_grads(g, "gf.", "gf.", sdf)
+
+
+def test_rays_and_full_render():
+    g = golden("render_full_tiny")
+    K, c2w = g["K"], T(g["c2w"])
+    ro, rd = O.get_rays(16, 16, K, c2w)
+    eq(ro, g["rays_o"]); eq(rd, g["rays_d"])
+    ron, rdn = O.get_rays_np(16, 16, K, g["c2w"])
+    eq(ron, g["rays_o_np"]); eq(rdn, g["rays_d_np"])
+    no, nd = O.ndc_rays(16, 16, float(K[0][0]), 1.0, ro, rd)
+    eq(no, g["ndc_o"]); eq(nd, g["ndc_d"])
+    sdc = O.as_tensors(I.nerf_state_dict(4, 128, 10, 4, 5, True, seed=31))
+    sdf = O.as_tensors(I.nerf_state_dict(4, 128, 10, 4, 5, True, seed=32))
+    net = O.NetCfg(D=4, W=128, output_ch=5)
+    for ndc in (False, True):
+        near, far = (0.0, 1.0) if ndc else (2.0, 6.0)
+        rays = O.build_ray_batch(ro, rd, near, far, True, ndc, 16, 16, float(K[0][0]))
+        with torch.no_grad():
+            out = O.render_rays_pytest(rays, sdc, sdf, net, O.RenderCfg(16, 16, 0.0))
+        sfx = "_ndc" if ndc else ""
+        for k, gk in (("rgb_map", "rgb"), ("disp_map", "disp"), ("acc_map", "acc"), ("depth_map", "depth"),
+                      ("rgb0", "rgb0"), ("depth0", "depth0"), ("z_std", "z_std")):
+            close(out[k].reshape(g[gk + sfx].shape), g[gk + sfx], rtol=2e-5, atol=5e-6, name=gk + sfx)
+
+
+def test_warp():
+    g = golden("warp")
+    K = T(g["K"]); P = T(g["P"]); w2c = T(g["w2c_ref"])
+    c2w = torch.eye(4); c2w[:3, :4] = T(g["poses"][1])
+    img = T(g["images"][1]).permute(2, 0, 1); dep = T(g["depths"][1])
+    for tag, flip, masked in (("V", True, False), ("VT", False, True)):
+        rgb, d, Xc, ro, rd, inb = O.get_ref_rays(w2c, c2w, K, P, img, dep, flip, masked)
+        eq(rgb, g[tag + ".rgb_ref"][0]); eq(d, g[tag + ".depth_ref"][0, 0])
+        eq(Xc, g[tag + ".Xc"][0] if not masked else g[tag + ".Xc"])
+        eq(ro, g[tag + ".rays_o"]); eq(rd, g[tag + ".rays_d"]); eq(inb, g[tag + ".mask"][0])
+    Xc, x, y, inb = O.warp_points(P, w2c, K, 32, 40, True)
+    eq(y, g["label.y"][0]); eq(x, g["label.x"][0]); eq(inb, g["label.mask"][0]); eq(Xc[:, 2], g["label.z"][0])
+
+
+def test_hard_masks():
+    g = golden("hardmask_tiny")
+    masks, thr = O.hard_masks(96, 128, g["K"], g["poses"], g["depths"], list(g["i_train"]))
+    eq(masks, g["masks"])
+    assert np.array_equal(thr, g["thr"], equal_nan=True)
+    assert not g["masks"][3].any() and (g["thr"][:, 3] > 0.1).any()
+
+
+def test_masked_losses():
+    g = golden("losses_mask")
+    far, c = float(g["far"]), float(g["coef"])
+    for tag, m in (("mixed", g["mask"]), ("allone", np.ones_like(g["mask"]))):
+        r = T(g["rgb"]).requires_grad_(True); d = T(g["depth"]).requires_grad_(True)
+        lr = O.masked_rgb_loss(r, T(g["target"]), T(m), c)
+        ld = O.masked_depth_loss(d, T(g["prior"]), T(m), far)
+        eq(lr, g[tag + ".l_rgb"]); eq(ld, g[tag + ".l_depth"])
+        (lr + ld).backward()
+        eq(r.grad, g[tag + ".d_rgb"]); eq(d.grad, g[tag + ".d_depth"])
+    eq(O.psnr_from_mse(O.mse(T(g["rgb"]), T(g["target"]))), g["psnr"])
+
+
+def test_train_10_steps():
+    """Optimiser wiring: Adam(0.9,0.999,1e-8) + per-step exponential lr (R:768-788)."""
+    g = golden("train_10steps_C1")
+    sd = O.as_tensors(I.nerf_state_dict(4, 128, 10, 4, 4, True, seed=41), True)
+    net = O.NetCfg(D=4, W=128, output_ch=4)
+    cfg = O.RenderCfg(64, 0, 1.0, False, True, 0.0)
+    m = {k: torch.zeros_like(v) for k, v in sd.items()}
+    v = {k: torch.zeros_like(p) for k, p in sd.items()}
+    lr = 5e-4
+    for i in range(10):
+        rays = T(I.ray_batch(256, seed=100 + i))
+        target = T(np.random.RandomState(200 + i).uniform(size=(256, 3)).astype(np.float32))
+        out = O.render_rays_pytest(rays, sd, None, net, cfg)
+        loss = O.mse(out["rgb_map"], target)
+        assert abs(loss.item() - g["losses"][i]) <= 2e-6 * g["losses"][i], (i, loss.item(), g["losses"][i])
+        grads = torch.autograd.grad(loss, [p for p in sd.values()], allow_unused=True)
+        with torch.no_grad():
+            for (k, p), gr in zip(sd.items(), grads):
+                if gr is None:
+                    continue   # temp_rgb / temp_depth / depth_scale and the unused view branch bits
+                O.adam_step(p, gr, m[k], v[k], i + 1, lr)
+        lr = O.lr_at(5e-4, i, 250)
+    for k, p in sd.items():
+        ref = g["final." + k]
+        assert np.abs(p.detach().numpy() - ref).max() <= 5e-6, k
+    assert float(g["test_perturb"]) == 0.0
