@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py — training ray-samples/sec of the MI355X NeRF hot path (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+One "step" = one full optimisation step of BASELINE config C2 on synthetic DTU-like data, per GPU:
+4096 rays -> coarse 64 samples -> fine 64+128 samples (D=8/W=256 MLPs with view directions, stratified
+jitter, hierarchical resampling) -> mse(rgb)+mse(rgb0) -> backward (dgrad+wgrad of both nets) ->
+[N>1: one RCCL all-reduce of the flat fp32 gradient] -> Adam + lr decay.  1 048 576 ray-samples per GPU per
+step (64 + 192 network evaluations per ray); weak scaling (every rank renders its own 4096-ray
+slice of the global batch).  Inputs (ray bank, targets, weights) are resident in HBM before the timed region.
+
+Extra objects on the JSON line:
+  roofline     — dominant kernel of the step, algorithmic FLOPs per launch / its average duration measured
+                 with HIP events on the launch stream inside the timed region; peak = fp32 MFMA 157.3 TFLOP/s.
+  cpu_baseline — the CPU oracle ("port" of the reference step: stock ATen, fp32) timed on this host's cores on
+                 a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests", "golden")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+MAC_FWD, MAC_DGRAD, MAC_WGRAD = 593408, 557696, 593408   # per ray-sample, D=8/W=256/viewdirs
+PEAK_FP32_MFMA_TFLOPS = 157.3                              # MI355X_MICROARCH.md
+B_PER_GPU, NC, NF = 4096, 64, 128
+H_IMG, W_IMG, FOCAL, NEAR, FAR = 512, 640, 1446.0, 2.125, 4.67   # DTU-like
+
+
+def make_args(tmpdir):
+    return argparse.Namespace(
+        multires=10, i_embed=0, use_viewdirs=True, multires_views=4, N_importance=NF, netdepth=8, netwidth=256,
+        netdepth_fine=8, netwidth_fine=256, netchunk=1024 * 64, lrate=5e-4, basedir=tmpdir, expname="bench",
+        ft_path=None, no_reload=True, perturb=1.0, N_samples=NC, white_bkgd=False, raw_noise_std=0.0,
+        dataset_type="dtu", no_ndc=True, lindisp=False)
+
+
+def build_ray_bank(device, seed=0):
+    """3 DTU-like views on a ring of radius 3 -> [3*H*W, 11] rays + U[0,1) targets, shuffled with a fixed seed
+    (identical on every rank)."""
+    import _inputs as I
+    from consistentnerf_amd import ops
+    K = I.intrinsics(H_IMG, W_IMG, FOCAL)
+    banks = [ops.gen_rays(H_IMG, W_IMG, K, I.camera_pose(th, -20.0, 3.0), NEAR, FAR, True, False, device)
+             for th in (0.0, 25.0, -25.0)]
+    rays = torch.cat(banks, 0)
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    perm = torch.randperm(rays.shape[0], generator=g).to(device)
+    rays = rays[perm].contiguous()
+    target = torch.rand(rays.shape[0], 3, generator=torch.Generator(device="cpu").manual_seed(seed + 1)).to(device)
+    return K, rays, target
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """The CPU oracle's training step (same workload shape, B=256 rays) on this host's cores."""
+    import _inputs as I
+    from oracle import nerf_oracle as O
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    Bc = 256
+    sd = [O.as_tensors(I.nerf_state_dict(8, 256, 10, 4, 5, True, seed=s), True) for s in (21, 22)]
+    net, cfg = O.NetCfg(8, 256, output_ch=5), O.RenderCfg(NC, NF, 1.0)
+    rays = torch.from_numpy(I.ray_batch(Bc, seed=3, near=NEAR, far=FAR))
+    target = torch.rand(Bc, 3)
+    params = [p for d in sd for p in d.values()]
+    m = [torch.zeros_like(p) for p in params]
+    v = [torch.zeros_like(p) for p in params]
+
+    def step(i):
+        out = O.render_rays(rays, sd[0], sd[1], net, cfg, torch.rand(Bc, NC), torch.rand(Bc, NF))
+        loss = O.mse(out["rgb_map"], target) + O.mse(out["rgb0"], target)
+        grads = torch.autograd.grad(loss, params, allow_unused=True)
+        with torch.no_grad():
+            for p, g, mm, vv in zip(params, grads, m, v):
+                if g is not None:
+                    O.adam_step(p, g, mm, vv, i + 1, 5e-4)
+    step(0)
+    t0, n = time.perf_counter(), 0
+    while n < 3 or (time.perf_counter() - t0 < seconds_budget and n < 20):
+        step(n + 1)
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    return {"value": Bc * (NC + NC + NF) / dt, "unit": "ray-samples/s", "cores": ncores, "kind": "port",
+            "sample": f"{n} training steps of {Bc} rays (same C2 shapes: 64+192 samples, D=8/W=256, fwd+bwd+Adam), "
+                      f"{dt:.2f} s/step, torch {torch.__version__} CPU fp32, {ncores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch.distributed as dist
+    from consistentnerf_amd import distributed as D, ops
+    from consistentnerf_amd import run_nerf as R
+    rank, world, local = D.init_from_env("nccl" if a.gpus > 1 else None)
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    ok, name, cus, _ = ops.device_info(local)
+
+    import tempfile
+    torch.manual_seed(1234)                       # identical init on every rank (replicated weights)
+    with tempfile.TemporaryDirectory() as tmp:
+        kw_train, _, start, grad_vars, optimizer = R.create_nerf(make_args(tmp))
+    kw_train.update(near=NEAR, far=FAR)
+    K, bank, targets = build_ray_bank(dev)
+    nbank = bank.shape[0]
+    torch.manual_seed(99 + rank)                  # per-rank jitter streams (RegNeRF/train.py:364-365 precedent)
+    gstep = B_PER_GPU * world
+
+    def step(i):
+        lo = (i * gstep + rank * B_PER_GPU) % (nbank - B_PER_GPU)
+        rays, tgt = bank[lo:lo + B_PER_GPU], targets[lo:lo + B_PER_GPU]
+        rays_od = torch.stack([rays[:, 0:3], rays[:, 3:6]], 0)
+        rgb, disp, acc, extras = R.render(H_IMG, W_IMG, K, chunk=32768, rays=rays_od, retraw=True, **kw_train)
+        optimizer.zero_grad()
+        loss = R.img2mse(rgb, tgt) + R.img2mse(extras['rgb0'], tgt)
+        loss.backward()
+        D.allreduce_mean_(optimizer.flat_grad)
+        optimizer.step()
+        lr = 5e-4 * (0.1 ** (i / (250 * 1000)))
+        for pg in optimizer.param_groups:
+            pg['lr'] = lr
+        return loss
+
+    for i in range(a.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    D.barrier()
+    torch.cuda.synchronize()
+    ops.PROFILE = []
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        loss = step(a.warmup + i)
+    torch.cuda.synchronize()
+    D.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    final_loss = loss.item()
+
+    # live per-kernel timing (HIP events on the launch stream, inside the timed region)
+    kern = {}
+    for nme, units, e0, e1 in prof:
+        k = kern.setdefault((nme, units), [0.0, 0])
+        k[0] += e0.elapsed_time(e1)
+        k[1] += 1
+    flops = {"mlp_fwd_train": 2 * MAC_FWD, "mlp_fwd": 2 * MAC_FWD, "mlp_dgrad": 2 * MAC_DGRAD, "mlp_wgrad": 2 * MAC_WGRAD}
+    table = []
+    for (nme, units), (ms, n) in kern.items():
+        avg_ms = ms / n
+        table.append({"kernel": nme, "points": units, "launches": n, "avg_ms": round(avg_ms, 4),
+                      "tflops": round(flops[nme] * units / (avg_ms * 1e-3) / 1e12, 2),
+                      "share_of_step": round(ms / (elapsed * 1e3), 4)})
+    table.sort(key=lambda r: -r["avg_ms"] * r["launches"])
+    dom = table[0]
+    roofline = {"bound": "mfma", "kernel": f'{dom["kernel"]} (M={dom["points"]} points)', "achieved": dom["tflops"],
+                "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(dom["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4),
+                "traffic": None, "avg_launch_ms": dom["avg_ms"], "kernels": table}
+
+    if rank == 0:
+        samples_per_step = B_PER_GPU * (NC + NC + NF) * world
+        out = {
+            "metric": "train_ray_samples_per_sec", "value": samples_per_step * a.steps / elapsed,
+            "unit": "ray-samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "DTU scan8 3-view (synthetic 512x640 ray bank), 4096 rays/GPU/step, coarse 64 + "
+                                   "fine 64+128 samples, D=8 W=256 viewdirs MLPs (random init), perturb=1, "
+                                   "mse(rgb)+mse(rgb0), backward, Adam; BASELINE configs[1] (configs[3] when N>1)",
+                       "rays_per_gpu": B_PER_GPU, "ray_samples_per_ray": NC + NC + NF, "device": name, "cus": cus,
+                       "parallelism": f"ray-shard dp{world}" + (", RCCL all-reduce of the flat fp32 grad" if world > 1 else ""),
+                       "final_loss": final_loss},
+            "roofline": roofline,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,91 @@
+"""ctypes binding of libcnerf_hip.so (include/cnerf.h).  There is NO fallback: if the library is
+missing or a call fails, this raises — the product path never routes through CPU code."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcnerf_hip.so")
+MAX_TENSORS = 48
+
+
+class CnerfError(RuntimeError):
+    pass
+
+
+class Net(C.Structure):
+    """struct cnerf_net"""
+    _fields_ = [("D", C.c_int32), ("W", C.c_int32), ("multires", C.c_int32), ("multires_views", C.c_int32),
+                ("use_viewdirs", C.c_int32), ("output_ch", C.c_int32), ("skip", C.c_int32)]
+
+
+class Ptrs(C.Structure):
+    """struct cnerf_ptrs"""
+    _fields_ = [("p", C.c_void_p * MAX_TENSORS)]
+
+
+_vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+_NetP, _PtrsP = C.POINTER(Net), C.POINTER(Ptrs)
+
+# name -> (restype, argtypes); every symbol include/cnerf.h declares
+SIGNATURES = {
+    "cnerf_abi_version": (_i, []),
+    "cnerf_strerror": (C.c_char_p, [_i]),
+    "cnerf_device_info": (_i, [_i, C.c_char_p, C.POINTER(_i), C.POINTER(_i)]),
+    "cnerf_num_tensors": (_i, [_NetP]),
+    "cnerf_tensor_shape": (_i, [_NetP, _i, C.POINTER(_i64), C.POINTER(_i64)]),
+    "cnerf_packed_floats": (_i64, [_NetP]),
+    "cnerf_pack_weights": (_i, [_NetP, _PtrsP, _vp, _vp]),
+    "cnerf_coarse_z": (_i, [_vp, _i, _i64, _i, _vp, _vp, _i, _vp, _vp]),
+    "cnerf_embed": (_i, [_vp, _i64, _i, _vp, _vp]),
+    "cnerf_mlp_stash_floats": (_i64, [_NetP, _i64]),
+    "cnerf_mlp_fwd": (_i, [_NetP, _vp, _vp, _vp, _i, _vp, _vp, _i64, _i, _vp, _vp, _vp]),
+    "cnerf_mlp_bwd_ws_floats": (_i64, [_NetP, _i64]),
+    "cnerf_mlp_bwd": (_i, [_NetP, _vp, _vp, _i64, _i, _vp, _vp, _PtrsP, _i, _vp]),
+    "cnerf_mlp_dgrad": (_i, [_NetP, _vp, _vp, _i64, _i, _vp, _vp, _vp]),
+    "cnerf_mlp_wgrad": (_i, [_NetP, _i64, _i, _vp, _vp, _PtrsP, _i, _vp]),
+    "cnerf_composite_fwd": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cnerf_composite_bwd": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cnerf_sample_pdf": (_i, [_vp, _vp, _vp, _i64, _i64, _i, _i, _vp, _vp, _vp]),
+    "cnerf_resample": (_i, [_vp, _vp, _vp, _i64, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "cnerf_gen_rays": (_i, [_i, _i, _f, _f, _f, _f, C.POINTER(_f), _f, _f, _i, _i, _f, _f, _vp, _vp]),
+    "cnerf_pack_rays": (_i, [_vp, _vp, _i64, _f, _f, _i, _i, _f, _f, _vp, _vp]),
+    "cnerf_warp_points": (_i, [_vp, _i64, C.POINTER(_f), _f, _f, _f, _f, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "cnerf_hard_mask_pair": (_i, [_i, _i, _f, _f, _f, _f, C.POINTER(_f), C.POINTER(_f), _vp, _vp, _f, _i, _vp,
+                                  _vp, _vp]),
+    "cnerf_loss_ws_floats": (_i64, []),
+    "cnerf_masked_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
+    "cnerf_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _f, _f, _f, _f, _f, _f, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and type the library.  torch is imported first so that our NEEDED libamdhip64.so.7
+    resolves to the HIP runtime torch already mapped (one runtime per process: streams and device
+    pointers are shared)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  (must precede the dlopen, see docstring)
+    if not os.path.exists(LIB_PATH):
+        raise CnerfError(
+            f"{LIB_PATH} is missing: build it with `python -m consistentnerf_amd.build` "
+            "(hipcc --offload-arch=gfx950).  consistentnerf_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise CnerfError(f"libcnerf_hip.so does not export {name}") from e
+        fn.restype, fn.argtypes = res, args
+    if lib.cnerf_abi_version() != 1:
+        raise CnerfError("libcnerf_hip.so ABI version mismatch; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().cnerf_strerror(rc).decode()
+        raise CnerfError(f"{what} failed: {msg} (code {rc})")

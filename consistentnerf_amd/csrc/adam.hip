@@ -1,0 +1,37 @@
+// Optimiser tail in one launch over a flat parameter buffer: clip_grad_value_ (V:1983) + Adam with
+// betas (0.9, 0.999), eps 1e-8 (R:210, R:780); the caller passes the decayed lr of R:784-788.
+// Arithmetic follows torch.optim.Adam's single-tensor path (lerp / addcmul / sqrt / addcdiv).
+#include <math.h>
+
+#include "common.hpp"
+
+namespace {
+__global__ void adam_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                       float* __restrict__ v, int64_t n, float w1, float beta2, float w2, float step_size,
+                       float bc2_sqrt, float eps, float clip, float gscale) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float gi = g[i] * gscale;
+    if (clip > 0.f) gi = fminf(fmaxf(gi, -clip), clip);
+    const float mi = m[i] + w1 * (gi - m[i]);               // exp_avg.lerp_(grad, 1-beta1)
+    const float vi = v[i] * beta2 + w2 * (gi * gi);         // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1-beta2)
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    m[i] = mi; v[i] = vi;
+    p[i] = p[i] - step_size * (mi / denom);                 // param.addcdiv_(exp_avg, denom, -step_size)
+  }
+}
+}  // namespace
+
+extern "C" int cnerf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr,
+                               float beta1, float beta2, float eps, float clip, float grad_scale, void* stream) {
+  if (!p || !g || !m || !v || n < 0 || step < 1) return CNERF_E_ARG;
+  if (n == 0) return CNERF_OK;
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+  int64_t blocks = cn_div_up(n, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(adam_k, dim3((unsigned)blocks), dim3(256), 0, cn_stream(stream), p, g, m, v, n,
+                     (float)(1.0 - (double)beta1), beta2, (float)(1.0 - (double)beta2), step_size, bc2_sqrt, eps,
+                     clip, grad_scale);
+  CN_CHECK_LAUNCH();
+  return CNERF_OK;
+}

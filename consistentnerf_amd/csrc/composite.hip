@@ -1,0 +1,246 @@
+// Alpha compositing along rays (raw2outputs, reference R:265-308 / V:392-438) and its backward.
+// One wave64 per ray: lane l owns the C = ceil(S/64) consecutive samples [l*C, l*C+C).  The exclusive
+// transmittance product is a lane-local sequential product + one wave scan, carried in fp64 and
+// rounded to fp32 per sample (the CPU reference's cumprod accumulates fp32 inputs in fp64).
+// HBM-bound: 24 B per ray-sample forward (raw 16 + z 4 in, weights 4 out), 40 B backward.
+#include "common.hpp"
+
+namespace {
+
+constexpr int WAVES = 4;
+
+struct Sample {
+  float e;      // exp(-relu(sigma)*dist)
+  float alpha;  // 1 - e
+  float x;      // 1 - alpha + 1e-10   (factor of the transmittance product)
+  float r, g, b;  // sigmoid colours
+  float z, dist, sig;
+  bool live;
+};
+
+template <int C>
+__device__ __forceinline__ void load_samples(Sample (&sm)[C], const float* __restrict__ raw, int ch,
+                                             const float* __restrict__ zrow, const float* __restrict__ nrow,
+                                             float dnorm, int S, int lane) {
+#pragma unroll
+  for (int j = 0; j < C; ++j) {
+    const int s = lane * C + j;
+    Sample& q = sm[j];
+    q.live = s < S;
+    if (!q.live) {
+      q.e = 1.f; q.alpha = 0.f; q.x = 1.f; q.r = q.g = q.b = 0.f; q.z = 0.f; q.dist = 0.f; q.sig = 0.f;
+      continue;
+    }
+    float c0, c1, c2, sg;
+    if (ch == 4) {
+      const float4 v = *reinterpret_cast<const float4*>(raw + (int64_t)s * 4);
+      c0 = v.x; c1 = v.y; c2 = v.z; sg = v.w;
+    } else {
+      const float* p = raw + (int64_t)s * ch;
+      c0 = p[0]; c1 = p[1]; c2 = p[2]; sg = p[3];
+    }
+    q.z = zrow[s];
+    float d = (s + 1 < S) ? (zrow[s + 1] - q.z) : 1e10f;   // R:280-281
+    q.dist = d * dnorm;                                      // R:283
+    if (nrow) sg = sg + nrow[s];                             // R:296
+    q.sig = sg;
+    const float act = sg > 0.f ? sg : 0.f;
+    q.e = expf(-act * q.dist);
+    q.alpha = 1.f - q.e;
+    q.x = 1.f - q.alpha + 1e-10f;                            // R:298
+    q.r = 1.f / (1.f + expf(-c0));
+    q.g = 1.f / (1.f + expf(-c1));
+    q.b = 1.f / (1.f + expf(-c2));
+  }
+}
+
+// exclusive product scan over all samples of the ray; T[j] = fp32(prod_{k<s} x_k)
+template <int C>
+__device__ __forceinline__ void transmittance(const Sample (&sm)[C], float (&T)[C], int lane) {
+  double p = 1.0;
+#pragma unroll
+  for (int j = 0; j < C; ++j) p *= (double)sm[j].x;
+  double incl = p;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    double v = __shfl_up(incl, o, 64);
+    if (lane >= o) incl *= v;
+  }
+  double run = __shfl_up(incl, 1, 64);
+  if (lane == 0) run = 1.0;
+#pragma unroll
+  for (int j = 0; j < C; ++j) {
+    T[j] = (float)run;
+    run *= (double)sm[j].x;
+  }
+}
+
+__device__ __forceinline__ float ray_norm(const float* __restrict__ ray) {
+  const float dx = ray[3], dy = ray[4], dz = ray[5];
+  return sqrtf(dx * dx + dy * dy + dz * dz);
+}
+
+template <int C>
+__global__ __launch_bounds__(WAVES * 64) void composite_fwd_k(const float* __restrict__ raw, int ch,
+                                                              const float* __restrict__ z,
+                                                              const float* __restrict__ rays, int rs,
+                                                              const float* __restrict__ noise, int64_t B, int S,
+                                                              int white, float* __restrict__ rgb,
+                                                              float* __restrict__ disp, float* __restrict__ acc,
+                                                              float* __restrict__ depth, float* __restrict__ weights) {
+  const int lane = threadIdx.x & 63;
+  const int64_t b = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
+  if (b >= B) return;
+  Sample sm[C];
+  float T[C];
+  load_samples<C>(sm, raw + b * S * ch, ch, z + b * S, noise ? noise + b * S : nullptr, ray_norm(rays + b * rs), S,
+                  lane);
+  transmittance<C>(sm, T, lane);
+  double sr = 0, sg = 0, sb = 0, sd = 0, sa = 0;
+#pragma unroll
+  for (int j = 0; j < C; ++j) {
+    const float w = sm[j].alpha * T[j];
+    if (sm[j].live) {
+      if (weights) weights[b * S + lane * C + j] = w;
+      sr += (double)(w * sm[j].r);
+      sg += (double)(w * sm[j].g);
+      sb += (double)(w * sm[j].b);
+      sd += (double)(w * sm[j].z);
+      sa += (double)w;
+    }
+  }
+  sr = wave_sum(sr); sg = wave_sum(sg); sb = wave_sum(sb); sd = wave_sum(sd); sa = wave_sum(sa);
+  if (lane == 0) {
+    const float fa = (float)sa, fd = (float)sd;
+    float r = (float)sr, g = (float)sg, bl = (float)sb;
+    if (white) { const float bg = 1.f - fa; r += bg; g += bg; bl += bg; }   // R:305-306
+    if (rgb) { rgb[b * 3 + 0] = r; rgb[b * 3 + 1] = g; rgb[b * 3 + 2] = bl; }
+    if (acc) acc[b] = fa;
+    if (depth) depth[b] = fd;
+    if (disp) {
+      const float q = fd / fa;                          // 0/0 -> NaN propagates like torch.max (R:302)
+      disp[b] = (q != q) ? q : 1.f / fmaxf(1e-10f, q);
+    }
+  }
+}
+
+template <int C>
+__global__ __launch_bounds__(WAVES * 64) void composite_bwd_k(const float* __restrict__ raw, int ch,
+                                                              const float* __restrict__ z,
+                                                              const float* __restrict__ rays, int rs,
+                                                              const float* __restrict__ noise, int64_t B, int S,
+                                                              int white, const float* __restrict__ g_rgb,
+                                                              const float* __restrict__ g_disp,
+                                                              const float* __restrict__ g_acc,
+                                                              const float* __restrict__ g_depth,
+                                                              float* __restrict__ d_raw) {
+  const int lane = threadIdx.x & 63;
+  const int64_t b = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
+  if (b >= B) return;
+  Sample sm[C];
+  float T[C];
+  load_samples<C>(sm, raw + b * S * ch, ch, z + b * S, noise ? noise + b * S : nullptr, ray_norm(rays + b * rs), S,
+                  lane);
+  transmittance<C>(sm, T, lane);
+  float gr = 0.f, gg = 0.f, gb = 0.f, gd = 0.f, ga = 0.f;
+  if (g_rgb) { gr = g_rgb[b * 3 + 0]; gg = g_rgb[b * 3 + 1]; gb = g_rgb[b * 3 + 2]; }
+  if (g_depth) gd = g_depth[b];
+  if (g_acc) ga = g_acc[b];
+  if (white) ga -= (gr + gg + gb);
+  if (g_disp) {
+    // disp = 1/max(1e-10, depth/acc): needs the forward totals
+    double sd = 0, sa = 0;
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+      const float w = sm[j].alpha * T[j];
+      sd += (double)(w * sm[j].z);
+      sa += (double)w;
+    }
+    const float fd = (float)wave_sum(sd), fa = (float)wave_sum(sa);
+    const float q = fd / fa;
+    if (q > 1e-10f) {
+      const float gq = -g_disp[b] / (q * q);
+      gd += gq / fa;
+      ga += -gq * fd / (fa * fa);
+    }
+  }
+  // v_i = dL/dw_i ; suffix sums S_i = sum_{k>i} w_k v_k (reverse exclusive scan, fp64)
+  float v[C];
+  double tot = 0.0;
+#pragma unroll
+  for (int j = 0; j < C; ++j) {
+    v[j] = gr * sm[j].r + gg * sm[j].g + gb * sm[j].b + gd * sm[j].z + ga;
+    tot += (double)(sm[j].alpha * T[j]) * (double)v[j];
+  }
+  double incl = tot;   // inclusive suffix over lanes >= l
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    double t = __shfl_down(incl, o, 64);
+    if (lane + o < 64) incl += t;
+  }
+  double suf = incl - tot;   // sum over lanes > l
+#pragma unroll
+  for (int j = C - 1; j >= 0; --j) {
+    const float w = sm[j].alpha * T[j];
+    // cumprod backward (as autograd: reverse-cumsum(grad*out)/input) -> dL/dalpha
+    const float dalpha = T[j] * v[j] - (float)(suf / (double)sm[j].x);
+    suf += (double)w * (double)v[j];
+    if (!sm[j].live) continue;
+    const float dsig = sm[j].sig > 0.f ? dalpha * sm[j].dist * sm[j].e : 0.f;
+    const float dr = gr * w * sm[j].r * (1.f - sm[j].r);
+    const float dg = gg * w * sm[j].g * (1.f - sm[j].g);
+    const float db = gb * w * sm[j].b * (1.f - sm[j].b);
+    float* o = d_raw + (b * S + lane * C + j) * ch;
+    if (ch == 4) {
+      *reinterpret_cast<float4*>(o) = make_float4(dr, dg, db, dsig);
+    } else {
+      o[0] = dr; o[1] = dg; o[2] = db; o[3] = dsig;
+      for (int c = 4; c < ch; ++c) o[c] = 0.f;
+    }
+  }
+}
+
+template <typename F>
+int dispatch_c(int S, F f) {
+  const int C = (S + 63) / 64;
+  if (C <= 1) return f(std::integral_constant<int, 1>());
+  if (C == 2) return f(std::integral_constant<int, 2>());
+  if (C == 3) return f(std::integral_constant<int, 3>());
+  if (C == 4) return f(std::integral_constant<int, 4>());
+  if (C <= 8) return f(std::integral_constant<int, 8>());
+  if (C <= 16) return f(std::integral_constant<int, 16>());
+  return CNERF_E_UNSUPPORTED;
+}
+
+}  // namespace
+
+extern "C" int cnerf_composite_fwd(const float* raw, int raw_ch, const float* z, const float* rays, int ray_stride,
+                                   const float* noise, int64_t B, int S, int white_bkgd, float* rgb, float* disp,
+                                   float* acc, float* depth, float* weights, void* stream) {
+  if (!raw || !z || !rays || B < 0 || S <= 0 || raw_ch < 4 || ray_stride < 6) return CNERF_E_ARG;
+  if (B == 0) return CNERF_OK;
+  return dispatch_c(S, [&](auto c) -> int {
+    constexpr int C = decltype(c)::value;
+    hipLaunchKernelGGL((composite_fwd_k<C>), dim3((unsigned)cn_div_up(B, WAVES)), dim3(WAVES * 64), 0,
+                       cn_stream(stream), raw, raw_ch, z, rays, ray_stride, noise, B, S, white_bkgd, rgb, disp, acc,
+                       depth, weights);
+    CN_CHECK_LAUNCH();
+    return CNERF_OK;
+  });
+}
+
+extern "C" int cnerf_composite_bwd(const float* raw, int raw_ch, const float* z, const float* rays, int ray_stride,
+                                   const float* noise, int64_t B, int S, int white_bkgd, const float* g_rgb,
+                                   const float* g_disp, const float* g_acc, const float* g_depth, float* d_raw,
+                                   void* stream) {
+  if (!raw || !z || !rays || !d_raw || B < 0 || S <= 0 || raw_ch < 4 || ray_stride < 6) return CNERF_E_ARG;
+  if (B == 0) return CNERF_OK;
+  return dispatch_c(S, [&](auto c) -> int {
+    constexpr int C = decltype(c)::value;
+    hipLaunchKernelGGL((composite_bwd_k<C>), dim3((unsigned)cn_div_up(B, WAVES)), dim3(WAVES * 64), 0,
+                       cn_stream(stream), raw, raw_ch, z, rays, ray_stride, noise, B, S, white_bkgd, g_rgb, g_disp,
+                       g_acc, g_depth, d_raw);
+    CN_CHECK_LAUNCH();
+    return CNERF_OK;
+  });
+}

@@ -1,0 +1,214 @@
+// Backward of the fused encoding+MLP (autograd of run_network R:37-52 / NeRF.forward H:107-130).
+// Three launches:
+//   1. dgrad (this file): one wave64 per 32 points walks the network backwards with the TRANSPOSED weight
+//      panels as the MFMA A operand and the gradient tile in LDS as B; it writes the gradient w.r.t. every
+//      layer's pre-activation, dZ_l^T, as [rows][Mp] blocks (point-contiguous) into the workspace.
+//   2. wgrad (wgrad.hip): NT GEMMs contracted over points, dW_l = dZ_l^T . H_{l-1}, split over point ranges.
+//   3. a fixed-order reduction of the split partials into the parameter gradients (deterministic).
+// ReLU masks are re-derived from the forward stash (H > 0  <=>  pre-activation > 0).
+#include "mlp_common.hpp"
+
+int cn_wgrad_launch(const NetGeom& g, const float* stash, const float* G, int64_t M, int64_t Mp, float* partials,
+                    int nsplit, const cnerf_ptrs* grads, int accumulate, hipStream_t st);
+int cn_wgrad_nsplit(int64_t Mp);
+int64_t cn_param_floats(const NetGeom& g);
+
+namespace {
+
+struct BwdArgs {
+  NetGeom g;
+  const float* packed;
+  const float* d_raw;
+  const float* stash;
+  float* G;
+  int64_t M, Mp;
+};
+
+// mask (H>0) and park: acc <- acc * [stash row > 0]; write to the G block `grow` and to the LDS tile.
+template <int W, int NTO, bool MASK>
+__device__ __forceinline__ void mask_park(f32x16 (&acc)[NTO], float* Hs, const float* __restrict__ stash, int srow,
+                                          float* __restrict__ G, int grow, int64_t Mp, int64_t p, int64_t pc,
+                                          bool valid, int m, int hh) {
+#pragma unroll
+  for (int t = 0; t < NTO; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 v;
+      const int n0 = 32 * t + 8 * q + 4 * hh;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float x = acc[t][4 * q + j];
+        if (MASK) {
+          const float h = stash[(int64_t)(srow + n0 + j) * Mp + pc];
+          x = h > 0.f ? x : 0.f;
+        }
+        v[j] = x;
+      }
+      *reinterpret_cast<f32x4*>(Hs + hs_off<W>(m, 8 * t + 2 * q + hh)) = v;
+      if (valid) {
+        float* s = G + (int64_t)(grow + n0) * Mp + p;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[(int64_t)j * Mp] = v[j];
+      }
+    }
+}
+
+template <int NTO>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[NTO]) {
+#pragma unroll
+  for (int t = 0; t < NTO; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+}
+
+template <int NT, bool VD>
+__global__ __launch_bounds__(64) void mlp_dgrad_k(BwdArgs a) {
+  constexpr int W = NT * 32;
+  constexpr int NTH = NT / 2 > 0 ? NT / 2 : 1;
+  extern __shared__ __attribute__((aligned(16))) float Hs[];
+  const NetGeom& g = a.g;
+  const int lane = threadIdx.x, m = lane & 31, hh = lane >> 5;
+  const int64_t p = (int64_t)blockIdx.x * 32 + m;
+  const bool valid = p < a.M;
+  const int64_t pc = valid ? p : a.M - 1;
+  const float* pk = a.packed;
+  const int64_t Mp = a.Mp;
+  f32x16 acc[NT];
+
+  if (VD) {
+    const float4 d = *reinterpret_cast<const float4*>(a.d_raw + pc * 4);
+    const float dc[4] = {d.x, d.y, d.z, d.w};
+    if (valid && hh == 0) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) a.G[(int64_t)(g.g_out + c) * Mp + p] = dc[c];
+    }
+    // rgb_linear^T on the VALU, masked by the view-branch ReLU -> dZv (C-layout registers)
+    f32x16 accv[NTH];
+#pragma unroll
+    for (int t = 0; t < NTH; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n0 = 32 * t + 8 * q + 4 * hh;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const f32x4 w = *reinterpret_cast<const f32x4*>(pk + g.v_rgb + (int64_t)c * g.Wh + n0);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) s[j] += w[j] * dc[c];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) accv[t][4 * q + j] = s[j];
+      }
+    mask_park<W, NTH, true>(accv, Hs, a.stash, g.s_hv, a.G, g.g_hv, Mp, p, pc, valid, m, hh);
+    __builtin_amdgcn_wave_barrier();
+    // views_linears^T (feature columns only; gamma(d) needs no gradient) -> dF
+    zero_acc<NT>(acc);
+    gemm_seg<W, NT>(acc, pk + g.t_views, W, g.Wh / 8, Hs, m, hh);
+    __builtin_amdgcn_wave_barrier();
+    mask_park<W, NT, false>(acc, Hs, a.stash, 0, a.G, g.g_feat, Mp, p, pc, valid, m, hh);
+    __builtin_amdgcn_wave_barrier();
+    // feature_linear^T . dF  +  alpha_linear^T . dsigma, masked by the last trunk ReLU -> dZ_{D-1}
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(pk + g.v_alpha + 32 * t + 8 * q + 4 * hh);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[t][4 * q + j] = w[j] * dc[3];
+      }
+    gemm_seg<W, NT>(acc, pk + g.t_feat, W, W / 8, Hs, m, hh);
+  } else {
+    float dc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) dc[c] = c < g.out_ch ? a.d_raw[pc * g.out_ch + c] : 0.f;
+    if (valid && hh == 0)
+      for (int c = 0; c < g.out_ch; ++c) a.G[(int64_t)(g.g_out + c) * Mp + p] = dc[c];
+    // output_linear^T on the VALU
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n0 = 32 * t + 8 * q + 4 * hh;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+          if (c < g.out_ch) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(pk + g.v_out + (int64_t)c * W + n0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[j] += w[j] * dc[c];
+          }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[t][4 * q + j] = s[j];
+      }
+  }
+  __builtin_amdgcn_wave_barrier();
+  mask_park<W, NT, true>(acc, Hs, a.stash, g.s_h[g.D - 1], a.G, g.g_z[g.D - 1], Mp, p, pc, valid, m, hh);
+  __builtin_amdgcn_wave_barrier();
+  // trunk: dZ_{l-1} = relu'(.) * W_l^T dZ_l   (the gamma(x) columns of the skip layer get no gradient)
+  for (int l = g.D - 1; l >= 1; --l) {
+    zero_acc<NT>(acc);
+    gemm_seg<W, NT>(acc, pk + g.t_trunk[l], W, W / 8, Hs, m, hh);
+    __builtin_amdgcn_wave_barrier();
+    mask_park<W, NT, true>(acc, Hs, a.stash, g.s_h[l - 1], a.G, g.g_z[l - 1], Mp, p, pc, valid, m, hh);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <int NT>
+int launch(const BwdArgs& a, hipStream_t st) {
+  const unsigned grid = (unsigned)cn_div_up(a.M, 32);
+  const size_t lds = (size_t)NT * 32 * 32 * sizeof(float);
+  if (a.g.viewdirs) hipLaunchKernelGGL((mlp_dgrad_k<NT, true>), dim3(grid), dim3(64), lds, st, a);
+  else hipLaunchKernelGGL((mlp_dgrad_k<NT, false>), dim3(grid), dim3(64), lds, st, a);
+  CN_CHECK_LAUNCH();
+  return CNERF_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t cnerf_mlp_bwd_ws_floats(const cnerf_net* net, int64_t M) {
+  NetGeom g;
+  if (cn_make_geom(net, &g) || M < 0) return -1;
+  const int64_t Mp = cn_round_up(M, 32);
+  return (int64_t)g.g_rows * Mp + (int64_t)cn_wgrad_nsplit(Mp) * cn_round_up(cn_param_floats(g), 64);
+}
+
+extern "C" int cnerf_mlp_dgrad(const cnerf_net* net, const float* packed, const float* d_raw, int64_t B, int S,
+                               const float* stash, float* workspace, void* stream) {
+  BwdArgs a;
+  int rc = cn_make_geom(net, &a.g);
+  if (rc) return rc;
+  if (!packed || !d_raw || !stash || !workspace || B < 0 || S <= 0) return CNERF_E_ARG;
+  if (B == 0) return CNERF_OK;
+  a.packed = packed; a.d_raw = d_raw; a.stash = stash; a.G = workspace;
+  a.M = B * S; a.Mp = cn_round_up(a.M, 32);
+  hipStream_t st = cn_stream(stream);
+  switch (a.g.NT) {
+    case 2: return launch<2>(a, st);
+    case 4: return launch<4>(a, st);
+    case 8: return launch<8>(a, st);
+  }
+  return CNERF_E_UNSUPPORTED;
+}
+
+extern "C" int cnerf_mlp_wgrad(const cnerf_net* net, int64_t B, int S, const float* stash, float* workspace,
+                               const cnerf_ptrs* grads, int accumulate, void* stream) {
+  NetGeom g;
+  int rc = cn_make_geom(net, &g);
+  if (rc) return rc;
+  if (!stash || !workspace || !grads || B < 0 || S <= 0) return CNERF_E_ARG;
+  if (B == 0) return CNERF_OK;
+  const int64_t M = B * S, Mp = cn_round_up(M, 32);
+  const int nsplit = cn_wgrad_nsplit(Mp);
+  float* partials = workspace + (int64_t)g.g_rows * Mp;
+  return cn_wgrad_launch(g, stash, workspace, M, Mp, partials, nsplit, grads, accumulate, cn_stream(stream));
+}
+
+extern "C" int cnerf_mlp_bwd(const cnerf_net* net, const float* packed, const float* d_raw, int64_t B, int S,
+                             const float* stash, float* workspace, const cnerf_ptrs* grads, int accumulate,
+                             void* stream) {
+  if (!grads) return CNERF_E_ARG;
+  int rc = cnerf_mlp_dgrad(net, packed, d_raw, B, S, stash, workspace, stream);
+  if (rc) return rc;
+  return cnerf_mlp_wgrad(net, B, S, stash, workspace, grads, accumulate, stream);
+}

@@ -1,0 +1,228 @@
+// Sample placement along rays: stratified coarse depths, inverse-CDF resampling, sorted merge.
+// Replaces render_rays R:355-382 / R:395-399,415 and sample_pdf H:206-250 of the reference.
+// One wave64 per ray for the scan/search/sort parts; everything a ray needs lives in LDS/registers.
+#include "common.hpp"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// z[b,i] = near*(1-t_i) + far*t_i   (or the inverse-depth form), then the stratified jitter
+// z = lower + (upper-lower)*t_rand with bin edges at the midpoints (R:360-382).  Operation order and
+// roundings are the reference's (compiled with -ffp-contract=off: no FMA contraction).
+__device__ __forceinline__ float zlin(float near, float far, float t, int lindisp) {
+  if (!lindisp) return near * (1.f - t) + far * t;
+  return 1.f / (1.f / near * (1.f - t) + 1.f / far * t);
+}
+
+__global__ void coarse_z_k(const float* __restrict__ rays, int rs, int64_t B, int Nc,
+                           const float* __restrict__ t_vals, const float* __restrict__ t_rand, int lindisp,
+                           float* __restrict__ z) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * Nc) return;
+  int64_t b = idx / Nc;
+  int i = (int)(idx - b * Nc);
+  float near = rays[b * rs + 6], far = rays[b * rs + 7];
+  float zi = zlin(near, far, t_vals[i], lindisp);
+  if (t_rand != nullptr) {
+    float lower, upper;
+    if (i == 0) lower = zi;
+    else lower = .5f * (zi + zlin(near, far, t_vals[i - 1], lindisp));
+    if (i == Nc - 1) upper = zi;
+    else upper = .5f * (zlin(near, far, t_vals[i + 1], lindisp) + zi);
+    zi = lower + (upper - lower) * t_rand[idx];
+  }
+  z[idx] = zi;
+}
+
+// ------------------------------------------------------------------------------------------------
+constexpr int MAX_NB = 256;     // CDF entries per ray
+constexpr int MAX_ALL = 1024;   // Nc + Nf
+constexpr int WAVES = 4;
+
+struct PdfLds {
+  float cdf[WAVES][MAX_NB];
+  float bins[WAVES][MAX_NB];
+};
+
+// Builds cdf[0..Nb-1] and bins[0..Nb-1] for one ray in LDS.  w(j), j<Nb-1, is the raw weight;
+// pdf = (w+1e-5)/sum, cdf = [0, cumsum(pdf)] with the running sum carried in fp64 and each entry
+// rounded to fp32 (what the CPU reference's cumsum produces).
+template <typename WFn, typename BFn>
+__device__ __forceinline__ void build_cdf(float* cdf, float* bins, int Nb, int lane, WFn w, BFn bin) {
+  const int nw = Nb - 1;
+  // per-lane contiguous chunk so the scan is lane-local + one wave scan
+  const int C = (nw + 63) >> 6;
+  double tot = 0.0;
+  for (int j = 0; j < C; ++j) {
+    int k = lane * C + j;
+    if (k < nw) tot += (double)(w(k) + 1e-5f);
+  }
+  const float sum = (float)wave_sum(tot);
+  double run = 0.0;
+  for (int j = 0; j < C; ++j) {
+    int k = lane * C + j;
+    if (k < nw) run += (double)((w(k) + 1e-5f) / sum);
+  }
+  // inclusive wave scan of the lane totals
+  double incl = run;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    double v = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += v;
+  }
+  double acc = incl - run;   // exclusive prefix of this lane's chunk
+  for (int j = 0; j < C; ++j) {
+    int k = lane * C + j;
+    if (k < nw) {
+      acc += (double)((w(k) + 1e-5f) / sum);
+      cdf[k + 1] = (float)acc;
+    }
+  }
+  if (lane == 0) cdf[0] = 0.f;
+  for (int k = lane; k < Nb; k += 64) bins[k] = bin(k);
+}
+
+// searchsorted(cdf, u, right=True): number of entries <= u.
+__device__ __forceinline__ int upper_bound(const float* cdf, int Nb, float u) {
+  int lo = 0, hi = Nb;
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (cdf[mid] <= u) lo = mid + 1;
+    else hi = mid;
+  }
+  return lo;
+}
+
+__device__ __forceinline__ float invert_cdf(const float* cdf, const float* bins, int Nb, float u, int* ind_out) {
+  int ind = upper_bound(cdf, Nb, u);
+  *ind_out = ind;
+  int below = ind - 1 < 0 ? 0 : ind - 1;
+  int above = ind > Nb - 1 ? Nb - 1 : ind;
+  float c0 = cdf[below], c1 = cdf[above];
+  float b0 = bins[below], b1 = bins[above];
+  float denom = c1 - c0;
+  if (denom < 1e-5f) denom = 1.f;
+  float t = (u - c0) / denom;
+  return b0 + t * (b1 - b0);
+}
+
+__global__ __launch_bounds__(WAVES * 64) void sample_pdf_k(const float* __restrict__ bins_g,
+                                                           const float* __restrict__ weights_g,
+                                                           const float* __restrict__ u_g, int64_t u_stride,
+                                                           int64_t B, int Nb, int Nf, float* __restrict__ samples,
+                                                           int64_t* __restrict__ inds) {
+  __shared__ PdfLds lds;
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t b = (int64_t)blockIdx.x * WAVES + wv;
+  if (b >= B) return;
+  float* cdf = lds.cdf[wv];
+  float* bins = lds.bins[wv];
+  const float* wrow = weights_g + b * (Nb - 1);
+  const float* brow = bins_g + b * Nb;
+  build_cdf(cdf, bins, Nb, lane, [&](int k) { return wrow[k]; }, [&](int k) { return brow[k]; });
+  __builtin_amdgcn_wave_barrier();
+  const float* urow = u_g + b * u_stride;
+  for (int k = lane; k < Nf; k += 64) {
+    int ind;
+    float s = invert_cdf(cdf, bins, Nb, urow[k], &ind);
+    samples[b * Nf + k] = s;
+    if (inds) inds[b * Nf + k] = ind;
+  }
+}
+
+struct ResampleLds {
+  float cdf[WAVES][MAX_NB];
+  float bins[WAVES][MAX_NB];
+  float all[WAVES][MAX_ALL];
+};
+
+// z_mid -> sample_pdf(z_mid, weights[1:-1]) -> sort(cat[z, z_samples]) and std(z_samples), one ray/wave.
+__global__ __launch_bounds__(WAVES * 64) void resample_k(const float* __restrict__ z_g,
+                                                         const float* __restrict__ weights_g,
+                                                         const float* __restrict__ u_g, int64_t u_stride, int64_t B,
+                                                         int Nc, int Nf, float* __restrict__ z_fine,
+                                                         float* __restrict__ z_std, float* __restrict__ samples,
+                                                         int64_t* __restrict__ inds) {
+  __shared__ ResampleLds lds;
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t b = (int64_t)blockIdx.x * WAVES + wv;
+  if (b >= B) return;
+  float* cdf = lds.cdf[wv];
+  float* bins = lds.bins[wv];
+  float* all = lds.all[wv];
+  const float* zrow = z_g + b * Nc;
+  const float* wrow = weights_g + b * Nc;
+  const int Nb = Nc - 1;
+  build_cdf(cdf, bins, Nb, lane, [&](int k) { return wrow[k + 1]; },
+            [&](int k) { return .5f * (zrow[k + 1] + zrow[k]); });
+  for (int k = lane; k < Nc; k += 64) all[k] = zrow[k];
+  __builtin_amdgcn_wave_barrier();
+  const float* urow = u_g + b * u_stride;
+  double s1 = 0.0;
+  for (int k = lane; k < Nf; k += 64) {
+    int ind;
+    float s = invert_cdf(cdf, bins, Nb, urow[k], &ind);
+    all[Nc + k] = s;
+    s1 += (double)s;
+    if (samples) samples[b * Nf + k] = s;
+    if (inds) inds[b * Nf + k] = ind;
+  }
+  __builtin_amdgcn_wave_barrier();
+  // population std of the new samples (R:415), two-pass in fp64
+  const double mean = wave_sum(s1) / (double)Nf;
+  double s2 = 0.0;
+  for (int k = lane; k < Nf; k += 64) {
+    double d = (double)all[Nc + k] - mean;
+    s2 += d * d;
+  }
+  s2 = wave_sum(s2);
+  if (lane == 0) z_std[b] = (float)sqrt(s2 / (double)Nf);
+  // rank sort of the Nc+Nf depths (values only, ascending; ties keep input order)
+  const int n = Nc + Nf;
+  float* out = z_fine + b * n;
+  for (int e = lane; e < n; e += 64) {
+    const float x = all[e];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) {
+      const float y = all[j];
+      rank += (y < x) || (y == x && j < e);
+    }
+    out[rank] = x;
+  }
+}
+
+}  // namespace
+
+extern "C" int cnerf_coarse_z(const float* rays, int ray_stride, int64_t B, int Nc, const float* t_vals,
+                              const float* t_rand, int lindisp, float* z, void* stream) {
+  if (!rays || !t_vals || !z || B < 0 || Nc <= 0 || ray_stride < 8) return CNERF_E_ARG;
+  if (B == 0) return CNERF_OK;
+  int64_t n = B * Nc;
+  hipLaunchKernelGGL(coarse_z_k, dim3((unsigned)cn_div_up(n, 256)), dim3(256), 0, cn_stream(stream), rays, ray_stride,
+                     B, Nc, t_vals, t_rand, lindisp, z);
+  CN_CHECK_LAUNCH();
+  return CNERF_OK;
+}
+
+extern "C" int cnerf_sample_pdf(const float* bins, const float* weights, const float* u, int64_t u_row_stride,
+                                int64_t B, int Nb, int Nf, float* samples, int64_t* inds, void* stream) {
+  if (!bins || !weights || !u || !samples || B < 0 || Nb < 2 || Nf <= 0) return CNERF_E_ARG;
+  if (Nb > MAX_NB) return CNERF_E_UNSUPPORTED;
+  if (B == 0) return CNERF_OK;
+  hipLaunchKernelGGL(sample_pdf_k, dim3((unsigned)cn_div_up(B, WAVES)), dim3(WAVES * 64), 0, cn_stream(stream), bins,
+                     weights, u, u_row_stride, B, Nb, Nf, samples, inds);
+  CN_CHECK_LAUNCH();
+  return CNERF_OK;
+}
+
+extern "C" int cnerf_resample(const float* z, const float* weights, const float* u, int64_t u_row_stride, int64_t B,
+                              int Nc, int Nf, float* z_fine, float* z_std, float* samples, int64_t* inds,
+                              void* stream) {
+  if (!z || !weights || !u || !z_fine || !z_std || B < 0 || Nc < 3 || Nf <= 0) return CNERF_E_ARG;
+  if (Nc - 1 > MAX_NB || Nc + Nf > MAX_ALL) return CNERF_E_UNSUPPORTED;
+  if (B == 0) return CNERF_OK;
+  hipLaunchKernelGGL(resample_k, dim3((unsigned)cn_div_up(B, WAVES)), dim3(WAVES * 64), 0, cn_stream(stream), z,
+                     weights, u, u_row_stride, B, Nc, Nf, z_fine, z_std, samples, inds);
+  CN_CHECK_LAUNCH();
+  return CNERF_OK;
+}

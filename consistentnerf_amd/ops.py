@@ -1,0 +1,314 @@
+"""Tensor-level wrappers over the C ABI (include/cnerf.h).  Device memory, streams and allocation are
+PyTorch-ROCm plumbing; every computation here is a HIP kernel of libcnerf_hip.so.  No fallbacks."""
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import CnerfError, Net, Ptrs
+
+Tensor = torch.Tensor
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# Optional per-kernel timing with HIP events recorded on the stream the kernels are launched on
+# (bench.py's live roofline measurement).  PROFILE = None disables it (zero overhead).
+PROFILE = None
+
+
+class _timed:
+    def __init__(self, name, units):
+        self.name, self.units = name, units
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record(torch.cuda.current_stream())
+
+    def __exit__(self, *exc):
+        if PROFILE is not None:
+            self.e1.record(torch.cuda.current_stream())
+            PROFILE.append((self.name, self.units, self.e0, self.e1))
+        return False
+
+
+def _p(t: Optional[Tensor]):
+    return C.c_void_p(0) if t is None else C.c_void_p(t.data_ptr())
+
+
+def _chk(t: Optional[Tensor], name: str, dtype=torch.float32) -> Optional[Tensor]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise CnerfError(f"{name} must live on the GPU: consistentnerf_amd has no CPU path (got {t.device})")
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+@dataclass(frozen=True)
+class NetSpec:
+    """Architecture of one MLP (mirror of struct cnerf_net)."""
+    D: int = 8
+    W: int = 256
+    multires: int = 10
+    multires_views: int = 4
+    use_viewdirs: bool = True
+    output_ch: int = 4
+    skip: int = 4
+
+    def c(self) -> Net:
+        return Net(self.D, self.W, self.multires, self.multires_views, int(self.use_viewdirs), self.output_ch,
+                   self.skip)
+
+    @property
+    def raw_ch(self) -> int:
+        return 4 if self.use_viewdirs else self.output_ch
+
+    def num_tensors(self) -> int:
+        return _lib.load().cnerf_num_tensors(C.byref(self.c()))
+
+    def tensor_shapes(self):
+        lib, net, out = _lib.load(), self.c(), []
+        r, c = C.c_int64(), C.c_int64()
+        for i in range(self.num_tensors()):
+            _lib.check(lib.cnerf_tensor_shape(C.byref(net), i, C.byref(r), C.byref(c)), "cnerf_tensor_shape")
+            out.append((r.value,) if i & 1 else (r.value, c.value))
+        return out
+
+
+def _ptrs(tensors: Sequence[Optional[Tensor]]) -> Ptrs:
+    p = Ptrs()
+    for i, t in enumerate(tensors):
+        p.p[i] = None if t is None else t.data_ptr()
+    return p
+
+
+def device_info(dev: int = 0):
+    lib = _lib.load()
+    name = C.create_string_buffer(64)
+    cus, lds = C.c_int(), C.c_int()
+    rc = lib.cnerf_device_info(dev, name, C.byref(cus), C.byref(lds))
+    return rc == 0, name.value.decode(), cus.value, lds.value
+
+
+# ------------------------------------------------------------------------------------------ weights
+def pack_weights(spec: NetSpec, params: Sequence[Tensor], out: Optional[Tensor] = None) -> Tensor:
+    lib, net = _lib.load(), spec.c()
+    params = [_chk(p, f"param{i}") for i, p in enumerate(params)]
+    n = lib.cnerf_packed_floats(C.byref(net))
+    if n < 0:
+        raise CnerfError(f"unsupported network {spec}")
+    if out is None:
+        out = torch.empty(n, device=params[0].device, dtype=torch.float32)
+    ptrs = _ptrs(params)
+    _lib.check(lib.cnerf_pack_weights(C.byref(net), C.byref(ptrs), _p(out), _stream()), "cnerf_pack_weights")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ sampling
+_TVALS = {}
+
+
+def _t_vals(n: int, device) -> Tensor:
+    """torch.linspace(0,1,n) evaluated on the CPU (the reference's constants), cached per device."""
+    key = (n, str(device))
+    if key not in _TVALS:
+        _TVALS[key] = torch.linspace(0., 1., steps=n).to(device)
+    return _TVALS[key]
+
+
+def coarse_z(rays: Tensor, Nc: int, t_rand: Optional[Tensor], lindisp: bool) -> Tensor:
+    rays = _chk(rays, "rays")
+    B = rays.shape[0]
+    t_rand = _chk(t_rand, "t_rand")
+    z = torch.empty(B, Nc, device=rays.device, dtype=torch.float32)
+    _lib.check(_lib.load().cnerf_coarse_z(_p(rays), rays.shape[1], B, Nc, _p(_t_vals(Nc, rays.device)), _p(t_rand),
+                                          int(lindisp), _p(z), _stream()), "cnerf_coarse_z")
+    return z
+
+
+def sample_pdf(bins: Tensor, weights: Tensor, u: Tensor, want_inds: bool = False):
+    bins, weights, u = _chk(bins, "bins"), _chk(weights, "weights"), _chk(u, "u")
+    B, Nb = bins.shape
+    Nf = u.shape[-1]
+    stride = 0 if u.dim() == 1 or u.shape[0] == 1 else Nf
+    samples = torch.empty(B, Nf, device=bins.device, dtype=torch.float32)
+    inds = torch.empty(B, Nf, device=bins.device, dtype=torch.int64) if want_inds else None
+    _lib.check(_lib.load().cnerf_sample_pdf(_p(bins), _p(weights), _p(u), stride, B, Nb, Nf, _p(samples), _p(inds),
+                                            _stream()), "cnerf_sample_pdf")
+    return (samples, inds) if want_inds else samples
+
+
+def resample(z: Tensor, weights: Tensor, u: Tensor, want_samples: bool = False):
+    z, weights, u = _chk(z, "z"), _chk(weights, "weights"), _chk(u, "u")
+    B, Nc = z.shape
+    Nf = u.shape[-1]
+    stride = 0 if u.dim() == 1 or u.shape[0] == 1 else Nf
+    z_fine = torch.empty(B, Nc + Nf, device=z.device, dtype=torch.float32)
+    z_std = torch.empty(B, device=z.device, dtype=torch.float32)
+    samples = torch.empty(B, Nf, device=z.device, dtype=torch.float32) if want_samples else None
+    inds = torch.empty(B, Nf, device=z.device, dtype=torch.int64) if want_samples else None
+    _lib.check(_lib.load().cnerf_resample(_p(z), _p(weights), _p(u), stride, B, Nc, Nf, _p(z_fine), _p(z_std),
+                                          _p(samples), _p(inds), _stream()), "cnerf_resample")
+    return (z_fine, z_std, samples, inds) if want_samples else (z_fine, z_std)
+
+
+# ------------------------------------------------------------------------------------------ MLP
+def embed(x: Tensor, L: int) -> Tensor:
+    x = _chk(x, "x")
+    lead = x.shape[:-1]
+    x2 = x.reshape(-1, 3)
+    out = torch.empty(x2.shape[0], 3 + 6 * L, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().cnerf_embed(_p(x2), x2.shape[0], L, _p(out), _stream()), "cnerf_embed")
+    return out.reshape(*lead, 3 + 6 * L)
+
+
+def mlp_forward(spec: NetSpec, packed: Tensor, B: int, S: int, *, pts: Optional[Tensor] = None,
+                rays: Optional[Tensor] = None, z: Optional[Tensor] = None, dirs: Optional[Tensor] = None,
+                want_stash: bool = False):
+    lib, net = _lib.load(), spec.c()
+    pts, rays, z, dirs = _chk(pts, "pts"), _chk(rays, "rays"), _chk(z, "z"), _chk(dirs, "dirs")
+    dev = packed.device
+    raw = torch.empty(B, S, spec.raw_ch, device=dev, dtype=torch.float32)
+    stash = None
+    if want_stash:
+        stash = torch.empty(lib.cnerf_mlp_stash_floats(C.byref(net), B * S), device=dev, dtype=torch.float32)
+    rs = rays.shape[1] if rays is not None else 0
+    with _timed("mlp_fwd_train" if want_stash else "mlp_fwd", B * S):
+        _lib.check(lib.cnerf_mlp_fwd(C.byref(net), _p(packed), _p(pts), _p(rays), rs, _p(dirs), _p(z), B, S,
+                                     _p(raw), _p(stash), _stream()), "cnerf_mlp_fwd")
+    return raw, stash
+
+
+def mlp_backward(spec: NetSpec, packed: Tensor, d_raw: Tensor, B: int, S: int, stash: Tensor,
+                 grads: Optional[List[Tensor]] = None, accumulate: bool = False) -> List[Tensor]:
+    lib, net = _lib.load(), spec.c()
+    d_raw = _chk(d_raw, "d_raw")
+    dev = packed.device
+    if grads is None:
+        grads = [torch.empty(s, device=dev, dtype=torch.float32) for s in spec.tensor_shapes()]
+        accumulate = False
+    ws = torch.empty(lib.cnerf_mlp_bwd_ws_floats(C.byref(net), B * S), device=dev, dtype=torch.float32)
+    ptrs = _ptrs(grads)
+    with _timed("mlp_dgrad", B * S):
+        _lib.check(lib.cnerf_mlp_dgrad(C.byref(net), _p(packed), _p(d_raw), B, S, _p(stash), _p(ws), _stream()),
+                   "cnerf_mlp_dgrad")
+    with _timed("mlp_wgrad", B * S):
+        _lib.check(lib.cnerf_mlp_wgrad(C.byref(net), B, S, _p(stash), _p(ws), C.byref(ptrs), int(accumulate),
+                                       _stream()), "cnerf_mlp_wgrad")
+    return grads
+
+
+# ------------------------------------------------------------------------------------------ compositing
+def composite_forward(raw: Tensor, z: Tensor, rays: Tensor, noise: Optional[Tensor], white_bkgd: bool):
+    raw, z, rays, noise = _chk(raw, "raw"), _chk(z, "z"), _chk(rays, "rays"), _chk(noise, "noise")
+    B, S = z.shape
+    dev = raw.device
+    rgb = torch.empty(B, 3, device=dev)
+    disp, acc, depth = torch.empty(B, device=dev), torch.empty(B, device=dev), torch.empty(B, device=dev)
+    weights = torch.empty(B, S, device=dev)
+    _lib.check(_lib.load().cnerf_composite_fwd(_p(raw), raw.shape[-1], _p(z), _p(rays), rays.shape[1], _p(noise), B, S,
+                                               int(white_bkgd), _p(rgb), _p(disp), _p(acc), _p(depth), _p(weights),
+                                               _stream()), "cnerf_composite_fwd")
+    return rgb, disp, acc, weights, depth
+
+
+def composite_backward(raw, z, rays, noise, white_bkgd, g_rgb, g_disp, g_acc, g_depth) -> Tensor:
+    raw, z, rays, noise = _chk(raw, "raw"), _chk(z, "z"), _chk(rays, "rays"), _chk(noise, "noise")
+    g_rgb, g_disp, g_acc, g_depth = (_chk(g, "grad") for g in (g_rgb, g_disp, g_acc, g_depth))
+    B, S = z.shape
+    d_raw = torch.empty_like(raw)
+    _lib.check(_lib.load().cnerf_composite_bwd(_p(raw), raw.shape[-1], _p(z), _p(rays), rays.shape[1], _p(noise), B, S,
+                                               int(white_bkgd), _p(g_rgb), _p(g_disp), _p(g_acc), _p(g_depth),
+                                               _p(d_raw), _stream()), "cnerf_composite_bwd")
+    return d_raw
+
+
+# ------------------------------------------------------------------------------------------ rays
+def _f4(a) -> "C.Array":
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float32)[:3, :4]).reshape(-1)
+    return (C.c_float * 12)(*a.tolist())
+
+
+def gen_rays(H: int, W: int, K, c2w, near: float, far: float, use_viewdirs: bool, ndc: bool, device,
+             ndc_coef=(0.0, 0.0)) -> Tensor:
+    rays = torch.empty(H * W, 11 if use_viewdirs else 8, device=device, dtype=torch.float32)
+    if isinstance(c2w, torch.Tensor):
+        c2w = c2w.detach().cpu().numpy()
+    _lib.check(_lib.load().cnerf_gen_rays(H, W, float(K[0][0]), float(K[1][1]), float(K[0][2]), float(K[1][2]),
+                                          _f4(c2w), float(near), float(far), int(use_viewdirs), int(ndc),
+                                          float(ndc_coef[0]), float(ndc_coef[1]), _p(rays), _stream()),
+               "cnerf_gen_rays")
+    return rays
+
+
+def pack_rays(rays_o: Tensor, rays_d: Tensor, near: float, far: float, use_viewdirs: bool, ndc: bool,
+              ndc_coef=(0.0, 0.0)) -> Tensor:
+    rays_o, rays_d = _chk(rays_o.reshape(-1, 3), "rays_o"), _chk(rays_d.reshape(-1, 3), "rays_d")
+    B = rays_o.shape[0]
+    rays = torch.empty(B, 11 if use_viewdirs else 8, device=rays_o.device, dtype=torch.float32)
+    _lib.check(_lib.load().cnerf_pack_rays(_p(rays_o), _p(rays_d), B, float(near), float(far), int(use_viewdirs),
+                                           int(ndc), float(ndc_coef[0]), float(ndc_coef[1]), _p(rays), _stream()),
+               "cnerf_pack_rays")
+    return rays
+
+
+# ------------------------------------------------------------------------------------------ warp / masks
+def warp_points(P: Tensor, w2c, K, H: int, W: int, flip: bool):
+    P = _chk(P.reshape(-1, 3), "P")
+    N = P.shape[0]
+    dev = P.device
+    Xc = torch.empty(N, 3, device=dev)
+    px, py = torch.empty(N, device=dev), torch.empty(N, device=dev)
+    inb = torch.empty(N, device=dev, dtype=torch.uint8)
+    if isinstance(w2c, torch.Tensor):
+        w2c = w2c.detach().cpu().numpy()
+    _lib.check(_lib.load().cnerf_warp_points(_p(P), N, _f4(w2c), float(K[0][0]), float(K[1][1]), float(K[0][2]),
+                                             float(K[1][2]), H, W, int(flip), _p(Xc), _p(px), _p(py), _p(inb),
+                                             _stream()), "cnerf_warp_points")
+    return Xc, px, py, inb.bool()
+
+
+def hard_mask_pair(H, W, K, c2w_tgt, w2c_ref, depth_tgt: Tensor, depth_ref: Tensor, thr0: float, chunk: int,
+                   mask: Tensor, want_thr: bool = False):
+    depth_tgt, depth_ref = _chk(depth_tgt, "depth_tgt"), _chk(depth_ref, "depth_ref")
+    nchunks = (H * W + chunk - 1) // chunk
+    thr = torch.empty(nchunks, device=mask.device) if want_thr else None
+    _lib.check(_lib.load().cnerf_hard_mask_pair(H, W, float(K[0][0]), float(K[1][1]), float(K[0][2]), float(K[1][2]),
+                                                _f4(c2w_tgt), _f4(w2c_ref), _p(depth_tgt), _p(depth_ref), float(thr0),
+                                                chunk, _p(mask), _p(thr), _stream()), "cnerf_hard_mask_pair")
+    return thr
+
+
+# ------------------------------------------------------------------------------------------ loss / optimiser
+def masked_loss(rgb, target, depth, prior, mask, far: float, coef: float, counts=None, g_scale: float = 1.0,
+                want_grads: bool = True):
+    rgb, target = _chk(rgb, "rgb"), _chk(target, "target")
+    depth, prior, mask, counts = _chk(depth, "depth"), _chk(prior, "prior"), _chk(mask, "mask"), _chk(counts, "counts")
+    B = rgb.shape[0]
+    dev = rgb.device
+    loss = torch.empty(2, device=dev)
+    d_rgb = torch.empty_like(rgb) if want_grads else None
+    d_depth = torch.empty(B, device=dev) if (want_grads and depth is not None) else None
+    _lib.check(_lib.load().cnerf_masked_loss(_p(rgb), _p(target), _p(depth), _p(prior), _p(mask), B, float(far),
+                                             float(coef), _p(counts), float(g_scale), _p(loss), _p(d_rgb), _p(d_depth),
+                                             None, _stream()), "cnerf_masked_loss")
+    return loss, d_rgb, d_depth
+
+
+def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float, beta1=0.9, beta2=0.999, eps=1e-8,
+              clip: float = 0.0, grad_scale: float = 1.0):
+    for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32):
+            raise CnerfError(f"adam_step: {n} must be a contiguous fp32 GPU tensor")
+    _lib.check(_lib.load().cnerf_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), int(step), float(lr), float(beta1),
+                                           float(beta2), float(eps), float(clip), float(grad_scale), _stream()),
+               "cnerf_adam_step")

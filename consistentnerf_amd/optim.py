@@ -1,0 +1,85 @@
+"""Optimiser tail of the training step as ONE kernel over flat buffers:
+Adam(betas=(0.9,0.999), eps=1e-8) as created at R:210, optional clip_grad_value_ (V:1983) folded in,
+the caller keeps driving `param_groups[i]['lr']` per step exactly like R:784-788.
+
+Exposes the subset of torch.optim.Adam the reference driver touches: zero_grad(), step(), param_groups,
+state_dict(), load_state_dict() (R:768,780,787,802) — the state dict uses torch.optim.Adam's layout so
+checkpoints interchange.  Parameters are re-pointed into one flat fp32 buffer (same names / shapes /
+values), gradients into a second one: that flat gradient is also the single RCCL all-reduce message of the
+data-parallel path (distributed.py)."""
+from typing import Iterable, List
+
+import torch
+
+from . import ops
+
+
+class FusedAdam:
+    def __init__(self, params: Iterable[torch.nn.Parameter], lr=5e-4, betas=(0.9, 0.999), eps=1e-8,
+                 clip_value: float = 0.0):
+        self.params: List[torch.nn.Parameter] = [p for p in params]
+        if not self.params:
+            raise ValueError("FusedAdam got an empty parameter list")
+        dev = self.params[0].device
+        if dev.type != "cuda":
+            raise ops.CnerfError("FusedAdam needs GPU parameters (no CPU path)")
+        self.param_groups = [dict(params=self.params, lr=lr, betas=betas, eps=eps, clip_value=clip_value)]
+        self._step = 0
+        sizes = [p.numel() for p in self.params]
+        self._offsets = [0]
+        for n in sizes:
+            self._offsets.append(self._offsets[-1] + n)
+        total = self._offsets[-1]
+        self.flat_param = torch.empty(total, device=dev, dtype=torch.float32)
+        self.flat_grad = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.exp_avg = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.exp_avg_sq = torch.zeros(total, device=dev, dtype=torch.float32)
+        with torch.no_grad():
+            for p, o, n in zip(self.params, self._offsets, sizes):
+                self.flat_param[o:o + n].copy_(p.data.reshape(-1))
+                p.data = self.flat_param[o:o + n].view(p.shape)
+                p.grad = self.flat_grad[o:o + n].view(p.shape)
+
+    # -- torch.optim surface -------------------------------------------------------------------
+    def zero_grad(self, set_to_none: bool = False):
+        """Zeroes the flat gradient in place (the per-parameter .grad views stay attached)."""
+        self.flat_grad.zero_()
+        for p, o in zip(self.params, self._offsets):
+            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
+                p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
+
+    def step(self, grad_scale: float = 1.0):
+        g = self.param_groups[0]
+        self._step += 1
+        ops.adam_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self._step, g['lr'],
+                      g['betas'][0], g['betas'][1], g['eps'], g.get('clip_value', 0.0), grad_scale)
+        for p in self.params:   # the kernel wrote behind autograd's back: invalidate packed-weight caches
+            p._cnerf_epoch = getattr(p, "_cnerf_epoch", 0) + 1
+
+    def state_dict(self):
+        state = {}
+        for i, (p, o) in enumerate(zip(self.params, self._offsets)):
+            n = p.numel()
+            state[i] = {'step': torch.tensor(float(self._step)),
+                        'exp_avg': self.exp_avg[o:o + n].view(p.shape).clone(),
+                        'exp_avg_sq': self.exp_avg_sq[o:o + n].view(p.shape).clone()}
+        g = self.param_groups[0]
+        group = {k: v for k, v in g.items() if k != 'params'}
+        group.update(params=list(range(len(self.params))), amsgrad=False, weight_decay=0, maximize=False)
+        return {'state': state if self._step > 0 else {}, 'param_groups': [group]}
+
+    def load_state_dict(self, sd):
+        g = sd['param_groups'][0]
+        self.param_groups[0]['lr'] = g['lr']
+        self.param_groups[0]['betas'] = tuple(g.get('betas', (0.9, 0.999)))
+        self.param_groups[0]['eps'] = g.get('eps', 1e-8)
+        st = sd.get('state', {})
+        with torch.no_grad():
+            for i, (p, o) in enumerate(zip(self.params, self._offsets)):
+                s = st.get(i, st.get(str(i)))
+                if s is None:
+                    continue
+                n = p.numel()
+                self.exp_avg[o:o + n].copy_(s['exp_avg'].reshape(-1))
+                self.exp_avg_sq[o:o + n].copy_(s['exp_avg_sq'].reshape(-1))
+                self._step = int(float(s['step']))

@@ -1,0 +1,344 @@
+"""Drop-in for the render / model-construction surface of the reference's run_nerf.py (R):
+
+  batchify R:27 | run_network R:37 | batchify_rays R:55 | render R:70 | render_path R:140 |
+  create_nerf R:181 | raw2outputs R:265 | render_rays R:311
+
+Same signatures, kwargs dictionaries and return structures; the bodies launch the gfx950 kernels of
+libcnerf_hip.so (include/cnerf.h).  Autograd is wired with two torch.autograd.Function nodes (fused
+encoding+MLP, compositing); sampling carries no gradient, exactly like the reference (R:397).
+
+`run_nerf_view.py` of this package layers the ConsistentNeRF additions (depth outputs, warp, hard masks,
+masked losses) on top of this module.
+"""
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import ops
+from .optim import FusedAdam
+from .run_nerf_helpers import (NeRF, get_embedder, get_rays, img2mse, mse2psnr, ndc_coefficients,  # noqa: F401
+                               get_rays_np, ndc_rays, pytest_uniform, sample_pdf, sample_u, to8b)
+
+DEBUG = False
+
+
+# ----------------------------------------------------------------------------- autograd nodes
+class RayPoints:
+    """Lazy stand-in for the [N_rays, N_samples, 3] point tensor of R:384: the fused kernel evaluates
+    o + d*z itself, so the 9.4 MB/step point cloud is never written.  `.materialize()` gives the tensor."""
+
+    def __init__(self, rays, z_vals):
+        self.rays, self.z_vals = rays, z_vals
+        self.shape = torch.Size([z_vals.shape[0], z_vals.shape[1], 3])
+        self.device = z_vals.device
+
+    def materialize(self):
+        return self.rays[:, None, 0:3] + self.rays[:, None, 3:6] * self.z_vals[..., None]
+
+
+def _packed(model):
+    """Kernel-layout weights of `model`, re-packed only when a parameter changed (optimizer step / load)."""
+    ts = model.kernel_tensors()
+    key = tuple((t.data_ptr(), t._version, getattr(t, "_cnerf_epoch", 0)) for t in ts)
+    cache = getattr(model, "_cnerf_packed", None)
+    if cache is None or cache[0] != key:
+        with torch.no_grad():
+            packed = ops.pack_weights(model.spec(), ts, None if cache is None else cache[1])
+        cache = (key, packed)
+        model._cnerf_packed = cache
+    return cache[1]
+
+
+class _MlpFn(torch.autograd.Function):
+    """Fused gamma(x), gamma(d) + MLP (replaces R:37-52 + H:44-45 + H:107-130 and their autograd)."""
+
+    @staticmethod
+    def forward(ctx, model, B, S, pts, rays, z, dirs, *params):
+        spec = model.spec()
+        packed = _packed(model)
+        train = any(ctx.needs_input_grad[7:])
+        raw, stash = ops.mlp_forward(spec, packed, B, S, pts=pts, rays=rays, z=z, dirs=dirs, want_stash=train)
+        if train:
+            # the packed buffer is reused by the next pack; keep this step's copy for the backward
+            ctx.spec, ctx.B, ctx.S, ctx.stash, ctx.packed = spec, B, S, stash, packed.clone()
+        return raw
+
+    @staticmethod
+    def backward(ctx, g_raw):
+        grads = ops.mlp_backward(ctx.spec, ctx.packed, g_raw.contiguous(), ctx.B, ctx.S, ctx.stash)
+        ctx.stash = ctx.packed = None
+        return (None,) * 7 + tuple(grads)
+
+
+class _CompositeFn(torch.autograd.Function):
+    """raw2outputs (R:265-308) and its backward."""
+
+    @staticmethod
+    def forward(ctx, raw, z_vals, rays, noise, white_bkgd):
+        rgb, disp, acc, weights, depth = ops.composite_forward(raw, z_vals, rays, noise, white_bkgd)
+        ctx.save_for_backward(raw, z_vals, rays)
+        ctx.noise, ctx.white = noise, white_bkgd
+        ctx.mark_non_differentiable(weights)
+        ctx.set_materialize_grads(False)
+        return rgb, disp, acc, weights, depth
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_disp, g_acc, g_weights, g_depth):
+        raw, z_vals, rays = ctx.saved_tensors
+        d_raw = ops.composite_backward(raw, z_vals, rays, ctx.noise, ctx.white, g_rgb, g_disp, g_acc, g_depth)
+        return d_raw, None, None, None, None
+
+
+# ----------------------------------------------------------------------------- reference surface
+def batchify(fn, chunk):
+    """R:27-34.  Kept for API parity; the fused kernel tiles internally so chunking is a no-op."""
+    if chunk is None:
+        return fn
+
+    def ret(inputs):
+        return torch.cat([fn(inputs[i:i + chunk]) for i in range(0, inputs.shape[0], chunk)], 0)
+    return ret
+
+
+def run_network(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk=1024 * 64):
+    """R:37-52.  inputs: [N_rays, N_samples, 3] tensor (or the lazy RayPoints render_rays passes);
+    viewdirs: [N_rays, 3] or None.  embed_fn / embeddirs_fn only have to agree with the widths `fn` was
+    built with (the encodings are generated inside the kernel); netchunk is advisory (results are
+    chunk-invariant, R:79-80)."""
+    if not isinstance(fn, NeRF):
+        raise TypeError("run_network needs a consistentnerf_amd NeRF module")
+    spec = fn.spec()
+    if getattr(embed_fn, "out_dim", 3) != fn.input_ch:
+        raise ValueError("embed_fn width does not match the network input_ch")
+    if spec.use_viewdirs:
+        if viewdirs is None:
+            raise ValueError("network was built with use_viewdirs=True but viewdirs is None")
+        if embeddirs_fn is not None and getattr(embeddirs_fn, "out_dim", 3) != fn.input_ch_views:
+            raise ValueError("embeddirs_fn width does not match the network input_ch_views")
+    B, S = inputs.shape[0], inputs.shape[1]
+    dirs = viewdirs.contiguous() if (viewdirs is not None and spec.use_viewdirs) else None
+    params = fn.kernel_tensors()
+    if isinstance(inputs, RayPoints):
+        return _MlpFn.apply(fn, B, S, None, inputs.rays, inputs.z_vals, dirs, *params)
+    pts = inputs.reshape(-1, 3).contiguous()
+    return _MlpFn.apply(fn, B, S, pts, None, None, dirs, *params)
+
+
+def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0, white_bkgd=False, pytest=False):
+    """R:265-308 -> (rgb_map, disp_map, acc_map, weights, depth_map)."""
+    B = z_vals.shape[0]
+    rays = torch.cat([torch.zeros_like(rays_d), rays_d], -1).contiguous()
+    noise = _density_noise(raw.shape[:2], raw_noise_std, pytest, raw.device)
+    return _CompositeFn.apply(raw.contiguous(), z_vals.contiguous(), rays, noise, bool(white_bkgd))
+
+
+def _density_noise(shape, raw_noise_std, pytest, device):
+    if not raw_noise_std > 0.:
+        return None
+    if pytest:   # R:290-294: uniform in pytest mode
+        return pytest_uniform(tuple(shape), device) * raw_noise_std
+    return torch.randn(tuple(shape), device=device) * raw_noise_std
+
+
+def batchify_rays(rays_flat, chunk=1024 * 32, **kwargs):
+    """R:55-67."""
+    all_ret = {}
+    for i in range(0, rays_flat.shape[0], chunk):
+        ret = render_rays(rays_flat[i:i + chunk], **kwargs)
+        for k in ret:
+            all_ret.setdefault(k, []).append(ret[k])
+    return {k: (v[0] if len(v) == 1 else torch.cat(v, 0)) for k, v in all_ret.items()}
+
+
+def _ray_batch(H, W, K, rays, c2w, ndc, near, far, use_viewdirs, c2w_staticcam, device):
+    """R:97-125 -> (rays [B, 8|11], output leading shape)."""
+    coef = ndc_coefficients(H, W, K[0][0]) if ndc else (0., 0.)
+    if torch.is_tensor(near) or torch.is_tensor(far):
+        near_s, far_s = 0., 1.
+    else:
+        near_s, far_s = near, far
+    if c2w is not None:
+        sh = (H, W)
+        if c2w_staticcam is not None and use_viewdirs:
+            # viewdirs from c2w, geometry from the static camera (R:104-108)
+            vd = ops.gen_rays(H, W, K, c2w, near_s, far_s, True, False, device)[:, 8:11]
+            batch = ops.gen_rays(H, W, K, c2w_staticcam, near_s, far_s, True, ndc, device, coef)
+            batch[:, 8:11] = vd
+        else:
+            batch = ops.gen_rays(H, W, K, c2w, near_s, far_s, use_viewdirs, ndc, device, coef)
+    else:
+        rays_o, rays_d = rays
+        sh = tuple(rays_d.shape[:-1])
+        batch = ops.pack_rays(rays_o.to(device), rays_d.to(device), near_s, far_s, use_viewdirs, ndc, coef)
+    if torch.is_tensor(near):
+        batch[:, 6] = near.reshape(-1).to(batch)
+    if torch.is_tensor(far):
+        batch[:, 7] = far.reshape(-1).to(batch)
+    return batch, sh
+
+
+def _default_device():
+    if not torch.cuda.is_available():
+        raise ops.CnerfError("consistentnerf_amd needs an MI355X (no CPU execution path)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far=1., use_viewdirs=False,
+           c2w_staticcam=None, **kwargs):
+    """R:70-137 -> [rgb_map, disp_map, acc_map, extras]."""
+    return _render(H, W, K, chunk, rays, c2w, ndc, near, far, use_viewdirs, c2w_staticcam, False, kwargs)
+
+
+def _render(H, W, K, chunk, rays, c2w, ndc, near, far, use_viewdirs, c2w_staticcam, with_depth, kwargs):
+    net = kwargs.get("network_fn")
+    device = next(net.parameters()).device if net is not None else _default_device()
+    batch, sh = _ray_batch(H, W, K, rays, c2w, ndc, near, far, use_viewdirs, c2w_staticcam, device)
+    all_ret = batchify_rays(batch, chunk, _with_depth=with_depth, **kwargs)
+    for k in all_ret:
+        all_ret[k] = torch.reshape(all_ret[k], list(sh) + list(all_ret[k].shape[1:]))
+    k_extract = ['rgb_map', 'disp_map', 'acc_map'] + (['depth_map'] if with_depth else [])
+    ret_list = [all_ret[k] for k in k_extract]
+    ret_dict = {k: all_ret[k] for k in all_ret if k not in k_extract}
+    return ret_list + [ret_dict]
+
+
+def render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedir=None, render_factor=0):
+    """R:140-178 -> (rgbs, disps) numpy."""
+    H, W, focal = hwf
+    if render_factor != 0:
+        H, W, focal = H // render_factor, W // render_factor, focal / render_factor
+    rgbs, disps = [], []
+    t = time.time()
+    for i, c2w in enumerate(render_poses):
+        print(i, time.time() - t)
+        t = time.time()
+        with torch.no_grad():
+            rgb, disp, acc, _ = render(H, W, K, chunk=chunk, c2w=c2w[:3, :4], **render_kwargs)
+        rgbs.append(rgb.cpu().numpy())
+        disps.append(disp.cpu().numpy())
+        if i == 0:
+            print(rgb.shape, disp.shape)
+        if savedir is not None:
+            _save_png(os.path.join(savedir, '{:03d}.png'.format(i)), to8b(rgbs[-1]))
+    return np.stack(rgbs, 0), np.stack(disps, 0)
+
+
+def _save_png(path, img8):
+    try:
+        import imageio
+        imageio.imwrite(path, img8)
+    except ImportError:   # image IO is outside the hot path; keep the render usable without imageio
+        np.save(path + ".npy", img8)
+
+
+def create_nerf(args):
+    """R:181-262 -> (render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer)."""
+    return _create_nerf(args, NeRF, False)
+
+
+def _create_nerf(args, model_cls, view_variant):
+    device = _default_device()
+    embed_fn, input_ch = get_embedder(args.multires, args.i_embed)
+    input_ch_views, embeddirs_fn = 0, None
+    if args.use_viewdirs:
+        embeddirs_fn, input_ch_views = get_embedder(args.multires_views, args.i_embed)
+    output_ch = 5 if args.N_importance > 0 else 4
+    skips = [4]
+    extra = dict(coarse=True, stable_init=getattr(args, "stable_init", False)) if view_variant else {}
+    model = model_cls(D=args.netdepth, W=args.netwidth, input_ch=input_ch, output_ch=output_ch, skips=skips,
+                      input_ch_views=input_ch_views, use_viewdirs=args.use_viewdirs, **extra).to(device)
+    grad_vars = list(model.parameters())
+    model_fine = None
+    if args.N_importance > 0:
+        extra_f = dict(stable_init=getattr(args, "stable_init", False)) if view_variant else {}
+        model_fine = model_cls(D=args.netdepth_fine, W=args.netwidth_fine, input_ch=input_ch, output_ch=output_ch,
+                               skips=skips, input_ch_views=input_ch_views, use_viewdirs=args.use_viewdirs,
+                               **extra_f).to(device)
+        grad_vars += list(model_fine.parameters())
+    if view_variant:   # V:321: the coarse net starts as a copy of the fine net
+        model.load_state_dict(model_fine.state_dict())
+
+    def network_query_fn(inputs, viewdirs, network_fn):
+        return run_network(inputs, viewdirs, network_fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn,
+                           netchunk=args.netchunk)
+
+    optimizer = FusedAdam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999))
+    start = 0
+    basedir, expname = args.basedir, args.expname
+    if args.ft_path is not None and args.ft_path != 'None':
+        ckpts = [args.ft_path]
+    else:
+        d = os.path.join(basedir, expname)
+        ckpts = [os.path.join(d, f) for f in sorted(os.listdir(d)) if 'tar' in f] if os.path.isdir(d) else []
+    print('Found ckpts', ckpts)
+    if len(ckpts) > 0 and not args.no_reload:
+        ckpt_path = ckpts[-1]
+        print('Reloading from', ckpt_path)
+        ckpt = torch.load(ckpt_path, map_location=device, weights_only=False)
+        start = ckpt['global_step']
+        if not view_variant:      # V:351 skips the optimizer reload
+            optimizer.load_state_dict(ckpt['optimizer_state_dict'])
+        sd_c, sd_f = ckpt['network_fn_state_dict'], ckpt.get('network_fine_state_dict')
+        if view_variant:          # V:353-358 resets the three scalars
+            for sd in (sd_c, sd_f):
+                if sd is not None:
+                    for k in ('temp_rgb', 'temp_depth', 'depth_scale'):
+                        sd[k] = torch.full((1,), 0.1, device=device)
+        model.load_state_dict(sd_c)
+        if model_fine is not None and sd_f is not None:
+            model_fine.load_state_dict(sd_f)
+    render_kwargs_train = {
+        'network_query_fn': network_query_fn, 'perturb': args.perturb, 'N_importance': args.N_importance,
+        'network_fine': model_fine, 'N_samples': args.N_samples, 'network_fn': model,
+        'use_viewdirs': args.use_viewdirs, 'white_bkgd': args.white_bkgd, 'raw_noise_std': args.raw_noise_std,
+    }
+    if args.dataset_type != 'llff' or args.no_ndc:
+        print('Not ndc!')
+        render_kwargs_train['ndc'] = False
+        render_kwargs_train['lindisp'] = args.lindisp
+    render_kwargs_test = {k: render_kwargs_train[k] for k in render_kwargs_train}
+    render_kwargs_test['perturb'] = False
+    render_kwargs_test['raw_noise_std'] = 0.
+    return render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer
+
+
+def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False, lindisp=False, perturb=0.,
+                N_importance=0, network_fine=None, white_bkgd=False, raw_noise_std=0., verbose=False, pytest=False,
+                _with_depth=False):
+    """R:311-421 (V:441-551 when _with_depth).  Returns the same dict."""
+    rays = ray_batch if ray_batch.is_contiguous() else ray_batch.contiguous()
+    N_rays, dev = rays.shape[0], rays.device
+    viewdirs = rays[:, -3:] if rays.shape[-1] > 8 else None
+    t_rand = None
+    if perturb > 0.:
+        t_rand = pytest_uniform((N_rays, N_samples), dev) if pytest else torch.rand(N_rays, N_samples, device=dev)
+    z_vals = ops.coarse_z(rays, N_samples, t_rand, lindisp)
+    raw = network_query_fn(RayPoints(rays, z_vals), viewdirs, network_fn)
+    noise = _density_noise((N_rays, N_samples), raw_noise_std, pytest, dev)
+    rgb_map, disp_map, acc_map, weights, depth_map = _CompositeFn.apply(raw, z_vals, rays, noise, bool(white_bkgd))
+    if N_importance > 0:
+        rgb_map_0, disp_map_0, acc_map_0, depth_map_0 = rgb_map, disp_map, acc_map, depth_map
+        u = sample_u(N_rays, N_importance, perturb == 0., pytest, dev)
+        z_vals, z_std = ops.resample(z_vals, weights, u)          # R:395-399 + R:415, no gradient (R:397)
+        run_fn = network_fn if network_fine is None else network_fine
+        raw = network_query_fn(RayPoints(rays, z_vals), viewdirs, run_fn)
+        noise = _density_noise((N_rays, N_samples + N_importance), raw_noise_std, pytest, dev)
+        rgb_map, disp_map, acc_map, weights, depth_map = _CompositeFn.apply(raw, z_vals, rays, noise,
+                                                                            bool(white_bkgd))
+    ret = {'rgb_map': rgb_map, 'disp_map': disp_map, 'acc_map': acc_map}
+    if _with_depth:
+        ret['depth_map'] = depth_map
+    if retraw:
+        ret['raw'] = raw
+    if N_importance > 0:
+        ret['rgb0'], ret['disp0'], ret['acc0'] = rgb_map_0, disp_map_0, acc_map_0
+        if _with_depth:
+            ret['depth0'] = depth_map_0
+        ret['z_std'] = z_std
+    if DEBUG:
+        for k in ret:
+            if torch.isnan(ret[k]).any() or torch.isinf(ret[k]).any():
+                print(f"! [Numerical Error] {k} contains nan or inf.")
+    return ret

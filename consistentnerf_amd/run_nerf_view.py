@@ -1,0 +1,161 @@
+"""Drop-in for the hot-path surface of the reference's run_nerf_view.py (V) — the ConsistentNeRF driver:
+
+  render V:183-249 (4 maps + extras) | render_path V:252-294 (rgbs, disps, accs) | create_nerf V:297-389 |
+  render_rays V:441-551 | raw2outputs V:392-438 | get_rays_ref V:553 | get_ref_rays V:576 |
+  get_test_label V:630 | the hard-mask precompute of train() V:994-1046 (`compute_hard_masks`) |
+  the masked RGB / depth losses V:1645-1648, V:1737, V:1786-1788, V:1865 (`hardmask_losses`)
+
+The older in-loop variant of the warp (run_nerf_view_test.py VT:451-501: no axis flip, masked points) is
+available through `get_ref_rays(..., variant="VT")`.
+"""
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import ops
+from . import run_nerf as _R
+from .run_nerf import (batchify, batchify_rays, raw2outputs, run_network)  # noqa: F401
+from .run_nerf_helpers import (NeRF, get_embedder, get_rays, get_rays_np, img2mse, mse2psnr, ndc_rays,  # noqa: F401
+                               sample_pdf, to8b)
+
+
+def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far=1., use_viewdirs=False,
+           c2w_staticcam=None, **kwargs):
+    """V:183-249 -> [rgb_map, disp_map, acc_map, depth_map, extras]."""
+    return _R._render(H, W, K, chunk, rays, c2w, ndc, near, far, use_viewdirs, c2w_staticcam, True, kwargs)
+
+
+def render_rays(ray_batch, network_fn, network_query_fn, N_samples, **kw):
+    """V:441-551."""
+    kw.pop("_with_depth", None)
+    return _R.render_rays(ray_batch, network_fn, network_query_fn, N_samples, _with_depth=True, **kw)
+
+
+def render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedir=None, render_factor=0):
+    """V:252-294 -> (rgbs, disps, accs) numpy."""
+    H, W, focal = hwf
+    if render_factor != 0:
+        H, W, focal = H // render_factor, W // render_factor, focal / render_factor
+    rgbs, disps, accs = [], [], []
+    t = time.time()
+    for i, c2w in enumerate(render_poses):
+        print(i, time.time() - t)
+        t = time.time()
+        with torch.no_grad():
+            rgb, disp, acc, _, _ = render(H, W, K, chunk=chunk, c2w=c2w[:3, :4], **render_kwargs)
+        rgbs.append(rgb.cpu().numpy())
+        disps.append(disp.cpu().numpy())
+        accs.append(acc.cpu().numpy())
+        if i == 0:
+            print(rgb.shape, disp.shape)
+        if savedir is not None:
+            _R._save_png(os.path.join(savedir, 'color_{:03d}.png'.format(i)), to8b(rgbs[-1]))
+    return np.stack(rgbs, 0), np.stack(disps, 0), np.stack(accs, 0)
+
+
+def create_nerf(args):
+    """V:297-389 (coarse initialised from fine, stable_init, scalars reset on reload)."""
+    if args.N_importance <= 0:
+        raise ValueError("run_nerf_view.create_nerf copies the fine net into the coarse one (V:321): "
+                         "N_importance must be > 0; use run_nerf.create_nerf otherwise")
+    return _R._create_nerf(args, NeRF, True)
+
+
+# ----------------------------------------------------------------------------- cross-view warp (a12)
+def get_rays_ref(directions, c2w):
+    """V:553-574: camera-frame directions [..., 3] -> world rays through the reference camera."""
+    rays_d = directions @ c2w[:3, :3].T
+    rays_o = c2w[:3, 3].expand(rays_d.shape)
+    return rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)
+
+
+def _warp(w2c_ref, intrinsic_ref, point_samples, H, W, flip):
+    P = point_samples.reshape(-1, 3)
+    return ops.warp_points(P, w2c_ref[0], intrinsic_ref[0].detach().cpu().numpy(), H, W, flip)
+
+
+def get_ref_rays(w2c_ref, c2w_ref, intrinsic_ref, point_samples, img, depths_h=None, variant="V"):
+    """V:576-627 (variant="VT": VT:451-501).  Batch size 1 (the only use in the reference).
+    point_samples [1, N_rays, N_samples, 3]; img [1, 3, H, W]; depths_h [1, H, W].
+    Returns (rgb_ref [1,3,M], depth_ref [1,1,M], point_samples_cam, rays_o [M,3], rays_d [M,3], mask [1,N])."""
+    assert point_samples.shape[0] == 1 and img.shape[0] == 1, "reference only ever uses batch 1"
+    _, _, H, W = img.shape
+    Xc, px, py, inb = _warp(w2c_ref, intrinsic_ref, point_samples, H, W, variant == "V")
+    xs, ys = px[inb], py[inb]
+    Kr = intrinsic_ref[0]
+    directions = torch.stack([(xs - Kr[0, 2]) / Kr[0, 0], (ys - Kr[1, 2]) / Kr[1, 1], torch.ones_like(xs)], -1)
+    rays_o, rays_d = get_rays_ref(directions, c2w_ref[0].to(xs.device))
+    yi, xi = ys.long(), xs.long()
+    rgb_ref = img[:, :, yi, xi]
+    pts_cam = Xc[None] if variant == "V" else Xc[inb]
+    mask = inb[None]
+    if depths_h is not None:
+        return rgb_ref, depths_h.unsqueeze(1)[:, :, yi, xi], pts_cam, rays_o, rays_d, mask
+    return rgb_ref, pts_cam, rays_o, rays_d, mask
+
+
+def get_test_label(w2c_ref, c2w_ref, intrinsic_ref, point_samples, img):
+    """V:630-669 -> (pixel_y [1,N], pixel_x [1,N], mask [1,N], cam_z [1,N])."""
+    _, _, H, W = img.shape
+    Xc, px, py, inb = _warp(w2c_ref, intrinsic_ref, point_samples, H, W, True)
+    return py[None], px[None], inb[None], Xc[None, :, 2]
+
+
+# ----------------------------------------------------------------------------- hard masks (a13)
+def compute_hard_masks(H, W, K, poses, depths_cas, i_train, occlusion_threshold=0.1, chunk=5120,
+                       device=None, return_thresholds=False):
+    """The mask precompute of train() (V:994-1046): for every training view, OR over the other training
+    views of (projects in-bounds AND |depth in ref camera - ref depth prior| < threshold), the threshold
+    doubled per 5120-pixel chunk until some pixel of the chunk passes.  Non-training views get zeros.
+    poses [N,3,4] (c2w), depths_cas [N,H,W].  Returns bool numpy [N,H,W] like `masks_cas`."""
+    device = device or _R._default_device()
+    poses = np.asarray(poses, np.float32)
+    N = poses.shape[0]
+    dep = [torch.as_tensor(np.ascontiguousarray(depths_cas[i], np.float32), device=device).reshape(-1)
+           for i in range(N)]
+    w2c = {}
+    for r in i_train:
+        c2w = torch.eye(4)
+        c2w[:3, :4] = torch.from_numpy(poses[r, :3, :4])
+        w2c[r] = torch.inverse(c2w).numpy()          # 4x4 host inverse, as V:1008-1010
+    masks, thr = [], {}
+    for t in range(N):
+        m = torch.zeros(H * W, dtype=torch.uint8, device=device)
+        if t in i_train:
+            for r in i_train:
+                if r == t:
+                    continue
+                th = ops.hard_mask_pair(H, W, K, poses[t], w2c[r], dep[t], dep[r], occlusion_threshold, chunk, m,
+                                        want_thr=return_thresholds)
+                if return_thresholds:
+                    thr[(t, r)] = th.cpu().numpy()
+        masks.append(m.reshape(H, W).bool().cpu().numpy())
+    masks = np.stack(masks, 0)
+    return (masks, thr) if return_thresholds else masks
+
+
+# ----------------------------------------------------------------------------- masked losses (a14)
+class _MaskedLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rgb, depth, target, prior, mask, far, coef, counts):
+        loss, d_rgb, d_depth = ops.masked_loss(rgb, target, depth, prior, mask, far, coef, counts)
+        ctx.save_for_backward(d_rgb, d_depth if d_depth is not None else torch.empty(0, device=rgb.device))
+        ctx.has_depth = depth is not None
+        return loss[0], loss[1]
+
+    @staticmethod
+    def backward(ctx, g_rgb_loss, g_depth_loss):
+        d_rgb, d_depth = ctx.saved_tensors
+        gr = d_rgb * g_rgb_loss if g_rgb_loss is not None else None
+        gd = d_depth * g_depth_loss if (ctx.has_depth and g_depth_loss is not None) else None
+        return gr, gd, None, None, None, None, None, None
+
+
+def hardmask_losses(rgb, target, mask, hardmask_coef=0.2, depth=None, depth_prior=None, far=1.0, counts=None):
+    """(img_loss, depth_loss) of one level: V:1645-1648 / V:1786-1788 and V:1737 / V:1865.
+    mask [B] of 0/1 floats (None = plain img2mse, R:769).  `counts` = (n_masked, n_unmasked) tensor when the
+    batch is sharded over ranks (distributed.global_mask_counts) so the means stay global."""
+    m = None if mask is None else mask.reshape(-1).to(torch.float32)
+    return _MaskedLossFn.apply(rgb, depth, target, depth_prior, m, float(far), float(hardmask_coef), counts)

@@ -1,0 +1,177 @@
+/* cnerf.h — C ABI of libcnerf_hip.so: the MI355X (gfx950) NeRF render/train hot path.
+ *
+ * The reference (skhu101/ConsistentNeRF, nerf-pytorch-master/) has no FFI boundary: its hot path is
+ * in-process Python composing ATen ops.  Every entry point below names the reference function
+ * (file:line, H = run_nerf_helpers.py, R = run_nerf.py, V = run_nerf_view.py) whose composition of
+ * ATen ops it replaces.  The Python drop-in surface (consistentnerf_amd/run_nerf.py) binds these
+ * through ctypes; INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C: raw DEVICE pointers, explicit sizes, a `void* stream` (hipStream_t; NULL = default).
+ *   - all tensors fp32 row-major contiguous unless a stride argument says otherwise; indices int64.
+ *   - return 0 on success, <0 for an argument error (CNERF_E_*), >0 = hipError_t of a failed launch.
+ *   - no entry point allocates, frees, or synchronises; workspaces are caller-provided and sized by
+ *     the matching *_floats / *_bytes query.  Re-entrant across streams; no global mutable state.
+ */
+#ifndef CNERF_H
+#define CNERF_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CNERF_ABI_VERSION 1
+
+#define CNERF_OK 0
+#define CNERF_E_ARG (-1)        /* null pointer / negative size / inconsistent shapes            */
+#define CNERF_E_UNSUPPORTED (-2) /* architecture outside the compiled envelope (see cnerf_net)    */
+#define CNERF_E_NODEVICE (-3)   /* no gfx950 device visible                                       */
+
+/* Architecture of one NeRF MLP (H:67-130; created by create_nerf R:181-204).
+ * Compiled envelope: W in {64,128,256}; 1 <= D <= 16 and D != skip+1; 3+6*multires <= 64;
+ * 3+6*multires_views <= 32; use_viewdirs in {0,1}; output_ch in 1..8 (used only without viewdirs). */
+typedef struct cnerf_net {
+  int32_t D;               /* trunk depth  (netdepth)                                        */
+  int32_t W;               /* trunk width  (netwidth)                                        */
+  int32_t multires;        /* L of the point encoding, -1 = identity (i_embed=-1)           */
+  int32_t multires_views;  /* L of the direction encoding                                    */
+  int32_t use_viewdirs;    /* view-dependent colour branch (H:116-126)                       */
+  int32_t output_ch;       /* width of output_linear when use_viewdirs==0 (R:190)            */
+  int32_t skip;            /* trunk layer after which gamma(x) is re-concatenated (4), or -1  */
+} cnerf_net;
+
+/* Number / order of the parameter tensors of a net, as in the reference state_dict minus the three
+ * ConsistentNeRF scalars (H:79-84):  pts_linears.{0..D-1}.{weight,bias}, views_linears.0.{weight,bias},
+ * then feature_linear, alpha_linear, rgb_linear (viewdirs) or output_linear.  Weights are [out,in]. */
+#define CNERF_MAX_TENSORS 48
+int cnerf_num_tensors(const cnerf_net* net);
+/* shape of tensor i: rows (out), cols (in; 1 for a bias -> rows-long vector). */
+int cnerf_tensor_shape(const cnerf_net* net, int i, int64_t* rows, int64_t* cols);
+
+typedef struct cnerf_ptrs { float* p[CNERF_MAX_TENSORS]; } cnerf_ptrs;
+
+const char* cnerf_strerror(int code);
+int cnerf_abi_version(void);
+/* 0 if device `dev` is a gfx950 part; fills name (<=63 chars), #CUs and LDS/CU bytes. */
+int cnerf_device_info(int dev, char* name64, int* num_cus, int* lds_bytes);
+
+/* ---- weights: nn.Parameter tensors <-> kernel layout ------------------------------------------ */
+/* Floats in the packed buffer (forward K-grouped panels, transposed panels for dgrad, heads, biases). */
+int64_t cnerf_packed_floats(const cnerf_net* net);
+/* Re-pack the parameter tensors (device pointers, state-dict order above) into `packed`.  Called once
+ * per optimiser step (replaces nothing in the reference; it is the price of the MFMA operand layout). */
+int cnerf_pack_weights(const cnerf_net* net, const cnerf_ptrs* params, float* packed, void* stream);
+
+/* ---- a3: sample placement  (render_rays R:355-382) --------------------------------------------- */
+/* z[B,Nc] from near/far in rays[:,6:8]; t_vals[Nc] = linspace(0,1,Nc) supplied by the host so both
+ * sides use identical constants; t_rand[B,Nc] (U[0,1), or NULL when perturb==0) drives the stratified
+ * jitter; lindisp selects inverse-depth spacing. */
+int cnerf_coarse_z(const float* rays, int ray_stride, int64_t B, int Nc, const float* t_vals,
+                   const float* t_rand, int lindisp, float* z, void* stream);
+
+/* ---- a5: stand-alone positional encoding (Embedder.embed H:15-45): x[M,3] -> out[M, 3+6L]. The render
+ *      path does not use it (encodings are generated inside cnerf_mlp_fwd and never reach HBM). */
+int cnerf_embed(const float* x, int64_t M, int L, float* out, void* stream);
+
+/* ---- a4+a5+a6: positional encoding + MLP  (run_network R:37-52, Embedder H:15-63, NeRF.forward
+ *      H:107-130), fused; fp32 MFMA (v_mfma_f32_32x32x2_f32), activations never leave the CU. ------ */
+/* Points are either explicit (pts[M,3], M=B*S) or implicit o + d*z (pts==NULL, rays/z given, R:384).
+ * View directions are rays[:, ray_stride-3 : ray_stride] (one per ray, broadcast over its S samples)
+ * or `dirs[B,3]` when non-NULL.  raw[M, C], C = 4 with viewdirs else output_ch.
+ * `stash` == NULL: inference.  Otherwise (training) the kernel also writes the activations the backward
+ * needs; size = cnerf_mlp_stash_floats(net, M). */
+int64_t cnerf_mlp_stash_floats(const cnerf_net* net, int64_t M);
+int cnerf_mlp_fwd(const cnerf_net* net, const float* packed, const float* pts, const float* rays,
+                  int ray_stride, const float* dirs, const float* z, int64_t B, int S, float* raw,
+                  float* stash, void* stream);
+/* Backward of the above (autograd of R:37-52 / H:107-130): d_raw[M,C] -> gradients of every parameter
+ * tensor.  `grads` holds device pointers laid out like `params`; accumulate!=0 adds into them.
+ * workspace size = cnerf_mlp_bwd_ws_floats(net, M). */
+int64_t cnerf_mlp_bwd_ws_floats(const cnerf_net* net, int64_t M);
+int cnerf_mlp_bwd(const cnerf_net* net, const float* packed, const float* d_raw, int64_t B, int S,
+                  const float* stash, float* workspace, const cnerf_ptrs* grads, int accumulate,
+                  void* stream);
+/* The two halves of cnerf_mlp_bwd, separately launchable (same workspace): activation gradients
+ * (fused dgrad chain, one wave per 32 points) and weight gradients (point-contracted GEMMs + reduction). */
+int cnerf_mlp_dgrad(const cnerf_net* net, const float* packed, const float* d_raw, int64_t B, int S,
+                    const float* stash, float* workspace, void* stream);
+int cnerf_mlp_wgrad(const cnerf_net* net, int64_t B, int S, const float* stash, float* workspace,
+                    const cnerf_ptrs* grads, int accumulate, void* stream);
+
+/* ---- a7: alpha compositing  (raw2outputs R:265-308 / V:392-438) -------------------------------- */
+/* One wave64 per ray.  raw[B,S,C] (C>=4; channels 0..2 colour logits, 3 density), z[B,S], rays for
+ * |rays_d|, noise[B,S] already scaled by raw_noise_std or NULL.  Outputs: rgb[B,3] disp[B] acc[B]
+ * depth[B] weights[B,S] (any may be NULL).  Transmittance product scan carried in fp64 like the CPU
+ * reference's cumprod. */
+int cnerf_composite_fwd(const float* raw, int raw_ch, const float* z, const float* rays, int ray_stride,
+                        const float* noise, int64_t B, int S, int white_bkgd, float* rgb, float* disp,
+                        float* acc, float* depth, float* weights, void* stream);
+/* d_raw[B,S,C] (channels >=4 zeroed) from upstream grads (any may be NULL = 0). */
+int cnerf_composite_bwd(const float* raw, int raw_ch, const float* z, const float* rays, int ray_stride,
+                        const float* noise, int64_t B, int S, int white_bkgd, const float* g_rgb,
+                        const float* g_disp, const float* g_acc, const float* g_depth, float* d_raw,
+                        void* stream);
+
+/* ---- a8: inverse-CDF sampling  (sample_pdf H:206-250) ------------------------------------------ */
+/* bins[B,Nb], weights[B,Nb-1], u[B,Nf] (u_row_stride 0 broadcasts one row) -> samples[B,Nf];
+ * inds[B,Nf] int64 (searchsorted right=True result, the bit-exact parity target) optional. */
+int cnerf_sample_pdf(const float* bins, const float* weights, const float* u, int64_t u_row_stride,
+                     int64_t B, int Nb, int Nf, float* samples, int64_t* inds, void* stream);
+/* a8+a9 fused for render_rays (R:395-399,415): z_mid, sample_pdf(z_mid, weights[:,1:-1]), sort of the
+ * Nc+Nf depths, population std of the new samples.  z_fine[B,Nc+Nf], z_std[B]; samples/inds optional. */
+int cnerf_resample(const float* z, const float* weights, const float* u, int64_t u_row_stride, int64_t B,
+                   int Nc, int Nf, float* z_fine, float* z_std, float* samples, int64_t* inds,
+                   void* stream);
+
+/* ---- a1: ray generation  (get_rays H:164-173, ndc_rays H:186-202, render R:100-125) ------------- */
+/* Builds rays[H*W, 8|11] = o, d, near, far, (viewdirs) for a full image from c2w[3,4] (12 floats,
+ * HOST pointer) and K = fx, fy, cx, cy; viewdirs are normalised pre-NDC directions (R:103-110);
+ * ndc!=0 applies ndc_rays with near-plane 1 (R:116) using the two host-computed coefficients
+ * ndc_ax = -1/(W/(2 focal)), ndc_ay = -1/(H/(2 focal)) (H:193-199; computed on the host with the
+ * caller's own scalar types so they round exactly as in the reference expression). */
+int cnerf_gen_rays(int H, int W, float fx, float fy, float cx, float cy, const float* c2w_host,
+                   float near, float far, int use_viewdirs, int ndc, float ndc_ax, float ndc_ay,
+                   float* rays, void* stream);
+/* Same packing for a caller-provided batch rays_o[B,3], rays_d[B,3] (render(rays=...)). */
+int cnerf_pack_rays(const float* rays_o, const float* rays_d, int64_t B, float near, float far,
+                    int use_viewdirs, int ndc, float ndc_ax, float ndc_ay, float* rays, void* stream);
+
+/* ---- a12/a13: cross-view depth warp and hard masks  (get_ref_rays V:576-627, get_test_label
+ *      V:630-669, mask precompute V:994-1046) ---------------------------------------------------- */
+/* World points P[N,3] into the reference camera w2c[3,4] (HOST, 12 floats) with K (fx,fy,cx,cy):
+ * Xc[N,3] (axis-flipped to OpenCV when flip!=0, V:596), px[N], py[N] (rounded half-to-even, as
+ * floats), inb[N] (uint8, strict bounds V:611-613).  Any output may be NULL. */
+int cnerf_warp_points(const float* P, int64_t N, const float* w2c_host, float fx, float fy, float cx,
+                      float cy, int H, int W, int flip, float* Xc, float* px, float* py, uint8_t* inb,
+                      void* stream);
+/* One (target, reference) pair of the hard-mask precompute: for every pixel of the target view
+ * (rays from c2w_tgt, depth prior depth_tgt[H*W]) warp into the reference view and test
+ * |Xc_z - depth_ref[y,x]| < thr, thr = thr0 * 2^k with the smallest k>=0 that lets >=1 pixel of the
+ * pixel's 5120-chunk pass (V:1023-1029).  mask[H*W] (uint8) is OR-ed in place (V:1041);
+ * thr_out[ceil(H*W/chunk)] optional (NaN for chunks with no in-bounds pixel). */
+int cnerf_hard_mask_pair(int H, int W, float fx, float fy, float cx, float cy, const float* c2w_tgt_host,
+                         const float* w2c_ref_host, const float* depth_tgt, const float* depth_ref,
+                         float thr0, int chunk, uint8_t* mask, float* thr_out, void* stream);
+
+/* ---- a14: masked photometric / depth losses  (V:1645-1648, V:1737, V:1786-1788, V:1865) --------- */
+/* loss[0] = mean_{m==1}(rgb-t)^2 + coef*mean_{m==0}(rgb-t)^2 (second term only if some m==0);
+ * loss[1] = mean_{m==1}((depth-prior)/far)^2 (0 if depth==NULL).  Gradients d_rgb[B,3], d_depth[B]
+ * (scaled by g_scale) are written if non-NULL.  mask==NULL = plain MSE over all rays (R:769).
+ * counts[2] (n1, n0) may be supplied (e.g. all-reduced across ranks) or NULL to count locally.
+ * Uses `workspace` of cnerf_loss_ws_floats() floats. */
+int64_t cnerf_loss_ws_floats(void);
+int cnerf_masked_loss(const float* rgb, const float* target, const float* depth, const float* prior,
+                      const float* mask, int64_t B, float far, float coef, const float* counts,
+                      float g_scale, float* loss, float* d_rgb, float* d_depth, float* workspace,
+                      void* stream);
+
+/* ---- f-1: optimiser tail  (clip_grad_value_ V:1983, Adam R:210/780, lr decay R:784-788) --------- */
+/* In-place Adam over n contiguous floats; clip<=0 disables the value clip; step is 1-based. */
+int cnerf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr,
+                    float beta1, float beta2, float eps, float clip, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CNERF_H */

@@ -1,0 +1,421 @@
+"""GPU parity tests (run on the MI355X box: `pytest -m gpu`).  Every test drives the HIP path through the
+C ABI (ctypes -> libcnerf_hip.so) and compares with (a) the committed golden vectors captured from the
+reference and/or (b) the CPU oracle on the same seeded inputs.
+
+Stated tolerances (fp32 path, v_mfma_f32_32x32x2_f32 + OCML sin/cos/exp vs ATen/Sleef on the CPU):
+  raw network outputs      |d| <= 3e-5 * max(1, max|raw|)
+  rgb_map / acc_map        |d| <= 2e-5          depth_map  |d| <= 2e-5 * far
+  weights                  |d| <= 2e-5          z (coarse) bit-exact;  z (fine) |d| <= 2e-5 * far
+  sample_pdf indices       bit-exact wherever min_k |u - cdf_k| > 1e-5 (SURVEY hard part 3), mismatch rate reported
+  warp pixels / masks      bit-exact wherever the projected pixel is > 1e-3 px away from a rounding tie
+  gradients                |d| <= 2e-4 * max|g| per tensor
+"""
+import numpy as np
+import pytest
+import torch
+
+import _inputs as I
+from conftest import golden
+from oracle import nerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from consistentnerf_amd import ops
+    ok, name, cus, lds = ops.device_info(0)
+    print(f"device: {name} CUs={cus} LDS/CU={lds}")
+    assert ok, f"not a gfx950 device: {name}"
+    return torch.device("cuda:0")
+
+
+def T(a, dev=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return t.to(dev) if dev is not None else t
+
+
+def maxdiff(a, b):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    both_nan = np.isnan(a) & np.isnan(b)
+    d = np.abs(a.astype(np.float64) - b.astype(np.float64))
+    d[both_nan] = 0
+    assert not np.isnan(d).any(), "NaN mismatch"
+    return float(d.max()) if d.size else 0.0
+
+
+def check(a, b, atol, name):
+    d = maxdiff(a, b)
+    print(f"  {name}: max|d|={d:.3e} (tol {atol:.1e})")
+    assert d <= atol, f"{name}: max|d|={d:.3e} > {atol:.1e}"
+
+
+def make_model(D, W, vd, och, seed, dev):
+    from consistentnerf_amd.run_nerf_helpers import NeRF
+    sd = I.nerf_state_dict(D, W, 10, 4, och, vd, seed)
+    m = NeRF(D=D, W=W, input_ch=63, output_ch=och, skips=[4], input_ch_views=27 if vd else 0, use_viewdirs=vd)
+    m.load_state_dict({k: T(v) for k, v in sd.items()}, strict=True)
+    return m.to(dev), sd
+
+
+def check_param_grads(model, g, prefix_full, prefix_sum, rtol=2e-4):
+    worst = 0.0
+    for k, p in model.named_parameters():
+        gr = (p.grad if p.grad is not None else torch.zeros_like(p)).detach().cpu()
+        if prefix_full + k in g:
+            ref = g[prefix_full + k]
+            got = gr.numpy()
+        else:
+            ref = g[prefix_sum + k + ".sub"]
+            got = gr.reshape(-1)[::61].numpy()
+            a = float(g[prefix_sum + k + ".abssum"])
+            assert abs(gr.double().abs().sum().item() - a) <= 1e-3 * max(a, 1e-12) + 1e-9, f"{k} abssum"
+        scale = max(float(np.abs(ref).max()), 1e-12)
+        d = float(np.abs(got - ref).max()) / scale
+        worst = max(worst, d)
+        assert d <= rtol, f"grad {k}: rel max diff {d:.3e}"
+    print(f"  grads: worst rel max diff {worst:.3e}")
+
+
+# ------------------------------------------------------------------------------------------------
+def test_embed(dev):
+    from consistentnerf_amd import ops
+    g = golden("embed")
+    check(ops.embed(T(g["x"], dev), 10), g["L10"], 2e-6, "embed L10")
+    check(ops.embed(T(g["x"], dev), 4), g["L4"], 2e-6, "embed L4")
+
+
+@pytest.mark.parametrize("lindisp", [False, True])
+@pytest.mark.parametrize("perturb", [False, True])
+def test_coarse_z_bit_exact(dev, lindisp, perturb):
+    from consistentnerf_amd import ops
+    rays = T(I.ray_batch(300, seed=9), dev)
+    tr = O.pytest_uniform((300, 64)) if perturb else None
+    z = ops.coarse_z(rays, 64, tr.to(dev) if perturb else None, lindisp)
+    ref = O.coarse_z(rays[:, 6:7].cpu(), rays[:, 7:8].cpu(), 64, lindisp, tr)
+    assert torch.equal(z.cpu(), ref), f"max diff {maxdiff(z, ref)}"
+
+
+R2O = [("S64", 64, False, 0.0), ("S192", 192, False, 0.0), ("S64_white", 64, True, 0.0),
+       ("S192_white_noise", 192, True, 1.0)]
+
+
+@pytest.mark.parametrize("tag,S,white,noise", R2O)
+def test_composite_golden(dev, tag, S, white, noise):
+    from consistentnerf_amd.run_nerf import raw2outputs
+    g = golden("raw2outputs_" + tag)
+    raw, z, d = I.raw2outputs_inputs(32, S, seed=S + int(white))
+    rawt = T(raw, dev).requires_grad_(True)
+    rgb, disp, acc, w, depth = raw2outputs(rawt, T(z, dev), T(d, dev), noise, white, pytest=True)
+    check(rgb, g["rgb_map"], 2e-5, "rgb_map")
+    check(acc, g["acc_map"], 2e-5, "acc_map")
+    check(depth, g["depth_map"], 2e-5 * 6, "depth_map")
+    check(w, g["weights"], 2e-5, "weights")
+    dg, dr = disp.detach().cpu().numpy(), g["disp_map"]
+    assert np.array_equal(np.isnan(dg), np.isnan(dr)), "disp NaN pattern (acc==0 rays)"
+    ok = ~np.isnan(dr)
+    assert np.abs(dg[ok] - dr[ok]).max() <= 2e-5 * max(1.0, np.abs(dr[ok]).max())
+    loss = (rgb * T(g["g_rgb"], dev)).sum() + (depth * T(g["g_depth"], dev)).sum() + (acc * T(g["g_acc"], dev)).sum()
+    (d_raw,) = torch.autograd.grad(loss, rawt, retain_graph=True)
+    check(d_raw, g["d_raw"], 2e-4 * max(1.0, np.abs(g["d_raw"]).max()), "d_raw")
+    (dd,) = torch.autograd.grad((disp[2:] * T(g["g_disp"][2:], dev)).sum(), rawt)
+    check(dd, g["d_raw_disp"], 2e-4 * max(1.0, np.abs(g["d_raw_disp"]).max()), "d_raw (disp)")
+
+
+@pytest.mark.parametrize("tag", ["det", "rand"])
+def test_sample_pdf_indices(dev, tag):
+    from consistentnerf_amd import ops
+    g = golden("sample_pdf_" + tag)
+    bins, weights = I.sample_pdf_inputs(256, 64, seed=7)
+    samples, inds = ops.sample_pdf(T(bins, dev), T(weights, dev), T(g["u"], dev), want_inds=True)
+    inds = inds.cpu().numpy()
+    safe = g["margin"] > 1e-5
+    mism = inds != g["inds"]
+    print(f"  index mismatches: {mism.sum()} of {mism.size} ({(mism & safe).sum()} with margin > 1e-5)")
+    assert not (mism & safe).any(), "sample_pdf indices must be bit-exact away from CDF ties"
+    assert mism.mean() < 1e-3
+    check(samples, g["samples"], 2e-5 * 6, "samples")
+
+
+def test_resample_vs_oracle(dev):
+    from consistentnerf_amd import ops
+    rs = np.random.RandomState(3)
+    B, Nc, Nf = 257, 64, 128
+    z = np.sort(rs.uniform(2, 6, size=(B, Nc)), -1).astype(np.float32)
+    w = (rs.uniform(size=(B, Nc)) ** 6).astype(np.float32)
+    u = O.pytest_uniform((B, Nf))
+    zf, zstd, samples, inds = ops.resample(T(z, dev), T(w, dev), u.to(dev), want_samples=True)
+    zt, wt = T(z), T(w)
+    ref_s, ref_i = O.sample_pdf(0.5 * (zt[:, 1:] + zt[:, :-1]), wt[:, 1:-1], u)
+    ref_z, _ = torch.sort(torch.cat([zt, ref_s], -1), -1)
+    check(samples, ref_s, 2e-5 * 6, "z_samples")
+    check(zf, ref_z, 2e-5 * 6, "z_fine (sorted)")
+    assert (zf[:, 1:] >= zf[:, :-1]).all(), "sortedness"
+    check(zstd, torch.std(ref_s, dim=-1, unbiased=False), 2e-5, "z_std")
+    mism = (inds.cpu() != ref_i).float().mean().item()
+    print(f"  index mismatch rate vs oracle: {mism:.2e}")
+    assert mism < 1e-3
+
+
+MLP_CASES = [("D8W256_vd", 8, 256, True, 5), ("D4W128_vd", 4, 128, True, 4), ("D4W128_novd", 4, 128, False, 5),
+             ("D8W128_vd", 8, 128, True, 5)]
+
+
+@pytest.mark.parametrize("tag,D,W,vd,och", MLP_CASES)
+def test_mlp_golden(dev, tag, D, W, vd, och):
+    """a4+a5+a6 forward and backward against the reference capture (explicit-points mode)."""
+    from consistentnerf_amd.run_nerf import run_network
+    from consistentnerf_amd.run_nerf_helpers import get_embedder
+    g = golden("mlp_" + tag)
+    model, _ = make_model(D, W, vd, och, 11, dev)
+    e, _ = get_embedder(10, 0)
+    ed = get_embedder(4, 0)[0] if vd else None
+    raw = run_network(T(g["pts"], dev), T(g["dirs"], dev) if vd else None, model, e, ed)
+    scale = max(1.0, float(np.abs(g["raw"]).max()))
+    check(raw, g["raw"], 3e-5 * scale, "raw")
+    (raw * T(g["G"], dev)).sum().backward()
+    check_param_grads(model, g, "grad.", "gs.")
+
+
+RR = [("C1", 4, 128, 64, 0, 1.0, True, 0.0, False, 64), ("C1_noise", 4, 128, 64, 0, 1.0, True, 1.0, False, 32),
+      ("C2", 8, 256, 64, 128, 1.0, False, 0.0, False, 64), ("C2_det", 8, 256, 64, 128, 0.0, False, 0.0, False, 16),
+      ("small_lindisp", 4, 128, 32, 32, 1.0, False, 0.0, True, 32)]
+
+
+def _kwargs(coarse, fine, Nc, Nf, perturb, white, noise, lindisp):
+    from consistentnerf_amd.run_nerf import run_network
+    from consistentnerf_amd.run_nerf_helpers import get_embedder
+    e, _ = get_embedder(10, 0)
+    ed, _ = get_embedder(4, 0)
+    q = lambda inputs, viewdirs, fn: run_network(inputs, viewdirs, fn, embed_fn=e, embeddirs_fn=ed)  # noqa: E731
+    return dict(network_query_fn=q, perturb=perturb, N_importance=Nf, network_fine=fine, N_samples=Nc,
+                network_fn=coarse, white_bkgd=white, raw_noise_std=noise, lindisp=lindisp)
+
+
+@pytest.mark.parametrize("tag,D,W,Nc,Nf,perturb,white,noise,lindisp,B", RR)
+def test_render_rays_golden(dev, tag, D, W, Nc, Nf, perturb, white, noise, lindisp, B):
+    """a3 end to end (incl. a7-a9) against the reference capture, forward and parameter gradients."""
+    from consistentnerf_amd import run_nerf_view as V
+    g = golden("render_rays_" + tag)
+    och = 5 if Nf > 0 else 4
+    coarse, _ = make_model(D, W, True, och, 21, dev)
+    fine = make_model(D, W, True, och, 22, dev)[0] if Nf > 0 else None
+    rays = T(I.ray_batch(B, seed=3), dev)
+    ret = V.render_rays(rays, retraw=True, pytest=True, **_kwargs(coarse, fine, Nc, Nf, perturb, white, noise, lindisp))
+    assert set(ret) == {k for k in g if not k.startswith(("gc.", "gf.")) and k not in ("target", "prior", "loss")}
+    far = 6.0
+    check(ret["rgb_map"], g["rgb_map"], 2e-5, "rgb_map")
+    check(ret["acc_map"], g["acc_map"], 2e-5, "acc_map")
+    check(ret["depth_map"], g["depth_map"], 2e-5 * far, "depth_map")
+    check(ret["disp_map"], g["disp_map"], 2e-5, "disp_map")
+    check(ret["raw"], g["raw"], 3e-5 * max(1.0, float(np.abs(g["raw"]).max())), "raw")
+    if Nf > 0:
+        check(ret["rgb0"], g["rgb0"], 2e-5, "rgb0")
+        check(ret["depth0"], g["depth0"], 2e-5 * far, "depth0")
+        check(ret["acc0"], g["acc0"], 2e-5, "acc0")
+        check(ret["z_std"], g["z_std"], 2e-5 * far, "z_std")
+    target, prior = T(g["target"], dev), T(g["prior"], dev)
+    loss = V.img2mse(ret["rgb_map"], target) + V.img2mse(ret["depth_map"] / far, prior / far)
+    if Nf > 0:
+        loss = loss + V.img2mse(ret["rgb0"], target) + V.img2mse(ret["depth0"] / far, prior / far)
+    check(loss, g["loss"], 1e-5, "loss")
+    loss.backward()
+    check_param_grads(coarse, g, "gc.", "gc.")
+    if fine is not None:
+        check_param_grads(fine, g, "gf.", "gf.")
+
+
+def test_render_full_image_and_rays(dev):
+    """a1: render(c2w=...) incl. get_rays, viewdirs-before-NDC, ndc_rays; R and V surfaces."""
+    from consistentnerf_amd import run_nerf as R, run_nerf_view as V
+    from consistentnerf_amd.run_nerf_helpers import get_rays, ndc_rays
+    g = golden("render_full_tiny")
+    K, c2w = g["K"], g["c2w"]
+    ro, rd = get_rays(16, 16, K, T(c2w, dev))
+    check(ro, g["rays_o"], 0.0, "rays_o"); check(rd, g["rays_d"], 1e-6, "rays_d")
+    no, nd = ndc_rays(16, 16, float(K[0][0]), 1.0, T(g["rays_o"], dev), T(g["rays_d"], dev))
+    check(no, g["ndc_o"], 1e-5, "ndc_o"); check(nd, g["ndc_d"], 1e-5, "ndc_d")
+    coarse, _ = make_model(4, 128, True, 5, 31, dev)
+    fine, _ = make_model(4, 128, True, 5, 32, dev)
+    for ndc in (False, True):
+        kw = _kwargs(coarse, fine, 16, 16, 0.0, False, 0.0, False)
+        if ndc:
+            kw.pop("lindisp")
+        near, far = (0.0, 1.0) if ndc else (2.0, 6.0)
+        with torch.no_grad():
+            rgb, disp, acc, depth, extras = V.render(16, 16, K, chunk=100, c2w=T(c2w, dev), ndc=ndc, near=near,
+                                                     far=far, use_viewdirs=True, pytest=True, **kw)
+            rgb_r, disp_r, acc_r, extras_r = R.render(16, 16, K, chunk=100, c2w=T(c2w, dev), ndc=ndc, near=near,
+                                                      far=far, use_viewdirs=True, pytest=True, **kw)
+        sfx = "_ndc" if ndc else ""
+        tol = 1e-4 if ndc else 2e-5   # NDC divides by small z: conditioning, not kernel error
+        check(rgb, g["rgb" + sfx], tol, "rgb" + sfx)
+        check(acc, g["acc" + sfx], tol, "acc" + sfx)
+        check(depth, g["depth" + sfx], tol * far, "depth" + sfx)
+        check(extras["rgb0"], g["rgb0" + sfx], tol, "rgb0" + sfx)
+        assert rgb.shape == (16, 16, 3) and depth.shape == (16, 16)
+        assert torch.equal(rgb, rgb_r) and "depth_map" not in extras_r and "depth0" not in extras_r
+        assert set(extras_r) == {"rgb0", "disp0", "acc0", "z_std"}
+
+
+def test_warp_golden(dev):
+    from consistentnerf_amd import run_nerf_view as V
+    g = golden("warp")
+    K = T(g["K"], dev)[None]
+    P = T(g["P"], dev)[None, :, None, :]
+    w2c = T(g["w2c_ref"], dev)[None]
+    c2w = torch.eye(4, device=dev); c2w[:3, :4] = T(g["poses"][1], dev); c2w = c2w[None]
+    img = T(g["images"][1], dev).permute(2, 0, 1)[None]
+    dep = T(g["depths"][1], dev)[None]
+    for tag in ("V", "VT"):
+        rgb, d, Xc, ro, rd, mask = V.get_ref_rays(w2c, c2w, K, P, img, dep, variant=tag)
+        assert np.array_equal(mask.cpu().numpy(), g[tag + ".mask"]), f"{tag} in-bounds mask"
+        check(Xc, g[tag + ".Xc"], 1e-5, tag + ".Xc")
+        check(rgb, g[tag + ".rgb_ref"], 0.0, tag + ".rgb_ref")
+        check(d, g[tag + ".depth_ref"], 0.0, tag + ".depth_ref")
+        check(ro, g[tag + ".rays_o"], 1e-6, tag + ".rays_o")
+        check(rd, g[tag + ".rays_d"], 1e-5, tag + ".rays_d")
+    y, x, m, z = V.get_test_label(w2c, c2w, K, P, img)
+    check(y, g["label.y"], 0.0, "label.y"); check(x, g["label.x"], 0.0, "label.x")
+    assert np.array_equal(m.cpu().numpy(), g["label.mask"])
+    check(z, g["label.z"], 1e-5, "label.z")
+
+
+def test_hard_masks_golden(dev):
+    from consistentnerf_amd import run_nerf_view as V
+    g = golden("hardmask_tiny")
+    masks, thr = V.compute_hard_masks(96, 128, g["K"], g["poses"], g["depths"], list(g["i_train"]), 0.1, 5120,
+                                      device=dev, return_thresholds=True)
+    diff = (masks != g["masks"])
+    print(f"  mask pixels differing: {diff.sum()} of {diff.size}")
+    assert diff.sum() == 0, "hard masks must match the reference capture"
+    for (t, r, c, th) in g["thr"]:
+        got = thr[(int(t), int(r))][int(c)]
+        assert (np.isnan(th) and np.isnan(got)) or np.float32(th) == got, (t, r, c, th, got)
+    assert not masks[3].any()
+
+
+def test_masked_losses_golden(dev):
+    from consistentnerf_amd import run_nerf_view as V
+    g = golden("losses_mask")
+    far, c = float(g["far"]), float(g["coef"])
+    for tag, m in (("mixed", g["mask"]), ("allone", np.ones_like(g["mask"]))):
+        r = T(g["rgb"], dev).requires_grad_(True)
+        d = T(g["depth"], dev).requires_grad_(True)
+        lr, ld = V.hardmask_losses(r, T(g["target"], dev), T(m, dev), c, d, T(g["prior"], dev), far)
+        check(lr, g[tag + ".l_rgb"], 2e-7, tag + ".l_rgb"); check(ld, g[tag + ".l_depth"], 2e-7, tag + ".l_depth")
+        (lr + ld).backward()
+        check(r.grad, g[tag + ".d_rgb"], 1e-9, tag + ".d_rgb"); check(d.grad, g[tag + ".d_depth"], 1e-9, tag + ".d_depth")
+    lr, _ = V.hardmask_losses(T(g["rgb"], dev), T(g["target"], dev), None)
+    check(V.mse2psnr(lr), g["psnr"], 1e-5, "psnr (unmasked)")
+
+
+def test_train_10_steps_golden(dev):
+    """create_nerf -> render -> loss -> backward -> FusedAdam + lr decay, 10 steps at C1 shapes."""
+    import argparse
+    import tempfile
+    from consistentnerf_amd import run_nerf as R
+    g = golden("train_10steps_C1")
+    with tempfile.TemporaryDirectory() as tmp:
+        args = argparse.Namespace(
+            multires=10, i_embed=0, use_viewdirs=True, multires_views=4, N_importance=0, netdepth=4, netwidth=128,
+            netdepth_fine=4, netwidth_fine=128, netchunk=1024 * 64, lrate=5e-4, basedir=tmp, expname="exp",
+            ft_path=None, no_reload=True, perturb=1.0, N_samples=64, white_bkgd=True, raw_noise_std=0.0,
+            dataset_type="blender", no_ndc=False, lindisp=False)
+        kw_train, kw_test, start, grad_vars, optimizer = R.create_nerf(args)
+    sd = I.nerf_state_dict(4, 128, 10, 4, 4, True, seed=41)
+    kw_train["network_fn"].load_state_dict({k: T(v) for k, v in sd.items()})
+    kw_train.update(near=2.0, far=6.0)
+    K = I.intrinsics(100, 100, 138.0)
+    global_step = start
+    for i in range(10):
+        rays = T(I.ray_batch(256, seed=100 + i), dev)
+        target = T(np.random.RandomState(200 + i).uniform(size=(256, 3)).astype(np.float32), dev)
+        batch_rays = torch.stack([rays[:, 0:3], rays[:, 3:6]], 0)
+        rgb, disp, acc, extras = R.render(100, 100, K, chunk=32768, rays=batch_rays, retraw=True, pytest=True,
+                                          **kw_train)
+        optimizer.zero_grad()
+        loss = R.img2mse(rgb, target)
+        rel = abs(loss.item() - g["losses"][i]) / g["losses"][i]
+        print(f"  step {i}: loss {loss.item():.6f} ref {g['losses'][i]:.6f} rel {rel:.2e}")
+        assert rel < 2e-4, (i, loss.item(), g["losses"][i])
+        loss.backward()
+        optimizer.step()
+        new_lrate = args.lrate * (0.1 ** (global_step / (250 * 1000)))
+        for pg in optimizer.param_groups:
+            pg["lr"] = new_lrate
+        global_step += 1
+    worst = 0.0
+    for k, v in kw_train["network_fn"].state_dict().items():
+        worst = max(worst, float(np.abs(v.cpu().numpy() - g["final." + k]).max()))
+    print(f"  final weights: max|d| = {worst:.3e}")
+    assert worst < 2e-4   # 10 Adam steps of lr 5e-4: a sign flip of a ~0 gradient moves a weight by 1e-3 at most
+    assert kw_test["perturb"] is False and kw_test["raw_noise_std"] == 0.
+
+
+# ------------------------------------------------------------------------------------------------
+# full-size (BASELINE config C2: 4096 rays, 64+128 samples, D=8/W=256) property tests
+def _c2(dev, B=4096):
+    coarse, _ = make_model(8, 256, True, 5, 21, dev)
+    fine, _ = make_model(8, 256, True, 5, 22, dev)
+    rays = T(I.ray_batch(B, seed=5, near=2.125, far=4.67), dev)
+    return coarse, fine, rays
+
+
+def test_c2_properties(dev):
+    from consistentnerf_amd import run_nerf_view as V
+    coarse, fine, rays = _c2(dev)
+    kw = _kwargs(coarse, fine, 64, 128, 1.0, False, 0.0, False)
+    torch.manual_seed(0)
+    with torch.no_grad():
+        full = V.render_rays(rays, retraw=True, pytest=True, **kw)
+        # chunk invariance (R:79-80): 4096 rays at once == 4 chunks of 1024 (pytest RNG is per-call, so compare
+        # on the deterministic test-time path)
+        kwt = dict(kw, perturb=0.0)
+        a = V.render_rays(rays, **kwt)
+        parts = [V.render_rays(rays[i:i + 1024], **kwt) for i in range(0, 4096, 1024)]
+    for k in ("rgb_map", "depth_map", "acc_map", "rgb0"):
+        assert torch.equal(a[k], torch.cat([p[k] for p in parts])), f"chunk invariance {k}"
+    for k, v in full.items():
+        assert torch.isfinite(v).all(), k
+    assert (full["acc_map"] <= 1 + 1e-5).all() and (full["acc_map"] >= 0).all()
+    assert (full["rgb_map"] >= -1e-6).all() and (full["rgb_map"] <= 1 + 1e-5).all()
+    assert (full["depth_map"] <= 4.67 * 1.0001).all()
+    # oracle on a 128-ray slice of the same batch (CPU finishes in seconds)
+    sl = slice(1000, 1128)
+    sdc = O.as_tensors(I.nerf_state_dict(8, 256, 10, 4, 5, True, seed=21))
+    sdf = O.as_tensors(I.nerf_state_dict(8, 256, 10, 4, 5, True, seed=22))
+    with torch.no_grad():
+        got = V.render_rays(rays[sl], pytest=True, **kw)
+        ref = O.render_rays_pytest(rays[sl].cpu(), sdc, sdf, O.NetCfg(8, 256, output_ch=5), O.RenderCfg(64, 128, 1.0))
+    check(got["rgb_map"], ref["rgb_map"], 2e-5, "C2 rgb_map vs oracle")
+    check(got["depth_map"], ref["depth_map"], 2e-5 * 4.67, "C2 depth_map vs oracle")
+    check(got["rgb0"], ref["rgb0"], 2e-5, "C2 rgb0 vs oracle")
+
+
+def test_c2_gradient_linearity(dev):
+    """Backward is linear in the upstream gradient: grad(2L) == 2 grad(L), and two half-batches accumulate to
+    the full batch (size-independent checks of dgrad + wgrad + split reduction at full size)."""
+    from consistentnerf_amd import run_nerf_view as V
+    coarse, fine, rays = _c2(dev, 2048)
+    kw = _kwargs(coarse, fine, 64, 128, 0.0, False, 0.0, False)
+    tgt = torch.rand(2048, 3, device=dev)
+
+    def grads(scale, sl):
+        for m in (coarse, fine):
+            m.zero_grad(set_to_none=True)
+        out = V.render_rays(rays[sl], **kw)
+        loss = scale * (((out["rgb_map"] - tgt[sl]) ** 2).sum() + ((out["rgb0"] - tgt[sl]) ** 2).sum())
+        loss.backward()
+        return torch.cat([p.grad.reshape(-1) for m in (coarse, fine) for p in m.kernel_tensors()
+                          if p.grad is not None])
+    g1 = grads(1.0, slice(0, 2048))
+    g2 = grads(2.0, slice(0, 2048))
+    ga = grads(1.0, slice(0, 1024)) + grads(1.0, slice(1024, 2048))
+    s = g1.abs().max().item()
+    assert (g2 - 2 * g1).abs().max().item() <= 1e-5 * s
+    assert (ga - g1).abs().max().item() <= 2e-4 * s
+    assert torch.isfinite(g1).all() and s > 0

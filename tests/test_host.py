@@ -1,0 +1,136 @@
+"""CPU-side tests (no GPU): the C-ABI library loads and exports every symbol include/cnerf.h declares, the
+host logic (tensor bookkeeping, sharding) is right, and the product path REFUSES to run without a GPU
+(no CPU fallback).  No compute calls are made here."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from consistentnerf_amd import _lib, build
+    if not os.path.exists(_lib.LIB_PATH):
+        build.build(verbose=False)
+    return _lib.load()
+
+
+def test_header_symbols_all_exported(lib):
+    from consistentnerf_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "cnerf.h")).read()
+    declared = set(re.findall(r"\b(cnerf_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (cnerf_[a-z0-9_]+)", out))
+    assert declared <= exported, declared - exported
+    assert lib.cnerf_abi_version() == 1
+    assert lib.cnerf_strerror(-2).decode().startswith("configuration")
+
+
+def test_tensor_bookkeeping_matches_reference_state_dict(lib):
+    """cnerf_tensor_shape order/shapes == reference state_dict (minus the 3 scalars) for the BASELINE nets."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import _inputs as I
+    from consistentnerf_amd.ops import NetSpec
+    from consistentnerf_amd.run_nerf_helpers import NeRF
+    for D, W, vd, och in ((8, 256, True, 5), (4, 128, True, 4), (4, 128, False, 5), (8, 128, True, 5)):
+        spec = NetSpec(D=D, W=W, use_viewdirs=vd, output_ch=och)
+        shapes = spec.tensor_shapes()
+        ref = [s for n, s in I.nerf_param_shapes(D, W, 63, 27 if vd else 0, och, vd) if n not in
+               ("temp_rgb", "temp_depth", "depth_scale")]
+        assert shapes == [tuple(s) for s in ref]
+        m = NeRF(D=D, W=W, input_ch=63, output_ch=och, skips=[4], input_ch_views=27 if vd else 0, use_viewdirs=vd)
+        assert [tuple(t.shape) for t in m.kernel_tensors()] == shapes
+        assert m.spec() == spec if vd else m.spec().D == D
+        assert list(m.state_dict().keys()) == [n for n, _ in I.nerf_param_shapes(D, W, 63, 27 if vd else 0, och, vd)]
+    import ctypes as C
+    assert lib.cnerf_packed_floats(C.byref(NetSpec(D=5).c())) == -1          # D == skip+1: reference mis-shapes
+    assert lib.cnerf_packed_floats(C.byref(NetSpec(W=192).c())) == -1        # outside the compiled envelope
+
+
+def test_no_cpu_fallback():
+    from consistentnerf_amd import ops, CnerfError
+    from consistentnerf_amd.run_nerf_helpers import sample_pdf
+    with pytest.raises(CnerfError):
+        ops.embed(torch.zeros(4, 3), 10)
+    with pytest.raises(CnerfError):
+        sample_pdf(torch.zeros(2, 63), torch.zeros(2, 62), 8, det=True)
+    if not torch.cuda.is_available():
+        from consistentnerf_amd import run_nerf
+        with pytest.raises(CnerfError):
+            run_nerf._default_device()
+    src = "".join(open(os.path.join(ROOT, "consistentnerf_amd", f)).read()
+                  for f in os.listdir(os.path.join(ROOT, "consistentnerf_amd")) if f.endswith(".py"))
+    assert "oracle" not in src.replace("no CPU oracle", ""), "product code must never import the oracle"
+
+
+def test_shard_bounds():
+    from consistentnerf_amd.distributed import shard_bounds
+    for n in (4096, 4097, 7, 8):
+        for w in (1, 2, 3, 8):
+            b = [shard_bounds(n, r, w) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1
+
+
+WORKER = r'''
+import os, sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests", "golden"))
+import torch.distributed as dist
+import _inputs as I
+from consistentnerf_amd import distributed as D
+from oracle import nerf_oracle as O
+rank, world, _ = D.init_from_env("gloo")
+torch.manual_seed(0)
+# global batch (identical on every rank), masked depth/rgb losses with GLOBAL counts, flat-grad all-reduce
+B = 64
+sd = O.as_tensors(I.nerf_state_dict(4, 128, 10, 4, 4, True, seed=41), True)
+net, cfg = O.NetCfg(4, 128, output_ch=4), O.RenderCfg(16, 0, 0.0)
+rays = torch.from_numpy(I.ray_batch(B, seed=3)); rs = np.random.RandomState(1)
+target = torch.from_numpy(rs.uniform(size=(B, 3)).astype(np.float32))
+prior = torch.from_numpy(rs.uniform(2, 6, size=(B,)).astype(np.float32))
+mask = torch.from_numpy((rs.uniform(size=(B,)) < 0.6).astype(np.float32))
+def loss_on(sl, counts):
+    out = O.render_rays(rays[sl], sd, None, net, cfg)
+    m = mask[sl]
+    # per-ray weights normalised by GLOBAL counts (what hardmask_losses does with counts=...)
+    w = torch.where(m == 1, 1.0 / counts[0], 0.2 / counts[1])
+    l = (w[:, None] * (out["rgb_map"] - target[sl]) ** 2).sum() / 3
+    l = l + (((out["depth_map"] - prior[sl]) / 6.0) ** 2 * (m == 1)).sum() / counts[0]
+    return l
+params = [p for k, p in sd.items() if k not in ("temp_rgb", "temp_depth", "depth_scale")]
+counts = D.global_mask_counts(D.shard_batch(mask))
+assert counts.tolist() == [float((mask == 1).sum()), float((mask == 0).sum())]
+lo, hi = D.shard_bounds(B)
+g = torch.autograd.grad(loss_on(slice(lo, hi), counts), params, allow_unused=True)
+flat = torch.cat([(x if x is not None else torch.zeros_like(p)).reshape(-1) for x, p in zip(g, params)])
+D.allreduce_sum_(flat)
+gref = torch.autograd.grad(loss_on(slice(0, B), counts), params, allow_unused=True)
+fref = torch.cat([(x if x is not None else torch.zeros_like(p)).reshape(-1) for x, p in zip(gref, params)])
+err = (flat - fref).abs().max().item() / fref.abs().max().item()
+assert err < 1e-5, err
+t = torch.ones(3); D.allreduce_mean_(t); assert torch.allclose(t, torch.ones(3))
+D.barrier()
+if rank == 0: print("DIST_OK", world, err)
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_gloo_sharded_step_equals_single(tmp_path):
+    """N>1 path on CPU (gloo, world_size 2): sharded masked-loss gradients + one flat all-reduce == 1-rank."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", str(script), ROOT],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "DIST_OK 2" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
