@@ -306,8 +306,8 @@ def _create_nerf(args, model_cls, view_variant):
 
 def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False, lindisp=False, perturb=0.,
                 N_importance=0, network_fine=None, white_bkgd=False, raw_noise_std=0., verbose=False, pytest=False,
-                _with_depth=False):
-    """R:311-421 (V:441-551 when _with_depth).  Returns the same dict."""
+                _with_depth=False, _debug=False):
+    """R:311-421 (V:441-551 when _with_depth).  Returns the same dict (+ the sample depths when _debug)."""
     rays = ray_batch if ray_batch.is_contiguous() else ray_batch.contiguous()
     N_rays, dev = rays.shape[0], rays.device
     viewdirs = rays[:, -3:] if rays.shape[-1] > 8 else None
@@ -318,6 +318,7 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
     raw = network_query_fn(RayPoints(rays, z_vals), viewdirs, network_fn)
     noise = _density_noise((N_rays, N_samples), raw_noise_std, pytest, dev)
     rgb_map, disp_map, acc_map, weights, depth_map = _CompositeFn.apply(raw, z_vals, rays, noise, bool(white_bkgd))
+    z_coarse = z_vals
     if N_importance > 0:
         rgb_map_0, disp_map_0, acc_map_0, depth_map_0 = rgb_map, disp_map, acc_map, depth_map
         u = sample_u(N_rays, N_importance, perturb == 0., pytest, dev)
@@ -337,6 +338,8 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
         if _with_depth:
             ret['depth0'] = depth_map_0
         ret['z_std'] = z_std
+    if _debug:
+        ret['_z_coarse'], ret['_z_vals'], ret['_weights'] = z_coarse, z_vals, weights
     if DEBUG:
         for k in ret:
             if torch.isnan(ret[k]).any() or torch.isinf(ret[k]).any():

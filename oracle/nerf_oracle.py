@@ -194,7 +194,7 @@ def coarse_z(near: Tensor, far: Tensor, Nc: int, lindisp: bool, t_rand: Optional
 def render_rays(ray_batch: Tensor, sd_coarse, sd_fine, net: NetCfg, cfg: RenderCfg,
                 t_rand: Optional[Tensor] = None, u: Optional[Tensor] = None,
                 noise0: Optional[Tensor] = None, noise1: Optional[Tensor] = None,
-                retraw: bool = True, net_fine: Optional[NetCfg] = None):
+                retraw: bool = True, net_fine: Optional[NetCfg] = None, z_fine: Optional[Tensor] = None):
     """ray_batch [B, 8|11] = o, d, near, far, (viewdirs).  Randoms are passed IN (t_rand [B,Nc] for
     the stratified jitter when perturb>0; u [B,Nf] for sample_pdf; noise0/noise1 already scaled by
     raw_noise_std) so oracle and kernels consume identical streams.  If perturb==0, u defaults to
@@ -218,6 +218,8 @@ def render_rays(ray_batch: Tensor, sd_coarse, sd_fine, net: NetCfg, cfg: RenderC
         z_new, _ = sample_pdf(z_mid, w[:, 1:-1], u)
         z_new = z_new.detach()
         z, _ = torch.sort(torch.cat([z, z_new], dim=-1), dim=-1)
+        if z_fine is not None:   # "teacher forcing" for kernel tests: evaluate the fine level at given depths
+            z = z_fine
         pts = o[:, None, :] + d[:, None, :] * z[:, :, None]
         sd2, net2 = (sd_coarse, net) if sd_fine is None else (sd_fine, net_fine or net)
         raw = query(sd2, pts, vd, net2)
