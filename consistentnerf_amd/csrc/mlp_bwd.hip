@@ -24,11 +24,25 @@ struct BwdArgs {
   int64_t M, Mp;
 };
 
-// mask (H>0) and park: acc <- acc * [stash row > 0]; write to the G block `grow` and to the LDS tile.
+// Prefetch the stash block whose ReLU decides the mask (C-layout rows of this lane); issued BEFORE the GEMM that
+// produces the gradient so the ~2 us HBM latency of 16*NTO scattered dword loads hides under its MFMAs.
+template <int NTO>
+__device__ __forceinline__ void load_rows(f32x16 (&h)[NTO], const float* __restrict__ stash, int srow, int64_t Mp,
+                                          int64_t pc, int hh) {
+#pragma unroll
+  for (int t = 0; t < NTO; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        h[t][4 * q + j] = stash[(int64_t)(srow + 32 * t + 8 * q + 4 * hh + j) * Mp + pc];
+}
+
+// mask (H>0) and park: acc <- acc * [h > 0]; write to the G block `grow` and to the LDS tile.
 template <int W, int NTO, bool MASK>
-__device__ __forceinline__ void mask_park(f32x16 (&acc)[NTO], float* Hs, const float* __restrict__ stash, int srow,
-                                          float* __restrict__ G, int grow, int64_t Mp, int64_t p, int64_t pc,
-                                          bool valid, int m, int hh) {
+__device__ __forceinline__ void mask_park(f32x16 (&acc)[NTO], const f32x16 (&h)[NTO], float* Hs,
+                                          float* __restrict__ G, int grow, int64_t Mp, int64_t p, bool valid, int m,
+                                          int hh) {
 #pragma unroll
   for (int t = 0; t < NTO; ++t)
 #pragma unroll
@@ -38,10 +52,7 @@ __device__ __forceinline__ void mask_park(f32x16 (&acc)[NTO], float* Hs, const f
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float x = acc[t][4 * q + j];
-        if (MASK) {
-          const float h = stash[(int64_t)(srow + n0 + j) * Mp + pc];
-          x = h > 0.f ? x : 0.f;
-        }
+        if (MASK) x = h[t][4 * q + j] > 0.f ? x : 0.f;
         v[j] = x;
       }
       *reinterpret_cast<f32x4*>(Hs + hs_off<W>(m, 8 * t + 2 * q + hh)) = v;
@@ -74,6 +85,7 @@ __global__ __launch_bounds__(64) void mlp_dgrad_k(BwdArgs a) {
   const float* pk = a.packed;
   const int64_t Mp = a.Mp;
   f32x16 acc[NT];
+  f32x16 hm[NT];     // prefetched stash rows for the next ReLU mask
 
   if (VD) {
     const float4 d = *reinterpret_cast<const float4*>(a.d_raw + pc * 4);
@@ -99,13 +111,18 @@ __global__ __launch_bounds__(64) void mlp_dgrad_k(BwdArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) accv[t][4 * q + j] = s[j];
       }
-    mask_park<W, NTH, true>(accv, Hs, a.stash, g.s_hv, a.G, g.g_hv, Mp, p, pc, valid, m, hh);
+    {
+      f32x16 hv[NTH];
+      load_rows<NTH>(hv, a.stash, g.s_hv, Mp, pc, hh);
+      mask_park<W, NTH, true>(accv, hv, Hs, a.G, g.g_hv, Mp, p, valid, m, hh);
+    }
+    load_rows<NT>(hm, a.stash, g.s_h[g.D - 1], Mp, pc, hh);
     __builtin_amdgcn_wave_barrier();
     // views_linears^T (feature columns only; gamma(d) needs no gradient) -> dF
     zero_acc<NT>(acc);
     gemm_seg<W, NT>(acc, pk + g.t_views, W, g.Wh / 8, Hs, m, hh);
     __builtin_amdgcn_wave_barrier();
-    mask_park<W, NT, false>(acc, Hs, a.stash, 0, a.G, g.g_feat, Mp, p, pc, valid, m, hh);
+    mask_park<W, NT, false>(acc, hm, Hs, a.G, g.g_feat, Mp, p, valid, m, hh);
     __builtin_amdgcn_wave_barrier();
     // feature_linear^T . dF  +  alpha_linear^T . dsigma, masked by the last trunk ReLU -> dZ_{D-1}
 #pragma unroll
@@ -118,6 +135,7 @@ __global__ __launch_bounds__(64) void mlp_dgrad_k(BwdArgs a) {
       }
     gemm_seg<W, NT>(acc, pk + g.t_feat, W, W / 8, Hs, m, hh);
   } else {
+    load_rows<NT>(hm, a.stash, g.s_h[g.D - 1], Mp, pc, hh);
     float dc[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) dc[c] = c < g.out_ch ? a.d_raw[pc * g.out_ch + c] : 0.f;
@@ -142,14 +160,15 @@ __global__ __launch_bounds__(64) void mlp_dgrad_k(BwdArgs a) {
       }
   }
   __builtin_amdgcn_wave_barrier();
-  mask_park<W, NT, true>(acc, Hs, a.stash, g.s_h[g.D - 1], a.G, g.g_z[g.D - 1], Mp, p, pc, valid, m, hh);
+  mask_park<W, NT, true>(acc, hm, Hs, a.G, g.g_z[g.D - 1], Mp, p, valid, m, hh);
   __builtin_amdgcn_wave_barrier();
   // trunk: dZ_{l-1} = relu'(.) * W_l^T dZ_l   (the gamma(x) columns of the skip layer get no gradient)
   for (int l = g.D - 1; l >= 1; --l) {
+    load_rows<NT>(hm, a.stash, g.s_h[l - 1], Mp, pc, hh);
     zero_acc<NT>(acc);
     gemm_seg<W, NT>(acc, pk + g.t_trunk[l], W, W / 8, Hs, m, hh);
     __builtin_amdgcn_wave_barrier();
-    mask_park<W, NT, true>(acc, Hs, a.stash, g.s_h[l - 1], a.G, g.g_z[l - 1], Mp, p, pc, valid, m, hh);
+    mask_park<W, NT, true>(acc, hm, Hs, a.G, g.g_z[l - 1], Mp, p, valid, m, hh);
     __builtin_amdgcn_wave_barrier();
   }
 }

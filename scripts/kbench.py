@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Kernel micro-bench (GPU box): times cnerf_mlp_fwd (inference / training), dgrad, wgrad, composite, resample at
+C2 sizes with HIP events on the launch stream.  usage: python scripts/kbench.py [B] [reps]"""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import _inputs as I  # noqa: E402
+from consistentnerf_amd import ops  # noqa: E402
+from consistentnerf_amd.run_nerf_helpers import NeRF  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+REPS = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+dev = torch.device("cuda:0")
+MAC = {"fwd": 593408, "dgrad": 557696, "wgrad": 593408}
+
+
+def timeit(fn, reps=REPS):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def main():
+    from consistentnerf_amd.run_nerf import _packed
+    sd = I.nerf_state_dict(8, 256, 10, 4, 5, True, seed=21)
+    m = NeRF(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m = m.to(dev)
+    spec, packed = m.spec(), _packed(m)
+    rays = torch.from_numpy(I.ray_batch(B, seed=5, near=2.125, far=4.67)).to(dev)
+    for S in (192, 64):
+        M = B * S
+        z = ops.coarse_z(rays, S, torch.rand(B, S, device=dev), False)
+        t_inf = timeit(lambda: ops.mlp_forward(spec, packed, B, S, rays=rays, z=z))
+        raw, stash = ops.mlp_forward(spec, packed, B, S, rays=rays, z=z, want_stash=True)
+        t_tr = timeit(lambda: ops.mlp_forward(spec, packed, B, S, rays=rays, z=z, want_stash=True))
+        d_raw = torch.randn_like(raw)
+        import ctypes as C
+        from consistentnerf_amd import _lib
+        lib, net = _lib.load(), spec.c()
+        ws = torch.empty(lib.cnerf_mlp_bwd_ws_floats(C.byref(net), M), device=dev)
+        grads = [torch.empty(s, device=dev) for s in spec.tensor_shapes()]
+        ptrs = ops._ptrs(grads)
+        st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)  # noqa: E731
+        t_dg = timeit(lambda: lib.cnerf_mlp_dgrad(C.byref(net), ops._p(packed), ops._p(d_raw), B, S, ops._p(stash),
+                                                  ops._p(ws), st()))
+        t_wg = timeit(lambda: lib.cnerf_mlp_wgrad(C.byref(net), B, S, ops._p(stash), ops._p(ws), C.byref(ptrs), 0, st()))
+        tf = lambda k, ms: 2 * MAC[k] * M / (ms * 1e-3) / 1e12  # noqa: E731
+        print(f"S={S:4d} M={M:8d}  fwd(inf) {t_inf:7.3f} ms {tf('fwd', t_inf):6.1f} TF | fwd(train) {t_tr:7.3f} ms "
+              f"{tf('fwd', t_tr):6.1f} TF | dgrad {t_dg:7.3f} ms {tf('dgrad', t_dg):6.1f} TF | wgrad {t_wg:7.3f} ms "
+              f"{tf('wgrad', t_wg):6.1f} TF", flush=True)
+        if S == 192:
+            w = torch.rand(B, 64, device=dev)
+            zc = ops.coarse_z(rays, 64, None, False)
+            u = torch.rand(B, 128, device=dev)
+            t_rs = timeit(lambda: ops.resample(zc, w, u))
+            t_cf = timeit(lambda: ops.composite_forward(raw, z, rays, None, False))
+            g = torch.randn(B, 3, device=dev)
+            t_cb = timeit(lambda: ops.composite_backward(raw, z, rays, None, False, g, None, None, None))
+            print(f"          resample {t_rs*1e3:7.1f} us | composite fwd {t_cf*1e3:7.1f} us ({24*M/t_cf/1e6:6.1f} GB/s) | "
+                  f"bwd {t_cb*1e3:7.1f} us ({40*M/t_cb/1e6:6.1f} GB/s)", flush=True)
+        del stash, ws
+
+
+if __name__ == "__main__":
+    main()
