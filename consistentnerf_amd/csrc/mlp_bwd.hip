@@ -2,7 +2,7 @@
 // Three launches:
 //   1. dgrad (this file): one wave64 per 32 points walks the network backwards with the TRANSPOSED weight
 //      panels as the MFMA A operand and the gradient tile in LDS as B; it writes the gradient w.r.t. every
-//      layer's pre-activation, dZ_l^T, as [rows][Mp] blocks (point-contiguous) into the workspace.
+//      layer's pre-activation, dZ_l, into the point-major gradient workspace G[Mp][g_rows].
 //   2. wgrad (wgrad.hip): NT GEMMs contracted over points, dW_l = dZ_l^T . H_{l-1}, split over point ranges.
 //   3. a fixed-order reduction of the split partials into the parameter gradients (deterministic).
 // ReLU masks are re-derived from the forward stash (H > 0  <=>  pre-activation > 0).
@@ -24,31 +24,34 @@ struct BwdArgs {
   int64_t M, Mp;
 };
 
-// Prefetch the stash block whose ReLU decides the mask (C-layout rows of this lane); issued BEFORE the GEMM that
-// produces the gradient so the ~2 us HBM latency of 16*NTO scattered dword loads hides under its MFMAs.
+// Prefetch the stash block whose ReLU decides the mask (C-layout features of this lane = 4*NTO dwordx4 loads off
+// the point's stash row); issued BEFORE the GEMM that produces the gradient so the HBM latency hides under it.
 template <int NTO>
-__device__ __forceinline__ void load_rows(f32x16 (&h)[NTO], const float* __restrict__ stash, int srow, int64_t Mp,
-                                          int64_t pc, int hh) {
+__device__ __forceinline__ void load_rows(f32x16 (&h)[NTO], const float* __restrict__ sp, int col) {
 #pragma unroll
   for (int t = 0; t < NTO; ++t)
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(sp + col + 32 * t + 8 * q);
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        h[t][4 * q + j] = stash[(int64_t)(srow + 32 * t + 8 * q + 4 * hh + j) * Mp + pc];
+      for (int j = 0; j < 4; ++j) h[t][4 * q + j] = v[j];
+    }
 }
 
-// mask (H>0) and park: acc <- acc * [h > 0]; write to the G block `grow` and to the LDS tile.
+// mask (H>0) and park: acc <- acc * [h > 0]; the masked gradient goes to the LDS tile (B operand of the next
+// transposed GEMM) and, straight from the registers, to this point's row of the point-major gradient workspace
+// (`gp` = row + 4*hh, block column `col`): one 16-byte store per 4 consecutive features.  (Measured: routing the
+// stores through the LDS tile for 1 KiB-coalesced writes is SLOWER here — the ds_read -> store chain is exposed
+// latency on a one-wave-per-SIMD kernel, while L2 write-combines the 32-byte lane-pair pieces anyway.)
+// Padding points store zeros.
 template <int W, int NTO, bool MASK>
 __device__ __forceinline__ void mask_park(f32x16 (&acc)[NTO], const f32x16 (&h)[NTO], float* Hs,
-                                          float* __restrict__ G, int grow, int64_t Mp, int64_t p, bool valid, int m,
-                                          int hh) {
+                                          float* __restrict__ gp, int col, bool valid, int m, int hh) {
 #pragma unroll
   for (int t = 0; t < NTO; ++t)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       f32x4 v;
-      const int n0 = 32 * t + 8 * q + 4 * hh;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float x = acc[t][4 * q + j];
@@ -56,11 +59,8 @@ __device__ __forceinline__ void mask_park(f32x16 (&acc)[NTO], const f32x16 (&h)[
         v[j] = x;
       }
       *reinterpret_cast<f32x4*>(Hs + hs_off<W>(m, 8 * t + 2 * q + hh)) = v;
-      if (valid) {
-        float* s = G + (int64_t)(grow + n0) * Mp + p;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) s[(int64_t)j * Mp] = v[j];
-      }
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(gp + col + 32 * t + 8 * q) = valid ? v : z;
     }
 }
 
@@ -83,19 +83,19 @@ __global__ __launch_bounds__(64) void mlp_dgrad_k(BwdArgs a) {
   const bool valid = p < a.M;
   const int64_t pc = valid ? p : a.M - 1;
   const float* pk = a.packed;
-  const int64_t Mp = a.Mp;
+  const float* const sp = a.stash + p * g.s_rows + 4 * hh;   // this point's stash row (+ this half's features)
+  float* const gp = a.G + p * g.g_rows + 4 * hh;             // this point's gradient row (+ this half's features)
   f32x16 acc[NT];
-  f32x16 hm[NT];     // prefetched stash rows for the next ReLU mask
+  f32x16 hm[NT];     // prefetched stash features for the next ReLU mask
+  f32x4 a0[NT];      // prefetched first A group of the next transposed panel
 
   if (VD) {
     const float4 d = *reinterpret_cast<const float4*>(a.d_raw + pc * 4);
     const float dc[4] = {d.x, d.y, d.z, d.w};
-    if (valid && hh == 0) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) a.G[(int64_t)(g.g_out + c) * Mp + p] = dc[c];
-    }
     // rgb_linear^T on the VALU, masked by the view-branch ReLU -> dZv (C-layout registers)
     f32x16 accv[NTH];
+    f32x16 hv[NTH];
+    load_rows<NTH>(hv, sp, g.s_hv);
 #pragma unroll
     for (int t = 0; t < NTH; ++t)
 #pragma unroll
@@ -111,20 +111,22 @@ __global__ __launch_bounds__(64) void mlp_dgrad_k(BwdArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) accv[t][4 * q + j] = s[j];
       }
-    {
-      f32x16 hv[NTH];
-      load_rows<NTH>(hv, a.stash, g.s_hv, Mp, pc, hh);
-      mask_park<W, NTH, true>(accv, hv, Hs, a.G, g.g_hv, Mp, p, valid, m, hh);
-    }
-    load_rows<NT>(hm, a.stash, g.s_h[g.D - 1], Mp, pc, hh);
+    mask_park<W, NTH, true>(accv, hv, Hs, gp, g.g_hv, valid, m, hh);
     __builtin_amdgcn_wave_barrier();
+    load_a0<NT>(a0, pk + g.t_views, m, hh);
+    load_rows<NT>(hm, sp, g.s_h[g.D - 1]);
+    if (hh == 0) {
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(a.G + p * g.g_rows + g.g_out) = valid ? d : z4;
+    }
     // views_linears^T (feature columns only; gamma(d) needs no gradient) -> dF
     zero_acc<NT>(acc);
-    gemm_seg<W, NT>(acc, pk + g.t_views, W, g.Wh / 8, Hs, m, hh);
+    gemm_seg<W, NT>(acc, pk + g.t_views, W, g.Wh / 8, Hs, m, hh, a0);
     __builtin_amdgcn_wave_barrier();
-    mask_park<W, NT, false>(acc, hm, Hs, a.G, g.g_feat, Mp, p, valid, m, hh);
+    mask_park<W, NT, false>(acc, hm, Hs, gp, g.g_feat, valid, m, hh);
     __builtin_amdgcn_wave_barrier();
     // feature_linear^T . dF  +  alpha_linear^T . dsigma, masked by the last trunk ReLU -> dZ_{D-1}
+    load_a0<NT>(a0, pk + g.t_feat, m, hh);
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -133,14 +135,12 @@ __global__ __launch_bounds__(64) void mlp_dgrad_k(BwdArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[t][4 * q + j] = w[j] * dc[3];
       }
-    gemm_seg<W, NT>(acc, pk + g.t_feat, W, W / 8, Hs, m, hh);
+    gemm_seg<W, NT>(acc, pk + g.t_feat, W, W / 8, Hs, m, hh, a0);
   } else {
-    load_rows<NT>(hm, a.stash, g.s_h[g.D - 1], Mp, pc, hh);
+    load_rows<NT>(hm, sp, g.s_h[g.D - 1]);
     float dc[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) dc[c] = c < g.out_ch ? a.d_raw[pc * g.out_ch + c] : 0.f;
-    if (valid && hh == 0)
-      for (int c = 0; c < g.out_ch; ++c) a.G[(int64_t)(g.g_out + c) * Mp + p] = dc[c];
     // output_linear^T on the VALU
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -158,17 +158,20 @@ __global__ __launch_bounds__(64) void mlp_dgrad_k(BwdArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[t][4 * q + j] = s[j];
       }
+    if (hh == 0)
+      for (int c = 0; c < g.out_ch; ++c) a.G[p * g.g_rows + g.g_out + c] = valid ? dc[c] : 0.f;
   }
   __builtin_amdgcn_wave_barrier();
-  mask_park<W, NT, true>(acc, hm, Hs, a.G, g.g_z[g.D - 1], Mp, p, valid, m, hh);
+  mask_park<W, NT, true>(acc, hm, Hs, gp, g.g_z[g.D - 1], valid, m, hh);
   __builtin_amdgcn_wave_barrier();
   // trunk: dZ_{l-1} = relu'(.) * W_l^T dZ_l   (the gamma(x) columns of the skip layer get no gradient)
   for (int l = g.D - 1; l >= 1; --l) {
-    load_rows<NT>(hm, a.stash, g.s_h[l - 1], Mp, pc, hh);
+    load_a0<NT>(a0, pk + g.t_trunk[l], m, hh);
+    load_rows<NT>(hm, sp, g.s_h[l - 1]);
     zero_acc<NT>(acc);
-    gemm_seg<W, NT>(acc, pk + g.t_trunk[l], W, W / 8, Hs, m, hh);
+    gemm_seg<W, NT>(acc, pk + g.t_trunk[l], W, W / 8, Hs, m, hh, a0);
     __builtin_amdgcn_wave_barrier();
-    mask_park<W, NT, true>(acc, hm, Hs, a.G, g.g_z[l - 1], Mp, p, valid, m, hh);
+    mask_park<W, NT, true>(acc, hm, Hs, gp, g.g_z[l - 1], valid, m, hh);
     __builtin_amdgcn_wave_barrier();
   }
 }

@@ -34,13 +34,8 @@ struct FwdArgs {
 // gamma(x) channels of one point into Hs[m][0..chp): hh=0 lanes write x and the sines, hh=1 the cosines
 // and the zero padding.  Channel order H:24-45: [x, sin(2^0 x), cos(2^0 x), ..., sin(2^(L-1) x), cos(..)].
 template <int W>
-__device__ __forceinline__ void encode(float* Hs, const float (&x)[3], int L, int ch, int chp,
-                                       float* __restrict__ stash, int srow, int64_t Mp, int64_t p, bool valid,
-                                       int m, int hh) {
-  auto put = [&](int k, float v) {
-    Hs[hs_off<W>(m, k >> 2) + (k & 3)] = v;
-    if (stash != nullptr && valid) stash[(int64_t)(srow + k) * Mp + p] = v;
-  };
+__device__ __forceinline__ void encode(float* Hs, const float (&x)[3], int L, int ch, int chp, int m, int hh) {
+  auto put = [&](int k, float v) { Hs[hs_off<W>(m, k >> 2) + (k & 3)] = v; };
   if (hh == 0) {
     put(0, x[0]); put(1, x[1]); put(2, x[2]);
   } else {
@@ -78,31 +73,45 @@ __global__ __launch_bounds__(64) void mlp_fwd_k(FwdArgs a) {
     const float zz = a.z[pc];
     x[0] = r[0] + r[3] * zz; x[1] = r[1] + r[4] * zz; x[2] = r[2] + r[5] * zz;   // R:384 (no FMA contraction)
   }
-  encode<W>(Hs, x, g.L, g.in_ch, g.in_chp, a.stash, g.s_enc, a.Mp, p, valid, m, hh);
+  // training: the stash row of the tile's first point (point-major [Mp][s_rows]); every block of the tile is
+  // copied out of LDS with coalesced 1 KiB stores right after it is parked
+  const int64_t pbase = (int64_t)blockIdx.x * 32;
+  float* const st = a.stash != nullptr ? a.stash + pbase * g.s_rows : nullptr;
+  auto stash_tile = [&](int col, int ncols) {
+    if (st != nullptr) tile_to_global<W>(Hs, st + col, g.s_rows, ncols, pbase, a.M, lane);
+  };
+  // Ordering rule for every layer: [loads the next GEMM needs first: bias, A group 0] are queued BEFORE the
+  // stash stores of the block just parked (see load_a0), the GEMM after them.
+  encode<W>(Hs, x, g.L, g.in_ch, g.in_chp, m, hh);
   __builtin_amdgcn_wave_barrier();
 
   f32x16 acc[NT];
   f32x16 accs[NT];   // gamma(x) part of the skip layer, computed while gamma(x) is still in LDS
+  f32x4 a0[NT];
+  load_a0<NT>(a0, pk + g.f_l0, m, hh);
   init_bias<NT>(acc, pk + g.b_trunk[0], hh);
-  gemm_seg<W, NT>(acc, pk + g.f_l0, W, g.in_chp / 8, Hs, m, hh);
+  stash_tile(g.s_enc, g.in_chp);
+  gemm_seg<W, NT>(acc, pk + g.f_l0, W, g.in_chp / 8, Hs, m, hh, a0);
   if (g.skip >= 0) {
     init_bias<NT>(accs, pk + g.b_trunk[g.skip + 1], hh);
     gemm_seg<W, NT>(accs, pk + g.f_skip, W, g.in_chp / 8, Hs, m, hh);
   }
   __builtin_amdgcn_wave_barrier();
-  park<W, NT, true>(acc, Hs, true, a.stash, g.s_h[0], a.Mp, p, valid, m, hh);
+  park<W, NT, true>(acc, Hs, m, hh);
   __builtin_amdgcn_wave_barrier();
 
   for (int l = 1; l < g.D; ++l) {
+    load_a0<NT>(a0, pk + g.f_trunk[l], m, hh);
     if (l == g.skip + 1) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = accs[t];
     } else {
       init_bias<NT>(acc, pk + g.b_trunk[l], hh);
     }
-    gemm_seg<W, NT>(acc, pk + g.f_trunk[l], W, W / 8, Hs, m, hh);
+    stash_tile(g.s_h[l - 1], W);
+    gemm_seg<W, NT>(acc, pk + g.f_trunk[l], W, W / 8, Hs, m, hh, a0);
     __builtin_amdgcn_wave_barrier();
-    park<W, NT, true>(acc, Hs, true, a.stash, g.s_h[l], a.Mp, p, valid, m, hh);
+    park<W, NT, true>(acc, Hs, m, hh);
     __builtin_amdgcn_wave_barrier();
   }
 
@@ -125,9 +134,12 @@ __global__ __launch_bounds__(64) void mlp_fwd_k(FwdArgs a) {
     for (int c = 0; c < 8; ++c) o[c] += __shfl_xor(o[c], 32, 64);
     if (valid && hh == 0)
       for (int c = 0; c < g.out_ch; ++c) a.raw[p * g.out_ch + c] = o[c] + pk[g.b_out + c];
+    stash_tile(g.s_h[g.D - 1], W);
     return;
   } else {
     // sigma head (alpha_linear, H:117) on the VALU while the trunk output is in LDS
+    load_a0<NT>(a0, pk + g.f_feat, m, hh);
+    init_bias<NT>(acc, pk + g.b_feat, hh);
     float sig = 0.f;
     for (int i = 0; i < W / 8; ++i) {
       const int ck = 2 * i + hh;
@@ -137,26 +149,33 @@ __global__ __launch_bounds__(64) void mlp_fwd_k(FwdArgs a) {
     }
     sig += __shfl_xor(sig, 32, 64);
     sig += pk[g.b_alpha];
-    // feature_linear (H:118), no activation
-    init_bias<NT>(acc, pk + g.b_feat, hh);
-    gemm_seg<W, NT>(acc, pk + g.f_feat, W, W / 8, Hs, m, hh);
-    __builtin_amdgcn_wave_barrier();
-    // gamma(viewdir) overwrites the (now dead) trunk tile; its share of views_linears first
     float v[3];
     {
       const float* dsrc = a.dirs != nullptr ? a.dirs + ray * 3 : a.rays + ray * a.rs + (a.rs - 3);
       v[0] = dsrc[0]; v[1] = dsrc[1]; v[2] = dsrc[2];
     }
-    encode<W>(Hs, v, g.Ld, g.dir_ch, g.dir_chp, a.stash, g.s_denc, a.Mp, p, valid, m, hh);
+    stash_tile(g.s_h[g.D - 1], W);
+    // feature_linear (H:118), no activation
+    gemm_seg<W, NT>(acc, pk + g.f_feat, W, W / 8, Hs, m, hh, a0);
+    __builtin_amdgcn_wave_barrier();
+    // gamma(viewdir) overwrites the (now dead) trunk tile; its share of views_linears first
+    encode<W>(Hs, v, g.Ld, g.dir_ch, g.dir_chp, m, hh);
     __builtin_amdgcn_wave_barrier();
     f32x16 accv[NTH];
+    f32x4 av0[NTH];
+    load_a0<NTH>(av0, pk + g.f_viewsd, m, hh);
     init_bias<NTH>(accv, pk + g.b_views, hh);
-    gemm_seg<W, NTH>(accv, pk + g.f_viewsd, g.Wh, g.dir_chp / 8, Hs, m, hh);
+    stash_tile(g.s_denc, g.dir_chp);
+    gemm_seg<W, NTH>(accv, pk + g.f_viewsd, g.Wh, g.dir_chp / 8, Hs, m, hh, av0);
     __builtin_amdgcn_wave_barrier();
-    park<W, NT, false>(acc, Hs, true, a.stash, g.s_feat, a.Mp, p, valid, m, hh);
+    park<W, NT, false>(acc, Hs, m, hh);
     __builtin_amdgcn_wave_barrier();
-    gemm_seg<W, NTH>(accv, pk + g.f_views, g.Wh, W / 8, Hs, m, hh);
-    park<W, NTH, true>(accv, Hs, false, a.stash, g.s_hv, a.Mp, p, valid, m, hh);
+    load_a0<NTH>(av0, pk + g.f_views, m, hh);
+    stash_tile(g.s_feat, W);
+    gemm_seg<W, NTH>(accv, pk + g.f_views, g.Wh, W / 8, Hs, m, hh, av0);
+    __builtin_amdgcn_wave_barrier();
+    park<W, NTH, true>(accv, Hs, m, hh);      // ReLU in registers (rgb head below); LDS copy only feeds the stash
+    __builtin_amdgcn_wave_barrier();
     // rgb_linear (H:125) straight from the accumulators: lane holds n = 32t + 8q + 4hh + j
     float o[3] = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -175,6 +194,7 @@ __global__ __launch_bounds__(64) void mlp_fwd_k(FwdArgs a) {
       *reinterpret_cast<float4*>(a.raw + p * 4) =
           make_float4(o[0] + pk[g.b_rgb + 0], o[1] + pk[g.b_rgb + 1], o[2] + pk[g.b_rgb + 2], sig);
     }
+    stash_tile(g.s_hv, g.Wh);
   }
 }
 

@@ -1,14 +1,15 @@
-// Weight gradients of the NeRF MLP: dW[n][k] = sum_m X^T[n][m] * Y^T[k][m]  (m = points)
-// with X^T = gradient w.r.t. a layer's pre-activation and Y^T = that layer's input, both stored
-// feature-major / point-contiguous ([rows][Mp]) by mlp_fwd / mlp_dgrad.  "NT" GEMMs on
-// v_mfma_f32_32x32x2_f32 whose contraction runs over up to ~10^6 points.
+// Weight gradients of the NeRF MLP: dW[n][k] = sum_m X[m][n] * Y[m][k]  (m = points)
+// with X = gradient w.r.t. a layer's pre-activation (columns of the point-major workspace G[Mp][g_rows]) and
+// Y = that layer's input (columns of the point-major stash[Mp][s_rows]).  GEMMs on v_mfma_f32_32x32x2_f32 whose
+// contraction runs over up to ~10^6 points.
 //
 // A workgroup (4 waves, one per SIMD) owns one GEMM's whole (<=256 x <=256) output and one of `nsplit` point
 // ranges.  The 4 waves tile the output as a gn x gk grid chosen per GEMM so that all four have work
-// (256x256 -> 2x2 waves of 4x4 MFMA tiles; 128x256 -> 1x4 of 4x2; 256x64 -> 2x2 of 4x1; 1x256 -> 1x4 ...).
-// 32-point slabs of X^T / Y^T are staged through a DOUBLE-BUFFERED LDS image (row stride 36 floats:
-// conflict-free ds_read_b128): slab s+1 is written to the other buffer after the MFMAs of slab s, one barrier
-// per slab, and the global loads of slab s+2 are in flight under the 256 MFMAs per wave of slab s+1.
+// (256x256 -> 2x2 waves of 4x4 MFMA tiles; 128x256 -> 4x2 tiles each; 256x64 -> 2x2 each; 1x256 -> 1x2 ...).
+// Operands move HBM -> LDS by DMA (`global_load_lds_dwordx4`, no VGPR staging): a 32-point slab of X is
+// 32 x (N*4 B) contiguous pieces that land as the LDS image Xs[m][n]; the MFMA A operand of step s is then the
+// conflict-free `ds_read_b32` Xs[2s+hh][32x + lane&31] (B likewise from Ys).  Two LDS buffers: the DMA of slab
+// s+1 runs under the 16 steps x (an x ak) MFMAs of slab s; one barrier per slab.
 // GEMMs are launched largest-first over many small point ranges so the tail of the grid is short; split
 // partials are reduced in a fixed order by a second kernel (bit-reproducible run to run).
 #include "mlp_common.hpp"
@@ -16,17 +17,18 @@
 namespace {
 
 constexpr int MAX_WG_JOBS = 48;
-constexpr int TM = 32;         // points per LDS slab
-constexpr int LDR = TM + 4;    // padded LDS row (floats)
-constexpr int TILE_FLOATS = 256 * LDR;
+constexpr int TM = 32;                      // points per LDS slab
+constexpr int TILE_FLOATS = TM * 256;       // one operand slab at full width
 
 struct WgJob {
-  int xrow, yrow;     // first row of X^T in G, of Y^T in the stash
-  int N, K;           // valid output rows / cols
+  int xcol, ycol;     // first column of X in G rows, of Y in stash rows
+  int N, K;           // output rows [n_lo, N) x cols [0, K) of the slab product are valid
+  int n_lo;           // (rows below n_lo belong to another GEMM that shares the X columns; keeps DMA 16-B aligned)
   int tensor;         // destination parameter tensor
   int ld, col0;       // its row stride and first column
   int bias_tensor;    // -1: none
   int gk, an, ak;     // wave grid: wave w -> (wn, wk) = (w / gk, w % gk) owns an x ak tiles of 32x32
+  int lgx, lgy;       // log2 of the LDS row length (floats) of the X / Y slab = log2(32 * #tiles)
 };
 
 struct WgArgs {
@@ -35,125 +37,130 @@ struct WgArgs {
   const float* stash;
   const float* G;
   float* partials;
-  int64_t M, Mp, pstride;            // pstride = floats per split slice
+  int64_t Mp, pstride;               // pstride = floats per split slice
   int64_t chunk;                     // points per split (multiple of 32)
+  int s_rows, g_rows;
 };
 
-__global__ __launch_bounds__(256) void wgrad_k(WgArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];   // [2 buffers][X tile | Y tile]
-  const WgJob jb = a.job[blockIdx.y];
+typedef __attribute__((address_space(3))) void* lds_ptr;
+typedef const __attribute__((address_space(1))) void* glb_ptr;
+
+// DMA one operand slab: TM points x RL=2^lg floats, global rows `stride` floats apart, into lds[m][RL].
+// A wave-instruction moves 1 KiB (lane l -> floats 4l..4l+3 of a 256-float chunk); chunks round-robin over waves.
+__device__ __forceinline__ void dma_slab(const float* __restrict__ src, int64_t stride, int lg, float* dst, int wv,
+                                         int lane) {
+  const int nchunk = (TM << lg) >> 8;
+  const int e0 = 4 * lane;
+  for (int c = wv; c < nchunk; c += 4) {
+    const int e = (c << 8) + e0;
+    const int pt = e >> lg, col = e & ((1 << lg) - 1);
+    __builtin_amdgcn_global_load_lds((glb_ptr)(src + (int64_t)pt * stride + col), (lds_ptr)(dst + (c << 8)), 16, 0, 0);
+  }
+}
+
+// Body for a compile-time per-wave tile block AN x AK (<= 4 x 4): straight-line MFMA steps the compiler can
+// software-pipeline (runtime tile-count guards inside the step loop fragment it into one basic block per MFMA).
+template <int AN, int AK>
+__device__ __forceinline__ void wgrad_body(const WgArgs& a, const WgJob& jb, float* lds) {
   const int split = blockIdx.x;
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, i31 = lane & 31, hh = lane >> 5;
   const int wn = wv / jb.gk, wk = wv - wn * jb.gk;
   const int64_t m_begin = (int64_t)split * a.chunk;
   const int64_t m_end = m_begin + a.chunk < a.Mp ? m_begin + a.chunk : a.Mp;
-  const float* X = a.G + (int64_t)jb.xrow * a.Mp;
-  const float* Y = a.stash + (int64_t)jb.yrow * a.Mp;
+  const float* X = a.G + jb.xcol;
+  const float* Y = a.stash + jb.ycol;
   const int ntn = (jb.N + 31) >> 5, ntk = (jb.K + 31) >> 5;
-  const int tn0 = wn * jb.an, tk0 = wk * jb.ak;   // first n / k tile of this wave
-  f32x16 acc[4][4];
+  const int tn0 = wn * AN, tk0 = wk * AK;          // first n / k tile of this wave
+  const bool active = tn0 < ntn && tk0 < ntk;      // wave-uniform (tile counts are powers of two: all-or-nothing)
+  const int RLx = 1 << jb.lgx, RLy = 1 << jb.lgy;
+  f32x16 acc[AN][AK];
 #pragma unroll
-  for (int x = 0; x < 4; ++x)
+  for (int x = 0; x < AN; ++x)
 #pragma unroll
-    for (int y = 0; y < 4; ++y)
+    for (int y = 0; y < AK; ++y)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
-  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  float bsum[AN];
+#pragma unroll
+  for (int x = 0; x < AN; ++x) bsum[x] = 0.f;
 
-  // staging: thread -> (row = tid/8 + 32 i, 16-byte chunk = tid%8), i = 0..7, for X and for Y
-  const int srow = tid >> 3, sch = tid & 7;
-  const int nrx = ntn * 32, nry = ntk * 32;       // rows that are ever read back
-  f32x4 px[8], py[8];
-  auto fetch = [&](int64_t m0) {
-    const int64_t col = m0 + 4 * sch;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int r = srow + 32 * i;
-      f32x4 vx = {0.f, 0.f, 0.f, 0.f}, vy = {0.f, 0.f, 0.f, 0.f};
-      if (r < jb.N) vx = *reinterpret_cast<const f32x4*>(X + (int64_t)r * a.Mp + col);
-      if (r < jb.K) vy = *reinterpret_cast<const f32x4*>(Y + (int64_t)r * a.Mp + col);
-      if (col + 3 >= a.M) {   // padding columns [M, Mp) hold garbage: zero them on both sides
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (col + j >= a.M) { vx[j] = 0.f; vy[j] = 0.f; }
-      }
-      px[i] = vx; py[i] = vy;
-    }
-  };
-  auto commit = [&](float* buf) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int r = srow + 32 * i;
-      if (r < nrx) *reinterpret_cast<f32x4*>(buf + r * LDR + 4 * sch) = px[i];
-      if (r < nry) *reinterpret_cast<f32x4*>(buf + TILE_FLOATS + r * LDR + 4 * sch) = py[i];
-    }
+  auto issue = [&](int64_t m0, int buf) {
+    float* b = lds + buf * 2 * TILE_FLOATS;
+    dma_slab(X + m0 * a.g_rows, a.g_rows, jb.lgx, b, wv, lane);
+    dma_slab(Y + m0 * a.s_rows, a.s_rows, jb.lgy, b + TILE_FLOATS, wv, lane);
   };
 
   int cur = 0;
   if (m_begin < m_end) {
-    fetch(m_begin);
-    commit(lds);
+    issue(m_begin, 0);
+    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's DMA pieces have landed
     __syncthreads();
-    if (m_begin + TM < m_end) fetch(m_begin + TM);
   }
   for (int64_t m0 = m_begin; m0 < m_end; m0 += TM) {
-    const float* Xs = lds + cur * 2 * TILE_FLOATS;
-    const float* Ys = Xs + TILE_FLOATS;
+    if (m0 + TM < m_end) issue(m0 + TM, cur ^ 1);   // other buffer: all its readers passed the previous barrier
+    if (active) {
+      const float* Xs = lds + cur * 2 * TILE_FLOATS + 32 * tn0 + i31 + hh * RLx;
+      const float* Ys = lds + cur * 2 * TILE_FLOATS + TILE_FLOATS + 32 * tk0 + i31 + hh * RLy;
+#pragma unroll 4
+      for (int st = 0; st < TM / 2; ++st) {
+        float av[AN], bv[AK];
 #pragma unroll
-    for (int st = 0; st < TM / 8; ++st) {
-      f32x4 av[4], bv[4];
+        for (int x = 0; x < AN; ++x) av[x] = Xs[2 * st * RLx + 32 * x];
 #pragma unroll
-      for (int x = 0; x < 4; ++x) {
-        if (x < jb.an) av[x] = *reinterpret_cast<const f32x4*>(Xs + (32 * (tn0 + x) + i31) * LDR + 8 * st + 4 * hh);
-        if (x < jb.ak) bv[x] = *reinterpret_cast<const f32x4*>(Ys + (32 * (tk0 + x) + i31) * LDR + 8 * st + 4 * hh);
-      }
-      if (wk == 0) {
+        for (int y = 0; y < AK; ++y) bv[y] = Ys[2 * st * RLy + 32 * y];
+        if (wk == 0) {
 #pragma unroll
-        for (int x = 0; x < 4; ++x)
-          if (x < jb.an) bsum[x] += (av[x][0] + av[x][1]) + (av[x][2] + av[x][3]);
-      }
-#pragma unroll
-      for (int x = 0; x < 4; ++x) {
-        if (x < jb.an && tn0 + x < ntn) {
-#pragma unroll
-          for (int y = 0; y < 4; ++y) {
-            if (y < jb.ak && tk0 + y < ntk) {
-#pragma unroll
-              for (int j = 0; j < 4; ++j) acc[x][y] = mfma(av[x][j], bv[y][j], acc[x][y]);
-            }
-          }
+          for (int x = 0; x < AN; ++x) bsum[x] += av[x];
         }
+#pragma unroll
+        for (int x = 0; x < AN; ++x)
+#pragma unroll
+          for (int y = 0; y < AK; ++y) acc[x][y] = mfma(av[x], bv[y], acc[x][y]);
       }
     }
-    if (m0 + TM < m_end) commit(lds + (cur ^ 1) * 2 * TILE_FLOATS);   // other buffer: its readers passed the last barrier
+    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0) before the barrier publishes the next slab
     __syncthreads();
-    if (m0 + 2 * TM < m_end) fetch(m0 + 2 * TM);
     cur ^= 1;
   }
+  if (!active) return;
 
   float* out = a.partials + (int64_t)split * a.pstride;
   float* Wout = out + a.toff[jb.tensor];
 #pragma unroll
-  for (int x = 0; x < 4; ++x)
+  for (int x = 0; x < AN; ++x)
 #pragma unroll
-    for (int y = 0; y < 4; ++y) {
-      if (x >= jb.an || y >= jb.ak) continue;
+    for (int y = 0; y < AK; ++y) {
       const int k = 32 * (tk0 + y) + i31;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = 32 * (tn0 + x) + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if (n < jb.N && k < jb.K) Wout[(int64_t)n * jb.ld + jb.col0 + k] = acc[x][y][r];
+        if (n >= jb.n_lo && n < jb.N && k < jb.K) Wout[(int64_t)(n - jb.n_lo) * jb.ld + jb.col0 + k] = acc[x][y][r];
       }
     }
   if (jb.bias_tensor >= 0 && wk == 0) {
     float* Bout = out + a.toff[jb.bias_tensor];
 #pragma unroll
-    for (int x = 0; x < 4; ++x) {
-      if (x >= jb.an) continue;
+    for (int x = 0; x < AN; ++x) {
       const float s = bsum[x] + __shfl_xor(bsum[x], 32, 64);
       const int n = 32 * (tn0 + x) + i31;
-      if (hh == 0 && n < jb.N) Bout[n] = s;
+      if (hh == 0 && n >= jb.n_lo && n < jb.N) Bout[n - jb.n_lo] = s;
     }
+  }
+}
+
+__global__ __launch_bounds__(256) void wgrad_k(WgArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // [2 buffers][X slab | Y slab]
+  const WgJob& jb = a.job[blockIdx.y];
+  switch (jb.an * 8 + jb.ak) {     // block-uniform
+    case 4 * 8 + 4: wgrad_body<4, 4>(a, jb, lds); break;
+    case 4 * 8 + 2: wgrad_body<4, 2>(a, jb, lds); break;
+    case 2 * 8 + 4: wgrad_body<2, 4>(a, jb, lds); break;
+    case 4 * 8 + 1: wgrad_body<4, 1>(a, jb, lds); break;
+    case 1 * 8 + 4: wgrad_body<1, 4>(a, jb, lds); break;
+    case 2 * 8 + 2: wgrad_body<2, 2>(a, jb, lds); break;
+    case 2 * 8 + 1: wgrad_body<2, 1>(a, jb, lds); break;
+    case 1 * 8 + 2: wgrad_body<1, 2>(a, jb, lds); break;
+    default: wgrad_body<1, 1>(a, jb, lds); break;
   }
 }
 
@@ -182,6 +189,12 @@ __global__ void wgrad_reduce_k(RedArgs a) {
   }
 }
 
+int ilog2(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+
 }  // namespace
 
 int64_t cn_param_floats(const NetGeom& g) {
@@ -208,6 +221,7 @@ int cn_wgrad_nsplit(int64_t Mp) {
 
 int cn_wgrad_launch(const NetGeom& g, const float* stash, const float* G, int64_t M, int64_t Mp, float* partials,
                     int nsplit, const cnerf_ptrs* grads, int accumulate, hipStream_t st) {
+  (void)M;   // padding points [M, Mp) are stored as zeros by the producers: no masking here
   cnerf_net net{g.D, g.W, g.L, g.Ld, g.viewdirs, g.out_ch, g.skip};
   WgArgs a;
   RedArgs r;
@@ -225,7 +239,8 @@ int cn_wgrad_launch(const NetGeom& g, const float* stash, const float* G, int64_
   const int64_t pstride = cn_round_up(off, 64);
   int nj = 0;
   const int D = g.D, W = g.W, Wh = g.Wh;
-  auto add = [&](int xrow, int yrow, int N, int K, int tensor, int ld, int col0, int bias_tensor) {
+  bool ok = true;
+  auto add = [&](int xcol, int ycol, int N, int K, int tensor, int ld, int col0, int bias_tensor, int n_lo = 0) {
     const int ntn = (N + 31) / 32, ntk = (K + 31) / 32;
     // wave grid gn x gk in {1x4, 2x2, 4x1}: an x ak <= 4x4 tiles per wave; minimise the busiest wave's tile
     // count (= the workgroup's MFMA time), then the operand traffic an+ak
@@ -237,7 +252,11 @@ int cn_wgrad_launch(const NetGeom& g, const float* stash, const float* G, int64_
       const int cost = an * ak * 16 + an + ak;
       if (cost < best_cost) { best_cost = cost; best_gk = gk; best_an = an; best_ak = ak; }
     }
-    a.job[nj++] = WgJob{xrow, yrow, N, K, tensor, ld, col0, bias_tensor, best_gk ? best_gk : 2, best_an, best_ak};
+    const int lgx = ilog2(ntn * 32), lgy = ilog2(ntk * 32);
+    // slab rows are DMA'd as 2^lg floats: the tile count must be a power of two and the slab a multiple of 1 KiB
+    if (best_gk == 0 || (1 << lgx) != ntn * 32 || (1 << lgy) != ntk * 32 || best_an == 3 || best_ak == 3) ok = false;
+    a.job[nj++] = WgJob{xcol, ycol, N, K, n_lo, tensor, ld, col0, bias_tensor, best_gk ? best_gk : 2, best_an,
+                        best_ak, lgx, lgy};
     r.touched[tensor] = 1;
     if (bias_tensor >= 0) r.touched[bias_tensor] = 1;
   };
@@ -255,18 +274,14 @@ int cn_wgrad_launch(const NetGeom& g, const float* stash, const float* G, int64_
   if (g.skip >= 0) add(g.g_z[g.skip + 1], g.s_enc, W, g.in_ch, 2 * (g.skip + 1), W + g.in_ch, 0, -1);
   if (g.viewdirs) {
     add(g.g_hv, g.s_denc, Wh, g.dir_ch, base + 0, W + g.dir_ch, W, -1);
-    add(g.g_out + 3, g.s_h[D - 1], 1, W, base + 4, W, 0, base + 5);
+    add(g.g_out, g.s_h[D - 1], 4, W, base + 4, W, 0, base + 5, 3);   // d_sigma is column 3 of the d_raw copy
     add(g.g_out, g.s_hv, 3, Wh, base + 6, Wh, 0, base + 7);
   } else {
     add(g.g_out, g.s_h[D - 1], g.out_ch, W, base + 2, W, 0, base + 3);
   }
-  if (nj > MAX_WG_JOBS) return CNERF_E_UNSUPPORTED;
-  for (int j = 0; j < nj; ++j) {   // every tile must be owned by a wave
-    const WgJob& jb = a.job[j];
-    const int gn = 4 / jb.gk;
-    if (gn * jb.an * 32 < jb.N || jb.gk * jb.ak * 32 < jb.K) return CNERF_E_UNSUPPORTED;
-  }
-  a.stash = stash; a.G = G; a.partials = partials; a.M = M; a.Mp = Mp; a.pstride = pstride;
+  if (!ok || nj > MAX_WG_JOBS) return CNERF_E_UNSUPPORTED;
+  a.stash = stash; a.G = G; a.partials = partials; a.Mp = Mp; a.pstride = pstride;
+  a.s_rows = g.s_rows; a.g_rows = g.g_rows;
   a.chunk = cn_round_up(cn_div_up(Mp, nsplit), TM);
   const size_t lds_bytes = (size_t)4 * TILE_FLOATS * sizeof(float);
   static bool attr_set = false;

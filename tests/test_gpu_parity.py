@@ -91,9 +91,12 @@ def check_param_grads(model, g, prefix_full, prefix_sum, rtol=5e-2, l2tol=5e-3):
 
 
 def stash_blocks(stash, M, D, W, vd):
-    """[rows][Mp] training stash of cnerf_mlp_fwd -> dict of [M, rows] float64 CPU tensors (common.hpp)."""
+    """point-major [Mp][rows] training stash of cnerf_mlp_fwd -> dict of [M, cols] float64 CPU tensors (common.hpp).
+    Padding points [M, Mp) must have been stored as zeros (the wgrad DMA relies on it)."""
     Mp = (M + 31) // 32 * 32
-    s = stash.reshape(-1, Mp)[:, :M].t().double().cpu()
+    full = stash.reshape(Mp, -1)
+    assert float(full[M:].abs().max()) == 0.0 if Mp > M else True
+    s = full[:M].double().cpu()
     out, r = {}, 0
 
     def take(name, n):
