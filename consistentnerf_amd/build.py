@@ -16,7 +16,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: the reference composes separately-rounded ATen ops; FMA contraction would change
 # sample positions / encodings by an ulp that 2^9-frequency encodings amplify.  MFMA code is unaffected.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-         "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-Wno-unused-result"]
+         "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-Wno-unused-result"] + os.environ.get("CN_EXTRA_FLAGS", "").split()
 
 
 def sources():

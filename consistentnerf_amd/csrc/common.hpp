@@ -35,10 +35,12 @@ __device__ __forceinline__ float wave_sum(float v) {
 // as P[K/8][Np][8] floats, P[kg][n][j] = W[n][8*kg + j] (zero padded), so that lane (i = lane&31,
 // hh = lane>>5) of a wave fetches the 4 consecutive k it feeds to 4 successive
 // v_mfma_f32_32x32x2_f32 with ONE 16-byte load at P + ((kg*Np + n0 + i)*8 + 4*hh), and a wave's 64
-// lanes read 1 KiB contiguous.
+// lanes read 1 KiB contiguous.  Forward panels of biased layers carry ONE MORE group, P[K/8][n][0] = bias[n]:
+// the bias is added by a last MFMA step against a constant B operand (1 for the hh=0 half-wave), so no bias
+// vector is ever loaded into registers.
 struct NetGeom {
   int D, W, NT;             // NT = W/32 output tiles of a W-wide layer
-  int in_ch, in_chp;        // gamma(x) channels (63) and padded to a multiple of 16 (64)
+  int in_ch, in_chp;        // gamma(x) channels (63) and padded to a multiple of 32 (64)
   int dir_ch, dir_chp;      // gamma(d) channels (27) / padded (32); 0 without viewdirs
   int L, Ld;                // encoding frequencies
   int viewdirs, out_ch, skip;

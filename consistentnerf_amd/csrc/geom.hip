@@ -19,24 +19,24 @@ int cn_make_geom(const cnerf_net* net, NetGeom* g) {
   if (!net->use_viewdirs && (net->output_ch < 4 || net->output_ch > 8)) return CNERF_E_UNSUPPORTED;
   g->D = net->D; g->W = net->W; g->NT = net->W / 32; g->Wh = net->W / 2;
   g->L = net->multires; g->Ld = net->multires_views;
-  g->in_ch = enc_dim(net->multires); g->in_chp = (int)cn_round_up(g->in_ch, 16);
+  g->in_ch = enc_dim(net->multires); g->in_chp = (int)cn_round_up(g->in_ch, 32);
   g->viewdirs = net->use_viewdirs ? 1 : 0;
   g->dir_ch = g->viewdirs ? enc_dim(net->multires_views) : 0;
-  g->dir_chp = (int)cn_round_up(g->dir_ch, 16);
+  g->dir_chp = (int)cn_round_up(g->dir_ch, 32);
   g->out_ch = g->viewdirs ? 4 : net->output_ch;
   g->skip = (net->skip >= 0 && net->skip + 1 < net->D) ? net->skip : -1;
   const int64_t W = g->W, Wh = g->Wh;
   int64_t off = 0;
   auto take = [&](int64_t n) { int64_t o = off; off += cn_round_up(n, 64); return o; };
-  g->f_l0 = take((int64_t)g->in_chp * W);
-  for (int l = 1; l < g->D; ++l) g->f_trunk[l] = take(W * W);
-  g->f_skip = g->skip >= 0 ? take((int64_t)g->in_chp * W) : -1;
+  g->f_l0 = take((int64_t)(g->in_chp + 8) * W);            // + bias group (common.hpp)
+  for (int l = 1; l < g->D; ++l) g->f_trunk[l] = take((W + 8) * W);
+  g->f_skip = g->skip >= 0 ? take((int64_t)(g->in_chp + 8) * W) : -1;
   for (int l = 1; l < g->D; ++l) g->t_trunk[l] = take(W * W);
   for (int l = 0; l < g->D; ++l) g->b_trunk[l] = take(W);
   if (g->viewdirs) {
-    g->f_feat = take(W * W);
+    g->f_feat = take((W + 8) * W);
     g->f_views = take(W * Wh);
-    g->f_viewsd = take((int64_t)g->dir_chp * Wh);
+    g->f_viewsd = take((int64_t)(g->dir_chp + 8) * Wh);
     g->t_feat = take(W * W);
     g->t_views = take(Wh * W);
     g->v_alpha = take(W);
@@ -146,13 +146,15 @@ struct PackJob {
   int rows_p;         // padded row count of the panel (N rounded to 32 for PANEL; K rounded to 32 for PANEL_T)
   int groups;         // number of 8-wide groups along the contracted index
   int64_t dst;
+  const float* bias;  // JOB_PANEL only: extra group `groups` with P[groups][n][0] = bias[n] (the bias MFMA step)
 };
-constexpr int MAX_JOBS = 64;
+constexpr int MAX_JOBS = 56;
 struct PackArgs { PackJob job[MAX_JOBS]; float* packed; };
 
 __global__ void pack_k(PackArgs a) {
   const PackJob j = a.job[blockIdx.y];
-  const int64_t n = j.mode == JOB_COPY ? (int64_t)j.N * j.K : (int64_t)j.groups * j.rows_p * 8;
+  const int ngroups = j.groups + (j.mode == JOB_PANEL && j.bias != nullptr ? 1 : 0);
+  const int64_t n = j.mode == JOB_COPY ? (int64_t)j.N * j.K : (int64_t)ngroups * j.rows_p * 8;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     float v = 0.f;
     if (j.mode == JOB_COPY) {
@@ -164,7 +166,8 @@ __global__ void pack_k(PackArgs a) {
       const int grp = (int)((i >> 3) / j.rows_p);
       if (j.mode == JOB_PANEL) {          // P[kg][n][e] = W[n][col0 + 8kg + e]
         const int k = 8 * grp + e;
-        if (row < j.N && k < j.K) v = j.src[(int64_t)row * j.ld + j.col0 + k];
+        if (grp == j.groups) { if (e == 0 && row < j.N) v = j.bias[row]; }
+        else if (row < j.N && k < j.K) v = j.src[(int64_t)row * j.ld + j.col0 + k];
       } else {                            // PT[ng][k][e] = W[8ng + e][col0 + k]
         const int nn = 8 * grp + e;
         if (nn < j.N && row < j.K) v = j.src[(int64_t)nn * j.ld + j.col0 + row];
@@ -188,39 +191,39 @@ extern "C" int cnerf_pack_weights(const cnerf_net* net, const cnerf_ptrs* params
   a.packed = packed;
   int nj = 0;
   const int W = g.W, Wh = g.Wh, D = g.D;
-  auto panel = [&](const float* src, int ld, int col0, int N, int K, int64_t dst) {
-    a.job[nj++] = PackJob{src, ld, col0, N, K, JOB_PANEL, (int)cn_round_up(N, 32), (int)cn_div_up(K, 8), dst};
+  // contracted width padded to a multiple of 32 (4 groups: the depth of the A-operand prefetch ring)
+  auto panel = [&](const float* src, int ld, int col0, int N, int K, int64_t dst, const float* bias = nullptr) {
+    a.job[nj++] = PackJob{src, ld, col0, N, K, JOB_PANEL, (int)cn_round_up(N, 32), (int)cn_round_up(K, 32) / 8, dst,
+                          bias};
   };
   auto panel_t = [&](const float* src, int ld, int col0, int N, int K, int64_t dst) {
-    a.job[nj++] = PackJob{src, ld, col0, N, K, JOB_PANEL_T, (int)cn_round_up(K, 32), (int)cn_div_up(N, 8), dst};
+    a.job[nj++] = PackJob{src, ld, col0, N, K, JOB_PANEL_T, (int)cn_round_up(K, 32), (int)cn_div_up(N, 8), dst,
+                          nullptr};
   };
   auto copy = [&](const float* src, int N, int K, int64_t dst) {
-    a.job[nj++] = PackJob{src, K, 0, N, K, JOB_COPY, 0, 0, dst};
+    a.job[nj++] = PackJob{src, K, 0, N, K, JOB_COPY, 0, 0, dst, nullptr};
   };
   auto Wt = [&](int l) { return params->p[2 * l]; };
   auto Bt = [&](int l) { return params->p[2 * l + 1]; };
-  panel(Wt(0), g.in_ch, 0, W, g.in_ch, g.f_l0);
+  panel(Wt(0), g.in_ch, 0, W, g.in_ch, g.f_l0, Bt(0));
   for (int l = 1; l < D; ++l) {
     const bool sk = g.skip >= 0 && l == g.skip + 1;
     const int ld = sk ? W + g.in_ch : W, c0 = sk ? g.in_ch : 0;
-    panel(Wt(l), ld, c0, W, W, g.f_trunk[l]);
+    panel(Wt(l), ld, c0, W, W, g.f_trunk[l], sk ? nullptr : Bt(l));   // skip layer: bias rides on f_skip
     panel_t(Wt(l), ld, c0, W, W, g.t_trunk[l]);
-    if (sk) panel(Wt(l), ld, 0, W, g.in_ch, g.f_skip);
+    if (sk) panel(Wt(l), ld, 0, W, g.in_ch, g.f_skip, Bt(l));
   }
-  for (int l = 0; l < D; ++l) copy(Bt(l), 1, W, g.b_trunk[l]);
   const int base = 2 * D;
   if (g.viewdirs) {
     const float* Wv = params->p[base + 0];
     const int ldv = W + g.dir_ch;
-    panel(params->p[base + 2], W, 0, W, W, g.f_feat);
+    panel(params->p[base + 2], W, 0, W, W, g.f_feat, params->p[base + 3]);
     panel_t(params->p[base + 2], W, 0, W, W, g.t_feat);
     panel(Wv, ldv, 0, Wh, W, g.f_views);
-    panel(Wv, ldv, W, Wh, g.dir_ch, g.f_viewsd);
+    panel(Wv, ldv, W, Wh, g.dir_ch, g.f_viewsd, params->p[base + 1]);
     panel_t(Wv, ldv, 0, Wh, W, g.t_views);
     copy(params->p[base + 4], 1, W, g.v_alpha);
     copy(params->p[base + 6], 3, Wh, g.v_rgb);
-    copy(params->p[base + 3], 1, W, g.b_feat);
-    copy(params->p[base + 1], 1, Wh, g.b_views);
     copy(params->p[base + 5], 1, 1, g.b_alpha);
     copy(params->p[base + 7], 1, 3, g.b_rgb);
   } else {

@@ -64,14 +64,6 @@ __device__ __forceinline__ void mask_park(f32x16 (&acc)[NTO], const f32x16 (&h)[
     }
 }
 
-template <int NTO>
-__device__ __forceinline__ void zero_acc(f32x16 (&acc)[NTO]) {
-#pragma unroll
-  for (int t = 0; t < NTO; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-}
-
 template <int NT, bool VD>
 __global__ __launch_bounds__(64) void mlp_dgrad_k(BwdArgs a) {
   constexpr int W = NT * 32;
@@ -121,7 +113,7 @@ __global__ __launch_bounds__(64) void mlp_dgrad_k(BwdArgs a) {
     }
     // views_linears^T (feature columns only; gamma(d) needs no gradient) -> dF
     zero_acc<NT>(acc);
-    gemm_seg<W, NT>(acc, pk + g.t_views, W, g.Wh / 8, Hs, m, hh, a0);
+    gemm_seg_a0<W, NT>(acc, pk + g.t_views, W, g.Wh / 8, Hs, m, hh, a0);
     __builtin_amdgcn_wave_barrier();
     mask_park<W, NT, false>(acc, hm, Hs, gp, g.g_feat, valid, m, hh);
     __builtin_amdgcn_wave_barrier();
@@ -135,7 +127,7 @@ __global__ __launch_bounds__(64) void mlp_dgrad_k(BwdArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[t][4 * q + j] = w[j] * dc[3];
       }
-    gemm_seg<W, NT>(acc, pk + g.t_feat, W, W / 8, Hs, m, hh, a0);
+    gemm_seg_a0<W, NT>(acc, pk + g.t_feat, W, W / 8, Hs, m, hh, a0);
   } else {
     load_rows<NT>(hm, sp, g.s_h[g.D - 1]);
     float dc[8];
@@ -169,7 +161,7 @@ __global__ __launch_bounds__(64) void mlp_dgrad_k(BwdArgs a) {
     load_a0<NT>(a0, pk + g.t_trunk[l], m, hh);
     load_rows<NT>(hm, sp, g.s_h[l - 1]);
     zero_acc<NT>(acc);
-    gemm_seg<W, NT>(acc, pk + g.t_trunk[l], W, W / 8, Hs, m, hh, a0);
+    gemm_seg_a0<W, NT>(acc, pk + g.t_trunk[l], W, W / 8, Hs, m, hh, a0);
     __builtin_amdgcn_wave_barrier();
     mask_park<W, NT, true>(acc, hm, Hs, gp, g.g_z[l - 1], valid, m, hh);
     __builtin_amdgcn_wave_barrier();

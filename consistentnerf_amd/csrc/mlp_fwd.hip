@@ -3,17 +3,19 @@
 // encodings and every [M,256] activation of the reference never reach HBM (inference), or reach it
 // exactly once as the training stash.
 //
-// Mapping.  One wave64 owns 32 points and walks them through the whole network.  Every layer is
-// computed TRANSPOSED, Out^T[N x 32] = W[N x K] . H^T[K x 32], with v_mfma_f32_32x32x2_f32 (exact
-// fp32, bit-equal to an fmaf chain):
+// Mapping.  A workgroup of two wave64 owns 32 points and walks them through the whole network; 4 workgroups per
+// CU = 2 waves per SIMD.  Every layer is computed TRANSPOSED, Out^T[N x 32] = W[N x K] . H^T[K x 32], with
+// v_mfma_f32_32x32x2_f32 (exact fp32, bit-equal to an fmaf chain); wave w produces output tiles
+// [w*NT/2, (w+1)*NT/2):
 //   A operand  = weights, lane (i = lane&31, hh = lane>>5) holds W[n0+i][k + hh'] — one 16-byte load of
 //                the packed panel (common.hpp) feeds 4 consecutive MFMAs; a wave reads 1 KiB contiguous.
-//   B operand  = activations of the wave's 32 points, lane (m = lane&31, hh) holds H^T[k][m]; read from a
-//                per-wave LDS tile Hs[m][k] (16-byte chunks XOR-swizzled by m&15: conflict-free b128).
+//   B operand  = activations of the 32 points, lane (m = lane&31, hh) holds H^T[k][m]; read from the workgroup's
+//                LDS tile Hs[m][k] (16-byte chunks XOR-swizzled by m&15: conflict-free b128).
 //   D (C-layout) lane (m, hh) holds rows n = 32t + 8(r>>2) + 4hh + (r&3): 4 consecutive n per float4,
 //                so ReLU'd accumulators go back to Hs with ds_write_b128 and straight into the next layer.
-// No workgroup barriers, no cross-wave traffic; weights (2.4 MB/net) stay L2-resident and are streamed by
-// every wave; MFMA-bound by construction (593 920 MAC per point at D=8/W=256 incl. K padding).
+// Two workgroup barriers per layer (tile fully read -> overwrite -> fully written); weights (2.4 MB/net) stay
+// L2-resident and are streamed once per 32 points; MFMA-bound by construction (593 920 MAC per point at
+// D=8/W=256 incl. K padding).
 #include "mlp_common.hpp"
 
 namespace {
@@ -31,39 +33,50 @@ struct FwdArgs {
   int S, rs;
 };
 
-// gamma(x) channels of one point into Hs[m][0..chp): hh=0 lanes write x and the sines, hh=1 the cosines
-// and the zero padding.  Channel order H:24-45: [x, sin(2^0 x), cos(2^0 x), ..., sin(2^(L-1) x), cos(..)].
+// gamma(x) channels of one point into Hs[m][0..chp), split over the workgroup's two waves (w) and the two
+// half-waves (hh): wave w takes the frequencies l = w, w+2, ...; hh=0 lanes their sines, hh=1 their cosines;
+// wave 0 / hh 0 the identity channels, wave 1 / hh 1 the zero padding.
+// Channel order H:24-45: [x, sin(2^0 x), cos(2^0 x), ..., sin(2^(L-1) x), cos(..)].  `srow` = this point's stash
+// row + block column (training) or nullptr.
 template <int W>
-__device__ __forceinline__ void encode(float* Hs, const float (&x)[3], int L, int ch, int chp, int m, int hh) {
-  auto put = [&](int k, float v) { Hs[hs_off<W>(m, k >> 2) + (k & 3)] = v; };
-  if (hh == 0) {
+__device__ __forceinline__ void encode(float* Hs, const float (&x)[3], int L, int ch, int chp, int w, int m, int hh,
+                                       float* __restrict__ srow, bool valid) {
+  auto put = [&](int k, float v) {
+    Hs[hs_off<W>(m, k >> 2) + (k & 3)] = v;
+    if (srow != nullptr) srow[k] = valid ? v : 0.f;
+  };
+  if (w == 0 && hh == 0) {
     put(0, x[0]); put(1, x[1]); put(2, x[2]);
-  } else {
+  }
+  if (w == 1 && hh == 1) {
     for (int k = ch; k < chp; ++k) put(k, 0.f);
   }
-  float f = 1.f;
-  for (int l = 0; l < L; ++l) {
+  float f = w ? 2.f : 1.f;
+  for (int l = w; l < L; l += 2) {
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
       const float arg = x[d] * f;
       put(3 + 6 * l + 3 * hh + d, hh ? cosf(arg) : sinf(arg));
     }
-    f *= 2.f;
+    f *= 4.f;
   }
 }
 
 template <int NT, bool VD>
-__global__ __launch_bounds__(64) void mlp_fwd_k(FwdArgs a) {
+__global__ __launch_bounds__(128, 2) void mlp_fwd_k(FwdArgs a) {
   constexpr int W = NT * 32;
-  constexpr int NTH = NT / 2 > 0 ? NT / 2 : 1;
-  extern __shared__ __attribute__((aligned(16))) float Hs[];
+  constexpr int NTW = NT / 2;                       // trunk / feature tiles per wave
+  constexpr int NTH = NT / 2;                       // view-branch tiles (W/2 wide)
+  constexpr int NTHW = NTH / 2 > 0 ? NTH / 2 : 1;   // ... per wave (W=64: one tile, wave 0 only)
+  extern __shared__ __attribute__((aligned(16))) float Hs[];   // [32][W] tile + 128 floats of head scratch
   const NetGeom& g = a.g;
-  const int lane = threadIdx.x, m = lane & 31, hh = lane >> 5;
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, m = lane & 31, hh = lane >> 5;
   const int64_t p = (int64_t)blockIdx.x * 32 + m;
   const bool valid = p < a.M;
   const int64_t pc = valid ? p : a.M - 1;
   const int64_t ray = pc / a.S;
   const float* pk = a.packed;
+  const int t0 = w * NTW;
 
   float x[3];
   if (a.pts != nullptr) {
@@ -73,137 +86,141 @@ __global__ __launch_bounds__(64) void mlp_fwd_k(FwdArgs a) {
     const float zz = a.z[pc];
     x[0] = r[0] + r[3] * zz; x[1] = r[1] + r[4] * zz; x[2] = r[2] + r[5] * zz;   // R:384 (no FMA contraction)
   }
-  // training: the stash row of the tile's first point (point-major [Mp][s_rows]); every block of the tile is
-  // copied out of LDS with coalesced 1 KiB stores right after it is parked
-  const int64_t pbase = (int64_t)blockIdx.x * 32;
-  float* const st = a.stash != nullptr ? a.stash + pbase * g.s_rows : nullptr;
-  auto stash_tile = [&](int col, int ncols) {
-    if (st != nullptr) tile_to_global<W>(Hs, st + col, g.s_rows, ncols, pbase, a.M, lane);
-  };
-  // Ordering rule for every layer: [loads the next GEMM needs first: bias, A group 0] are queued BEFORE the
-  // stash stores of the block just parked (see load_a0), the GEMM after them.
-  encode<W>(Hs, x, g.L, g.in_ch, g.in_chp, m, hh);
-  __builtin_amdgcn_wave_barrier();
+  // training: this point's stash row (point-major [Mp][s_rows]); padding points p in [M, Mp) are stored as zeros
+  float* const srow = a.stash != nullptr ? a.stash + p * g.s_rows : nullptr;
+  float* const sp = srow != nullptr ? srow + 4 * hh : nullptr;
 
-  f32x16 acc[NT];
-  f32x16 accs[NT];   // gamma(x) part of the skip layer, computed while gamma(x) is still in LDS
-  f32x4 a0[NT];
-  load_a0<NT>(a0, pk + g.f_l0, m, hh);
-  init_bias<NT>(acc, pk + g.b_trunk[0], hh);
-  stash_tile(g.s_enc, g.in_chp);
-  gemm_seg<W, NT>(acc, pk + g.f_l0, W, g.in_chp / 8, Hs, m, hh, a0);
+  encode<W>(Hs, x, g.L, g.in_ch, g.in_chp, w, m, hh, srow != nullptr ? srow + g.s_enc : nullptr, valid);
+  __syncthreads();
+
+  // Per layer: GEMM -> [queue the next panel's first A groups] -> barrier (tile fully read) -> park (ReLU, LDS,
+  // stash) -> barrier -> next GEMM.  Biases ride on the panels (gemm_run<BIAS>), accumulators start at zero.
+  f32x16 acc[NTW];
+  f32x16 accs[NTW];   // gamma(x) part (+ bias) of the skip layer, computed while gamma(x) is still in LDS
+  Ring<NTW> R;
+  zero_acc<NTW>(acc);
+  gemm_seg<W, NTW, true>(acc, pk + g.f_l0 + t0 * 256, W, g.in_chp / 8, Hs, m, hh);
   if (g.skip >= 0) {
-    init_bias<NT>(accs, pk + g.b_trunk[g.skip + 1], hh);
-    gemm_seg<W, NT>(accs, pk + g.f_skip, W, g.in_chp / 8, Hs, m, hh);
+    zero_acc<NTW>(accs);
+    gemm_seg<W, NTW, true>(accs, pk + g.f_skip + t0 * 256, W, g.in_chp / 8, Hs, m, hh);
   }
-  __builtin_amdgcn_wave_barrier();
-  park<W, NT, true>(acc, Hs, m, hh);
-  __builtin_amdgcn_wave_barrier();
-
   for (int l = 1; l < g.D; ++l) {
-    load_a0<NT>(a0, pk + g.f_trunk[l], m, hh);
-    if (l == g.skip + 1) {
+    const bool sk = l == g.skip + 1;
+    const float* panel = pk + g.f_trunk[l] + t0 * 256;
+    ring_start<NTW>(R, panel, W, sk ? W / 8 - 1 : W / 8, m, hh);
+    __syncthreads();                                 // both waves finished reading the tile
+    park<W, NTW, true>(acc, Hs, true, t0, m, hh, sp, g.s_h[l - 1], valid);
+    __syncthreads();
+    if (sk) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = accs[t];
+      for (int t = 0; t < NTW; ++t) acc[t] = accs[t];
+      gemm_run<W, NTW, false>(acc, R, panel, W, W / 8, Hs, m, hh);
     } else {
-      init_bias<NT>(acc, pk + g.b_trunk[l], hh);
+      zero_acc<NTW>(acc);
+      gemm_run<W, NTW, true>(acc, R, panel, W, W / 8, Hs, m, hh);
     }
-    stash_tile(g.s_h[l - 1], W);
-    gemm_seg<W, NT>(acc, pk + g.f_trunk[l], W, W / 8, Hs, m, hh, a0);
-    __builtin_amdgcn_wave_barrier();
-    park<W, NT, true>(acc, Hs, m, hh);
-    __builtin_amdgcn_wave_barrier();
   }
+  if (VD) ring_start<NTW>(R, pk + g.f_feat + t0 * 256, W, W / 8, m, hh);
+  __syncthreads();
+  park<W, NTW, true>(acc, Hs, true, t0, m, hh, sp, g.s_h[g.D - 1], valid);
+  __syncthreads();
 
   if (!VD) {
-    // output_linear (H:127-128): out[c] = b[c] + sum_k Wo[c][k] h[k]; each half-wave sums half the chunks
-    float o[8];
+    // output_linear (H:127-128) on the VALU of wave 0: out[c] = b[c] + sum_k Wo[c][k] h[k]; each half-wave sums
+    // half the chunks
+    if (w == 0) {
+      float o[8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) o[c] = 0.f;
-    for (int i = 0; i < W / 8; ++i) {
-      const int ck = 2 * i + hh;
-      const f32x4 h = *reinterpret_cast<const f32x4*>(Hs + hs_off<W>(m, ck));
+      for (int c = 0; c < 8; ++c) o[c] = 0.f;
+      for (int i = 0; i < W / 8; ++i) {
+        const int ck = 2 * i + hh;
+        const f32x4 h = *reinterpret_cast<const f32x4*>(Hs + hs_off<W>(m, ck));
 #pragma unroll
-      for (int c = 0; c < 8; ++c)
-        if (c < g.out_ch) {
-          const f32x4 w = *reinterpret_cast<const f32x4*>(pk + g.v_out + (int64_t)c * W + 4 * ck);
-          o[c] += h[0] * w[0] + h[1] * w[1] + h[2] * w[2] + h[3] * w[3];
-        }
+        for (int c = 0; c < 8; ++c)
+          if (c < g.out_ch) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(pk + g.v_out + (int64_t)c * W + 4 * ck);
+            o[c] += h[0] * wv[0] + h[1] * wv[1] + h[2] * wv[2] + h[3] * wv[3];
+          }
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) o[c] += __shfl_xor(o[c], 32, 64);
+      if (valid && hh == 0)
+        for (int c = 0; c < g.out_ch; ++c) a.raw[p * g.out_ch + c] = o[c] + pk[g.b_out + c];
     }
-#pragma unroll
-    for (int c = 0; c < 8; ++c) o[c] += __shfl_xor(o[c], 32, 64);
-    if (valid && hh == 0)
-      for (int c = 0; c < g.out_ch; ++c) a.raw[p * g.out_ch + c] = o[c] + pk[g.b_out + c];
-    stash_tile(g.s_h[g.D - 1], W);
     return;
   } else {
-    // sigma head (alpha_linear, H:117) on the VALU while the trunk output is in LDS
-    load_a0<NT>(a0, pk + g.f_feat, m, hh);
-    init_bias<NT>(acc, pk + g.b_feat, hh);
+    // sigma head (alpha_linear, H:117) on the VALU of wave 0 while the trunk output is in LDS
     float sig = 0.f;
-    for (int i = 0; i < W / 8; ++i) {
-      const int ck = 2 * i + hh;
-      const f32x4 h = *reinterpret_cast<const f32x4*>(Hs + hs_off<W>(m, ck));
-      const f32x4 w = *reinterpret_cast<const f32x4*>(pk + g.v_alpha + 4 * ck);
-      sig += h[0] * w[0] + h[1] * w[1] + h[2] * w[2] + h[3] * w[3];
+    if (w == 0) {
+      for (int i = 0; i < W / 8; ++i) {
+        const int ck = 2 * i + hh;
+        const f32x4 h = *reinterpret_cast<const f32x4*>(Hs + hs_off<W>(m, ck));
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(pk + g.v_alpha + 4 * ck);
+        sig += h[0] * wv[0] + h[1] * wv[1] + h[2] * wv[2] + h[3] * wv[3];
+      }
+      sig += __shfl_xor(sig, 32, 64);
+      sig += pk[g.b_alpha];
     }
-    sig += __shfl_xor(sig, 32, 64);
-    sig += pk[g.b_alpha];
+    // feature_linear (H:118), no activation
+    zero_acc<NTW>(acc);
+    gemm_run<W, NTW, true>(acc, R, pk + g.f_feat + t0 * 256, W, W / 8, Hs, m, hh);
+    __syncthreads();                                 // trunk output dead
+    // gamma(viewdir) overwrites the trunk tile; its share of views_linears first
     float v[3];
     {
       const float* dsrc = a.dirs != nullptr ? a.dirs + ray * 3 : a.rays + ray * a.rs + (a.rs - 3);
       v[0] = dsrc[0]; v[1] = dsrc[1]; v[2] = dsrc[2];
     }
-    stash_tile(g.s_h[g.D - 1], W);
-    // feature_linear (H:118), no activation
-    gemm_seg<W, NT>(acc, pk + g.f_feat, W, W / 8, Hs, m, hh, a0);
-    __builtin_amdgcn_wave_barrier();
-    // gamma(viewdir) overwrites the (now dead) trunk tile; its share of views_linears first
-    encode<W>(Hs, v, g.Ld, g.dir_ch, g.dir_chp, m, hh);
-    __builtin_amdgcn_wave_barrier();
-    f32x16 accv[NTH];
-    f32x4 av0[NTH];
-    load_a0<NTH>(av0, pk + g.f_viewsd, m, hh);
-    init_bias<NTH>(accv, pk + g.b_views, hh);
-    stash_tile(g.s_denc, g.dir_chp);
-    gemm_seg<W, NTH>(accv, pk + g.f_viewsd, g.Wh, g.dir_chp / 8, Hs, m, hh, av0);
-    __builtin_amdgcn_wave_barrier();
-    park<W, NT, false>(acc, Hs, m, hh);
-    __builtin_amdgcn_wave_barrier();
-    load_a0<NTH>(av0, pk + g.f_views, m, hh);
-    stash_tile(g.s_feat, W);
-    gemm_seg<W, NTH>(accv, pk + g.f_views, g.Wh, W / 8, Hs, m, hh, av0);
-    __builtin_amdgcn_wave_barrier();
-    park<W, NTH, true>(accv, Hs, m, hh);      // ReLU in registers (rgb head below); LDS copy only feeds the stash
-    __builtin_amdgcn_wave_barrier();
-    // rgb_linear (H:125) straight from the accumulators: lane holds n = 32t + 8q + 4hh + j
-    float o[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-    for (int t = 0; t < NTH; ++t)
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const f32x4 w = *reinterpret_cast<const f32x4*>(pk + g.v_rgb + (int64_t)c * g.Wh + 32 * t + 8 * q + 4 * hh);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) o[c] += accv[t][4 * q + j] * w[j];
-        }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) o[c] += __shfl_xor(o[c], 32, 64);
-    if (valid && hh == 0) {
-      *reinterpret_cast<float4*>(a.raw + p * 4) =
-          make_float4(o[0] + pk[g.b_rgb + 0], o[1] + pk[g.b_rgb + 1], o[2] + pk[g.b_rgb + 2], sig);
+    encode<W>(Hs, v, g.Ld, g.dir_ch, g.dir_chp, w, m, hh, srow != nullptr ? srow + g.s_denc : nullptr, valid);
+    __syncthreads();
+    const int t0v = w * NTHW;
+    const bool vact = t0v < NTH;                     // wave-uniform
+    f32x16 accv[NTHW];
+    if (vact) {
+      zero_acc<NTHW>(accv);
+      gemm_seg<W, NTHW, true>(accv, pk + g.f_viewsd + t0v * 256, g.Wh, g.dir_chp / 8, Hs, m, hh);
     }
-    stash_tile(g.s_hv, g.Wh);
+    __syncthreads();                                 // gamma(d) dead
+    park<W, NTW, false>(acc, Hs, true, t0, m, hh, sp, g.s_feat, valid);
+    __syncthreads();
+    float o[3] = {0.f, 0.f, 0.f};
+    if (vact) {
+      gemm_seg<W, NTHW, false>(accv, pk + g.f_views + t0v * 256, g.Wh, W / 8, Hs, m, hh);
+      park<W, NTHW, true>(accv, Hs, false, t0v, m, hh, sp, g.s_hv, valid);   // ReLU in registers (+ stash)
+      // rgb_linear (H:125) straight from the accumulators: lane holds n = 32t + 8q + 4hh + j
+#pragma unroll
+      for (int t = 0; t < NTHW; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(pk + g.v_rgb + (int64_t)c * g.Wh + 32 * (t0v + t) +
+                                                             8 * q + 4 * hh);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[c] += accv[t][4 * q + j] * wv[j];
+          }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) o[c] += __shfl_xor(o[c], 32, 64);
+    }
+    float* scratch = Hs + 32 * W;                    // 32 points x 4 floats, outside the tile
+    if (w == 1 && hh == 0) {
+      scratch[4 * m + 0] = o[0]; scratch[4 * m + 1] = o[1]; scratch[4 * m + 2] = o[2];
+    }
+    __syncthreads();
+    if (w == 0 && hh == 0 && valid) {
+      *reinterpret_cast<float4*>(a.raw + p * 4) =
+          make_float4(o[0] + scratch[4 * m + 0] + pk[g.b_rgb + 0], o[1] + scratch[4 * m + 1] + pk[g.b_rgb + 1],
+                      o[2] + scratch[4 * m + 2] + pk[g.b_rgb + 2], sig);
+    }
   }
 }
 
 template <int NT>
 int launch(const FwdArgs& a, hipStream_t st) {
   const unsigned grid = (unsigned)cn_div_up(a.M, 32);
-  const size_t lds = (size_t)NT * 32 * 32 * sizeof(float);
-  if (a.g.viewdirs) hipLaunchKernelGGL((mlp_fwd_k<NT, true>), dim3(grid), dim3(64), lds, st, a);
-  else hipLaunchKernelGGL((mlp_fwd_k<NT, false>), dim3(grid), dim3(64), lds, st, a);
+  const size_t lds = (size_t)(NT * 32 * 32 + 128) * sizeof(float);
+  if (a.g.viewdirs) hipLaunchKernelGGL((mlp_fwd_k<NT, true>), dim3(grid), dim3(128), lds, st, a);
+  else hipLaunchKernelGGL((mlp_fwd_k<NT, false>), dim3(grid), dim3(128), lds, st, a);
   CN_CHECK_LAUNCH();
   return CNERF_OK;
 }
