@@ -17,6 +17,7 @@
 namespace {
 
 constexpr int MAX_WG_JOBS = 48;
+constexpr int NWAVES = 8;                   // waves per workgroup (2 per SIMD)
 constexpr int TM = 32;                      // points per LDS slab
 constexpr int TILE_FLOATS = TM * 256;       // one operand slab at full width
 
@@ -51,7 +52,7 @@ __device__ __forceinline__ void dma_slab(const float* __restrict__ src, int64_t 
                                          int lane) {
   const int nchunk = (TM << lg) >> 8;
   const int e0 = 4 * lane;
-  for (int c = wv; c < nchunk; c += 4) {
+  for (int c = wv; c < nchunk; c += NWAVES) {
     const int e = (c << 8) + e0;
     const int pt = e >> lg, col = e & ((1 << lg) - 1);
     __builtin_amdgcn_global_load_lds((glb_ptr)(src + (int64_t)pt * stride + col), (lds_ptr)(dst + (c << 8)), 16, 0, 0);
@@ -148,11 +149,10 @@ __device__ __forceinline__ void wgrad_body(const WgArgs& a, const WgJob& jb, flo
   }
 }
 
-__global__ __launch_bounds__(256) void wgrad_k(WgArgs a) {
+__global__ __launch_bounds__(64 * NWAVES, 2) void wgrad_k(WgArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];   // [2 buffers][X slab | Y slab]
   const WgJob& jb = a.job[blockIdx.y];
   switch (jb.an * 8 + jb.ak) {     // block-uniform
-    case 4 * 8 + 4: wgrad_body<4, 4>(a, jb, lds); break;
     case 4 * 8 + 2: wgrad_body<4, 2>(a, jb, lds); break;
     case 2 * 8 + 4: wgrad_body<2, 4>(a, jb, lds); break;
     case 4 * 8 + 1: wgrad_body<4, 1>(a, jb, lds); break;
@@ -213,7 +213,7 @@ int64_t cn_param_floats(const NetGeom& g) {
 int cn_wgrad_nsplit(int64_t Mp) {
   // many small point ranges (>= 64 slabs of 32 points each) so that the ~15 GEMMs x nsplit workgroups of
   // unequal size pack well onto 256 CUs; capped to bound the partial-gradient buffer (nsplit x 4.8 MB)
-  int64_t s = Mp / 2048;
+  int64_t s = Mp / 4096;
   if (s < 1) s = 1;
   if (s > 128) s = 128;
   return (int)s;
@@ -245,10 +245,10 @@ int cn_wgrad_launch(const NetGeom& g, const float* stash, const float* G, int64_
     // wave grid gn x gk in {1x4, 2x2, 4x1}: an x ak <= 4x4 tiles per wave; minimise the busiest wave's tile
     // count (= the workgroup's MFMA time), then the operand traffic an+ak
     int best_gk = 0, best_an = 0, best_ak = 0, best_cost = 1 << 30;
-    for (int gn = 1; gn <= 4; gn *= 2) {
-      const int gk = 4 / gn;
+    for (int gn = 1; gn <= NWAVES; gn *= 2) {
+      const int gk = NWAVES / gn;
       const int an = (ntn + gn - 1) / gn, ak = (ntk + gk - 1) / gk;
-      if (an > 4 || ak > 4) continue;
+      if (an > 4 || ak > 4 || an * ak > 8) continue;   // <= 128 accumulator registers per wave
       const int cost = an * ak * 16 + an + ak;
       if (cost < best_cost) { best_cost = cost; best_gk = gk; best_an = an; best_ak = ak; }
     }
@@ -290,7 +290,7 @@ int cn_wgrad_launch(const NetGeom& g, const float* stash, const float* G, int64_
                         (int)lds_bytes);
     attr_set = true;
   }
-  hipLaunchKernelGGL(wgrad_k, dim3(nsplit, nj), dim3(256), lds_bytes, st, a);
+  hipLaunchKernelGGL(wgrad_k, dim3(nsplit, nj), dim3(64 * NWAVES), lds_bytes, st, a);
   CN_CHECK_LAUNCH();
   r.partials = partials; r.pstride = pstride; r.nsplit = nsplit; r.accumulate = accumulate;
   hipLaunchKernelGGL(wgrad_reduce_k, dim3(32, nt), dim3(256), 0, st, r);
