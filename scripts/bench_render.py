@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Inference / precompute side benches on the GPU box (not the headline metric):
+  * BASELINE config C5: one full-res LLFF frame (756x1008, NDC, 64+128 samples, D=8/W=256) through render();
+  * hard-mask precompute (V:994-1046) at DTU size (3 views of 512x640 -> 6 (target, reference) pairs).
+usage: python scripts/bench_render.py [frames]"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import _inputs as I  # noqa: E402
+from consistentnerf_amd import run_nerf as R, run_nerf_view as V  # noqa: E402
+
+
+def main():
+    frames = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    dev = torch.device("cuda:0")
+    H, W, focal = 756, 1008, 815.0
+    args = argparse.Namespace(
+        multires=10, i_embed=0, use_viewdirs=True, multires_views=4, N_importance=128, netdepth=8, netwidth=256,
+        netdepth_fine=8, netwidth_fine=256, netchunk=1024 * 64, lrate=5e-4, basedir=tempfile.mkdtemp(), expname="r",
+        ft_path=None, no_reload=True, perturb=1.0, N_samples=64, white_bkgd=False, raw_noise_std=1.0,
+        dataset_type="llff", no_ndc=False, lindisp=False)
+    torch.manual_seed(0)
+    _, kw_test, *_ = R.create_nerf(args)
+    kw_test.update(near=0.0, far=1.0)
+    K = I.intrinsics(H, W, focal)
+    poses = [I.camera_pose(5.0 * i, 0.0, 4.0) for i in range(frames + 1)]
+    # LLFF-style forward-facing cameras look down -z from z>0: camera_pose already does that
+    with torch.no_grad():
+        R.render(H, W, K, chunk=32768, c2w=torch.from_numpy(poses[0]), **kw_test)   # warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for c2w in poses[1:]:
+            rgb, disp, acc, extras = R.render(H, W, K, chunk=32768, c2w=torch.from_numpy(c2w), **kw_test)
+            rgb_host = rgb.cpu().numpy()            # render_path does the D2H per frame (R:158)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / frames
+    rays = H * W
+    out = {"render_frame_s": dt, "rays_per_s": rays / dt, "ray_samples_per_s": rays * 256 / dt,
+           "fwd_tflops": rays * 256 * 2 * 593408 / dt / 1e12, "frame": f"{H}x{W}, NDC, chunk 32768, 64+128 samples",
+           "finite": bool(np.isfinite(rgb_host).all())}
+    # hard masks at DTU size
+    Hd, Wd = 512, 640
+    Kd = I.intrinsics(Hd, Wd, 1446.0)
+    pd = [I.camera_pose(th, -20.0, 3.0) for th in (0.0, 25.0, -25.0)]
+    depths = np.stack([I.analytic_scene(Hd, Wd, Kd, p)[0] for p in pd])
+    V.compute_hard_masks(Hd, Wd, Kd, np.stack(pd), depths, [0, 1, 2], device=dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    masks = V.compute_hard_masks(Hd, Wd, Kd, np.stack(pd), depths, [0, 1, 2], device=dev)
+    torch.cuda.synchronize()
+    out["hard_masks_3views_512x640_s"] = time.perf_counter() - t0
+    out["hard_mask_fraction"] = float(masks.mean())
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
