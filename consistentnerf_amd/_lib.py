@@ -39,6 +39,7 @@ SIGNATURES = {
     "cnerf_embed": (_i, [_vp, _i64, _i, _vp, _vp]),
     "cnerf_mlp_stash_floats": (_i64, [_NetP, _i64]),
     "cnerf_mlp_fwd": (_i, [_NetP, _vp, _vp, _vp, _i, _vp, _vp, _i64, _i, _vp, _vp, _vp]),
+    "cnerf_mlp_fwd_embedded": (_i, [_NetP, _vp, _vp, _i64, _vp, _vp, _vp]),
     "cnerf_mlp_bwd_ws_floats": (_i64, [_NetP, _i64]),
     "cnerf_mlp_bwd": (_i, [_NetP, _vp, _vp, _i64, _i, _vp, _vp, _PtrsP, _i, _vp]),
     "cnerf_mlp_dgrad": (_i, [_NetP, _vp, _vp, _i64, _i, _vp, _vp, _vp]),

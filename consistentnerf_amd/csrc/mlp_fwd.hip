@@ -27,6 +27,7 @@ struct FwdArgs {
   const float* rays;
   const float* dirs;
   const float* z;
+  const float* emb;   // pre-embedded inputs [M, in_ch + dir_ch] (NeRF.forward surface) or nullptr
   float* raw;
   float* stash;
   int64_t M, Mp;
@@ -40,11 +41,15 @@ struct FwdArgs {
 // row + block column (training) or nullptr.
 template <int W>
 __device__ __forceinline__ void encode(float* Hs, const float (&x)[3], int L, int ch, int chp, int w, int m, int hh,
-                                       float* __restrict__ srow, bool valid) {
+                                       float* __restrict__ srow, bool valid, const float* __restrict__ pre = nullptr) {
   auto put = [&](int k, float v) {
     Hs[hs_off<W>(m, k >> 2) + (k & 3)] = v;
     if (srow != nullptr) srow[k] = valid ? v : 0.f;
   };
+  if (pre != nullptr) {   // NeRF.forward(x) on an already-embedded batch (H:107-109): copy this point's channels
+    for (int k = 2 * w + hh; k < chp; k += 4) put(k, k < ch ? pre[k] : 0.f);
+    return;
+  }
   if (w == 0 && hh == 0) {
     put(0, x[0]); put(1, x[1]); put(2, x[2]);
   }
@@ -78,8 +83,10 @@ __global__ __launch_bounds__(128, 2) void mlp_fwd_k(FwdArgs a) {
   const float* pk = a.packed;
   const int t0 = w * NTW;
 
-  float x[3];
-  if (a.pts != nullptr) {
+  float x[3] = {0.f, 0.f, 0.f};
+  const float* const pre = a.emb != nullptr ? a.emb + pc * (g.in_ch + g.dir_ch) : nullptr;
+  if (pre != nullptr) {
+  } else if (a.pts != nullptr) {
     x[0] = a.pts[pc * 3 + 0]; x[1] = a.pts[pc * 3 + 1]; x[2] = a.pts[pc * 3 + 2];
   } else {
     const float* r = a.rays + ray * a.rs;
@@ -90,7 +97,7 @@ __global__ __launch_bounds__(128, 2) void mlp_fwd_k(FwdArgs a) {
   float* const srow = a.stash != nullptr ? a.stash + p * g.s_rows : nullptr;
   float* const sp = srow != nullptr ? srow + 4 * hh : nullptr;
 
-  encode<W>(Hs, x, g.L, g.in_ch, g.in_chp, w, m, hh, srow != nullptr ? srow + g.s_enc : nullptr, valid);
+  encode<W>(Hs, x, g.L, g.in_ch, g.in_chp, w, m, hh, srow != nullptr ? srow + g.s_enc : nullptr, valid, pre);
   __syncthreads();
 
   // Per layer: GEMM -> [queue the next panel's first A groups] -> barrier (tile fully read) -> park (ReLU, LDS,
@@ -166,12 +173,13 @@ __global__ __launch_bounds__(128, 2) void mlp_fwd_k(FwdArgs a) {
     gemm_run<W, NTW, true>(acc, R, pk + g.f_feat + t0 * 256, W, W / 8, Hs, m, hh);
     __syncthreads();                                 // trunk output dead
     // gamma(viewdir) overwrites the trunk tile; its share of views_linears first
-    float v[3];
-    {
+    float v[3] = {0.f, 0.f, 0.f};
+    if (pre == nullptr) {
       const float* dsrc = a.dirs != nullptr ? a.dirs + ray * 3 : a.rays + ray * a.rs + (a.rs - 3);
       v[0] = dsrc[0]; v[1] = dsrc[1]; v[2] = dsrc[2];
     }
-    encode<W>(Hs, v, g.Ld, g.dir_ch, g.dir_chp, w, m, hh, srow != nullptr ? srow + g.s_denc : nullptr, valid);
+    encode<W>(Hs, v, g.Ld, g.dir_ch, g.dir_chp, w, m, hh, srow != nullptr ? srow + g.s_denc : nullptr, valid,
+              pre != nullptr ? pre + g.in_ch : nullptr);
     __syncthreads();
     const int t0v = w * NTHW;
     const bool vact = t0v < NTH;                     // wave-uniform
@@ -237,8 +245,27 @@ extern "C" int cnerf_mlp_fwd(const cnerf_net* net, const float* packed, const fl
   if (!pts && (!rays || !z || ray_stride < 8)) return CNERF_E_ARG;
   if (a.g.viewdirs && !dirs && (!rays || ray_stride < 11)) return CNERF_E_ARG;
   if (B == 0) return CNERF_OK;
-  a.packed = packed; a.pts = pts; a.rays = rays; a.dirs = dirs; a.z = z; a.raw = raw; a.stash = stash;
+  a.packed = packed; a.pts = pts; a.rays = rays; a.dirs = dirs; a.z = z; a.emb = nullptr; a.raw = raw;
+  a.stash = stash;
   a.M = B * S; a.Mp = cn_round_up(a.M, 32); a.S = S; a.rs = ray_stride;
+  switch (a.g.NT) {
+    case 2: return launch<2>(a, cn_stream(stream));
+    case 4: return launch<4>(a, cn_stream(stream));
+    case 8: return launch<8>(a, cn_stream(stream));
+  }
+  return CNERF_E_UNSUPPORTED;
+}
+
+extern "C" int cnerf_mlp_fwd_embedded(const cnerf_net* net, const float* packed, const float* x_embedded, int64_t M,
+                                      float* raw, float* stash, void* stream) {
+  FwdArgs a;
+  int rc = cn_make_geom(net, &a.g);
+  if (rc) return rc;
+  if (!packed || !x_embedded || !raw || M < 0) return CNERF_E_ARG;
+  if (M == 0) return CNERF_OK;
+  a.packed = packed; a.pts = nullptr; a.rays = nullptr; a.dirs = nullptr; a.z = nullptr; a.emb = x_embedded;
+  a.raw = raw; a.stash = stash;
+  a.M = M; a.Mp = cn_round_up(M, 32); a.S = 1; a.rs = 0;
   switch (a.g.NT) {
     case 2: return launch<2>(a, cn_stream(stream));
     case 4: return launch<4>(a, cn_stream(stream));

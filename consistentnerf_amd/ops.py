@@ -188,6 +188,21 @@ def mlp_forward(spec: NetSpec, packed: Tensor, B: int, S: int, *, pts: Optional[
     return raw, stash
 
 
+def mlp_forward_embedded(spec: NetSpec, packed: Tensor, x: Tensor, want_stash: bool = False):
+    """NeRF.forward on pre-embedded inputs x[M, in_ch + in_ch_views]."""
+    lib, net = _lib.load(), spec.c()
+    x = _chk(x, "x")
+    M = x.shape[0]
+    raw = torch.empty(M, spec.raw_ch, device=x.device, dtype=torch.float32)
+    stash = None
+    if want_stash:
+        stash = torch.empty(lib.cnerf_mlp_stash_floats(C.byref(net), M), device=x.device, dtype=torch.float32)
+    with _timed("mlp_fwd_train" if want_stash else "mlp_fwd", M):
+        _lib.check(lib.cnerf_mlp_fwd_embedded(C.byref(net), _p(packed), _p(x), M, _p(raw), _p(stash), _stream()),
+                   "cnerf_mlp_fwd_embedded")
+    return raw, stash
+
+
 def mlp_backward(spec: NetSpec, packed: Tensor, d_raw: Tensor, B: int, S: int, stash: Tensor,
                  grads: Optional[List[Tensor]] = None, accumulate: bool = False) -> List[Tensor]:
     lib, net = _lib.load(), spec.c()

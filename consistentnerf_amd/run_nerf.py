@@ -55,11 +55,14 @@ class _MlpFn(torch.autograd.Function):
     """Fused gamma(x), gamma(d) + MLP (replaces R:37-52 + H:44-45 + H:107-130 and their autograd)."""
 
     @staticmethod
-    def forward(ctx, model, B, S, pts, rays, z, dirs, *params):
+    def forward(ctx, model, B, S, pts, rays, z, dirs, emb, *params):
         spec = model.spec()
         packed = _packed(model)
-        train = any(ctx.needs_input_grad[7:])
-        raw, stash = ops.mlp_forward(spec, packed, B, S, pts=pts, rays=rays, z=z, dirs=dirs, want_stash=train)
+        train = any(ctx.needs_input_grad[8:])
+        if emb is not None:      # NeRF.forward(x) on pre-embedded inputs
+            raw, stash = ops.mlp_forward_embedded(spec, packed, emb, want_stash=train)
+        else:
+            raw, stash = ops.mlp_forward(spec, packed, B, S, pts=pts, rays=rays, z=z, dirs=dirs, want_stash=train)
         if train:
             # the packed buffer is reused by the next pack; keep this step's copy for the backward
             ctx.spec, ctx.B, ctx.S, ctx.stash, ctx.packed = spec, B, S, stash, packed.clone()
@@ -69,7 +72,7 @@ class _MlpFn(torch.autograd.Function):
     def backward(ctx, g_raw):
         grads = ops.mlp_backward(ctx.spec, ctx.packed, g_raw.contiguous(), ctx.B, ctx.S, ctx.stash)
         ctx.stash = ctx.packed = None
-        return (None,) * 7 + tuple(grads)
+        return (None,) * 8 + tuple(grads)
 
 
 class _CompositeFn(torch.autograd.Function):
@@ -121,9 +124,9 @@ def run_network(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk=1024 * 64
     dirs = viewdirs.contiguous() if (viewdirs is not None and spec.use_viewdirs) else None
     params = fn.kernel_tensors()
     if isinstance(inputs, RayPoints):
-        return _MlpFn.apply(fn, B, S, None, inputs.rays, inputs.z_vals, dirs, *params)
+        return _MlpFn.apply(fn, B, S, None, inputs.rays, inputs.z_vals, dirs, None, *params)
     pts = inputs.reshape(-1, 3).contiguous()
-    return _MlpFn.apply(fn, B, S, pts, None, None, dirs, *params)
+    return _MlpFn.apply(fn, B, S, pts, None, None, dirs, None, *params)
 
 
 def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0, white_bkgd=False, pytest=False):

@@ -6,9 +6,9 @@ structure, backed by the HIP kernels of libcnerf_hip.so.
 
 Differences a caller can observe (by design):
   * tensors must live on an MI355X; there is no CPU execution path (CnerfError otherwise);
-  * `NeRF` parameters keep the reference names/shapes (checkpoints interchange) but the module is
-    evaluated by the fused encoding+MLP kernel through `run_nerf.run_network`; calling `model(x)` on a
-    pre-embedded [M, 90] batch is not part of the render path and raises NotImplementedError.
+  * `NeRF` parameters keep the reference names/shapes (checkpoints interchange); the module is evaluated by the
+    fused encoding+MLP kernel — through `run_nerf.run_network` on raw points (render path, encodings never
+    materialised) or through `model(x)` on a pre-embedded [M, 90] batch like the reference.
 """
 import numpy as np
 import torch
@@ -114,9 +114,15 @@ class NeRF(nn.Module):
         return ts
 
     def forward(self, x):
-        raise NotImplementedError(
-            "consistentnerf_amd.NeRF is evaluated by the fused encoding+MLP kernel: call "
-            "run_nerf.run_network(pts, viewdirs, model, embed_fn, embeddirs_fn) (R:37-52) with raw points")
+        """H:107-130 on an already-embedded batch x[..., input_ch + input_ch_views] -> [..., 4 | output_ch]
+        (differentiable w.r.t. the parameters).  The render path does not come through here: run_network feeds
+        the kernel raw points and the encodings never exist in HBM."""
+        from .run_nerf import _MlpFn
+        lead = x.shape[:-1]
+        width = self.input_ch + (self.input_ch_views if self.use_viewdirs else 0)
+        x2 = x.reshape(-1, x.shape[-1])[:, :width].contiguous()
+        out = _MlpFn.apply(self, x2.shape[0], 1, None, None, None, None, x2, *self.kernel_tensors())
+        return out.reshape(*lead, out.shape[-1])
 
     def load_weights_from_keras(self, weights):
         """H:132-159."""

@@ -85,6 +85,11 @@ int64_t cnerf_mlp_stash_floats(const cnerf_net* net, int64_t M);
 int cnerf_mlp_fwd(const cnerf_net* net, const float* packed, const float* pts, const float* rays,
                   int ray_stride, const float* dirs, const float* z, int64_t B, int S, float* raw,
                   float* stash, void* stream);
+/* NeRF.forward(x) itself (H:107-130): x_embedded[M, in_ch + in_ch_views] already holds gamma(x) | gamma(d) per
+ * point (what callers of `model(embedded)` pass).  Same kernel, the encoding stage copies instead of computing;
+ * the stash (and therefore cnerf_mlp_bwd with B=M, S=1) works unchanged. */
+int cnerf_mlp_fwd_embedded(const cnerf_net* net, const float* packed, const float* x_embedded, int64_t M,
+                           float* raw, float* stash, void* stream);
 /* Backward of the above (autograd of R:37-52 / H:107-130): d_raw[M,C] -> gradients of every parameter
  * tensor.  `grads` holds device pointers laid out like `params`; accumulate!=0 adds into them.
  * workspace size = cnerf_mlp_bwd_ws_floats(net, M). */

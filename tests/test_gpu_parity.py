@@ -584,3 +584,63 @@ def test_c2_gradient_linearity(dev):
     assert (g2 - 2 * g1).abs().max().item() <= 1e-5 * s
     assert (ga - g1).abs().max().item() <= 2e-4 * s
     assert torch.isfinite(g1).all() and s > 0
+
+
+# ------------------------------------------------------------------------------------------------
+# secondary surface: NeRF.forward on pre-embedded inputs (H:107-130) and the corners of the compiled envelope
+@pytest.mark.parametrize("D,W,vd,och", [(8, 256, True, 5), (4, 128, False, 5)])
+def test_nerf_module_forward_on_embedded_inputs(dev, D, W, vd, och):
+    model, sd = make_model(D, W, vd, och, 11, dev)
+    rs = np.random.RandomState(8)
+    M = 203
+    pts = rs.uniform(-2, 2, size=(M, 3)).astype(np.float32)
+    dirs = rs.normal(size=(M, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+    xe = torch.cat([O.embed(T(pts), 10)] + ([O.embed(T(dirs), 4)] if vd else []), -1)
+    out = model(xe.to(dev))
+    sdt = O.as_tensors(sd, True)
+    ref = O.mlp_forward(sdt, xe[:, :63], xe[:, 63:] if vd else None, O.NetCfg(D, W, use_viewdirs=vd, output_ch=och))
+    check(out, ref.detach(), 3e-5 * max(1.0, float(ref.abs().max())), "NeRF.forward(embedded)")
+    G = T(rs.normal(size=tuple(ref.shape)).astype(np.float32))
+    (out * G.to(dev)).sum().backward()
+    (ref * G).sum().backward()
+    gref = {"g." + k: (p.grad if p.grad is not None else torch.zeros_like(p)).numpy() for k, p in sdt.items()}
+    check_param_grads(model, gref, "g.", "g.", rtol=5e-2, l2tol=5e-3)
+
+
+@pytest.mark.parametrize("D,W,vd,och,multires,i_embed", [(2, 64, True, 4, 10, 0), (6, 64, False, 4, 10, 0),
+                                                          (8, 256, True, 5, 0, -1), (3, 128, True, 4, 4, 0)])
+def test_envelope_corners_vs_oracle(dev, D, W, vd, och, multires, i_embed):
+    """W=64 (one view-branch tile: wave 1 idles there), D=2, D=6 (skip right before the last layer), identity
+    embedding (i_embed=-1: 3 input channels padded to 32) — forward + gradients against the CPU oracle."""
+    from consistentnerf_amd.run_nerf import run_network
+    from consistentnerf_amd.run_nerf_helpers import NeRF, get_embedder
+    L = -1 if i_embed == -1 else multires
+    Ld = -1 if i_embed == -1 else 4
+    in_ch, dir_ch = O.embed_dim(L), (O.embed_dim(Ld) if vd else 0)
+    rs = np.random.RandomState(3)
+    model = NeRF(D=D, W=W, input_ch=in_ch, output_ch=och, skips=[4], input_ch_views=dir_ch, use_viewdirs=vd)
+    with torch.no_grad():
+        for p_ in model.parameters():
+            if p_.dim() == 2:
+                b = float(np.sqrt(6.0 / p_.shape[1]))
+                p_.copy_(T(rs.uniform(-b, b, size=tuple(p_.shape)).astype(np.float32)))
+            elif p_.numel() > 1:
+                p_.copy_(T(rs.uniform(-0.1, 0.1, size=tuple(p_.shape)).astype(np.float32)))
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    model = model.to(dev)
+    B, S = 19, 11
+    pts = rs.uniform(-2, 2, size=(B, S, 3)).astype(np.float32)
+    dirs = rs.normal(size=(B, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+    e, _ = get_embedder(multires, i_embed)
+    ed = get_embedder(4, i_embed)[0] if vd else None
+    raw = run_network(T(pts, dev), T(dirs, dev) if vd else None, model, e, ed)
+    cfg = O.NetCfg(D=D, W=W, multires=L, multires_views=Ld, use_viewdirs=vd, output_ch=och)
+    ref = O.query(sd, T(pts), T(dirs) if vd else None, cfg)
+    check(raw, ref.detach(), 3e-5 * max(1.0, float(ref.abs().max())), "raw")
+    G = T(rs.normal(size=tuple(ref.shape)).astype(np.float32))
+    (raw * G.to(dev)).sum().backward()
+    (ref * G).sum().backward()
+    gref = {"g." + k: (p.grad if p.grad is not None else torch.zeros_like(p)).numpy() for k, p in sd.items()}
+    check_param_grads(model, gref, "g.", "g.", rtol=5e-2, l2tol=5e-3)
