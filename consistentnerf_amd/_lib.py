@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcnerf_hip.so")
+# CNERF_LIB_PATH: load an experiment build of the same ABI instead (kernel ablations, scripts/kvariants.sh)
+LIB_PATH = os.environ.get("CNERF_LIB_PATH") or os.path.join(_HERE, "libcnerf_hip.so")
 MAX_TENSORS = 48
 
 

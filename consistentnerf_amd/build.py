@@ -10,8 +10,11 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(CSRC, "build")
-LIB = os.path.join(HERE, "libcnerf_hip.so")
+# CN_BUILD_TAG=<name> builds an experiment variant (with CN_EXTRA_FLAGS) next to the product library; a variant is
+# only ever loaded when CNERF_LIB_PATH points at it (scripts/kvariants.sh).
+TAG = os.environ.get("CN_BUILD_TAG", "")
+OBJ = os.path.join(CSRC, "build" + ("_" + TAG if TAG else ""))
+LIB = os.path.join(HERE, "libcnerf_hip.so") if not TAG else os.path.join(ROOT, "variants", f"libcnerf_{TAG}.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: the reference composes separately-rounded ATen ops; FMA contraction would change
 # sample positions / encodings by an ulp that 2^9-frequency encodings amplify.  MFMA code is unaffected.
@@ -32,6 +35,7 @@ def _stale(out, deps):
 
 def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
     headers.append(os.path.join(ROOT, "include", "cnerf.h"))
     jobs = []

@@ -7,6 +7,7 @@
 //   3. a fixed-order reduction of the split partials into the parameter gradients (deterministic).
 // ReLU masks are re-derived from the forward stash (H > 0  <=>  pre-activation > 0).
 #include "mlp_common.hpp"
+#include "timing.hpp"
 
 int cn_wgrad_launch(const NetGeom& g, const float* stash, const float* G, int64_t M, int64_t Mp, float* partials,
                     int nsplit, const cnerf_ptrs* grads, int accumulate, hipStream_t st);
@@ -37,6 +38,21 @@ __device__ __forceinline__ void load_rows(f32x16 (&h)[NTO], const float* __restr
       for (int j = 0; j < 4; ++j) h[t][4 * q + j] = v[j];
     }
 }
+
+// The same loads as a `side` functor of gemm_pipe (one 16-byte load behind an MFMA each): slot i -> tile i/4, quad i%4.
+template <int NTO>
+struct RowLoader {
+  f32x16 (&h)[NTO];
+  const float* __restrict__ src;   // sp + col
+  __device__ __forceinline__ void operator()(int i) const {
+    const int t = i >> 2, q = i & 3;
+    if (t < NTO) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src + 32 * t + 8 * q);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) h[t][4 * q + j] = v[j];
+    }
+  }
+};
 
 // mask (H>0) and park: acc <- acc * [h > 0]; the masked gradient goes to the LDS tile (B operand of the next
 // transposed GEMM) and, straight from the registers, to this point's row of the point-major gradient workspace
@@ -75,11 +91,13 @@ __global__ __launch_bounds__(64) void mlp_dgrad_k(BwdArgs a) {
   const bool valid = p < a.M;
   const int64_t pc = valid ? p : a.M - 1;
   const float* pk = a.packed;
+  const APanel AP{make_rsrc(a.packed, (unsigned)(g.total * 4)), (m * 8 + 4 * hh) * 4};
   const float* const sp = a.stash + p * g.s_rows + 4 * hh;   // this point's stash row (+ this half's features)
   float* const gp = a.G + p * g.g_rows + 4 * hh;             // this point's gradient row (+ this half's features)
   f32x16 acc[NT];
   f32x16 hm[NT];     // prefetched stash features for the next ReLU mask
-  f32x4 a0[NT];      // prefetched first A group of the next transposed panel
+  f32x4 a0[NT], a1[NT];   // A-operand sets (even / odd K-groups) of the current / next transposed panel
+  CN_TINIT(1)
 
   if (VD) {
     const float4 d = *reinterpret_cast<const float4*>(a.d_raw + pc * 4);
@@ -103,22 +121,26 @@ __global__ __launch_bounds__(64) void mlp_dgrad_k(BwdArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) accv[t][4 * q + j] = s[j];
       }
+    CN_T(0)
     mask_park<W, NTH, true>(accv, hv, Hs, gp, g.g_hv, valid, m, hh);
     __builtin_amdgcn_wave_barrier();
-    load_a0<NT>(a0, pk + g.t_views, m, hh);
-    load_rows<NT>(hm, sp, g.s_h[g.D - 1]);
+    CN_T(3)
+    a_prefetch<NT>(a0, a1, AP, (int)g.t_views, W, g.Wh / 8 - 1);
     if (hh == 0) {
       const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
       *reinterpret_cast<float4*>(a.G + p * g.g_rows + g.g_out) = valid ? d : z4;
     }
     // views_linears^T (feature columns only; gamma(d) needs no gradient) -> dF
     zero_acc<NT>(acc);
-    gemm_seg_a0<W, NT>(acc, pk + g.t_views, W, g.Wh / 8, Hs, m, hh, a0);
+    CN_T(4)
+    gemm_pipe<W, NT, false>(acc, a0, a1, AP, (int)g.t_views, W, g.Wh / 8, Hs, m, hh);
+    a_prefetch<NT>(a0, a1, AP, (int)g.t_feat, W, W / 8 - 1);
     __builtin_amdgcn_wave_barrier();
+    CN_T(2)
     mask_park<W, NT, false>(acc, hm, Hs, gp, g.g_feat, valid, m, hh);
     __builtin_amdgcn_wave_barrier();
+    CN_T(3)
     // feature_linear^T . dF  +  alpha_linear^T . dsigma, masked by the last trunk ReLU -> dZ_{D-1}
-    load_a0<NT>(a0, pk + g.t_feat, m, hh);
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -127,7 +149,10 @@ __global__ __launch_bounds__(64) void mlp_dgrad_k(BwdArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[t][4 * q + j] = w[j] * dc[3];
       }
-    gemm_seg_a0<W, NT>(acc, pk + g.t_feat, W, W / 8, Hs, m, hh, a0);
+    CN_T(4)
+    gemm_pipe<W, NT, false>(acc, a0, a1, AP, (int)g.t_feat, W, W / 8, Hs, m, hh,
+                            RowLoader<NT>{hm, sp + g.s_h[g.D - 1]});
+    CN_T(2)
   } else {
     load_rows<NT>(hm, sp, g.s_h[g.D - 1]);
     float dc[8];
@@ -153,19 +178,26 @@ __global__ __launch_bounds__(64) void mlp_dgrad_k(BwdArgs a) {
     if (hh == 0)
       for (int c = 0; c < g.out_ch; ++c) a.G[p * g.g_rows + g.g_out + c] = valid ? dc[c] : 0.f;
   }
+  if (g.D > 1) a_prefetch<NT>(a0, a1, AP, (int)g.t_trunk[g.D - 1], W, W / 8 - 1);
   __builtin_amdgcn_wave_barrier();
+  CN_T(0)
   mask_park<W, NT, true>(acc, hm, Hs, gp, g.g_z[g.D - 1], valid, m, hh);
   __builtin_amdgcn_wave_barrier();
+  CN_T(3)
   // trunk: dZ_{l-1} = relu'(.) * W_l^T dZ_l   (the gamma(x) columns of the skip layer get no gradient)
   for (int l = g.D - 1; l >= 1; --l) {
-    load_a0<NT>(a0, pk + g.t_trunk[l], m, hh);
-    load_rows<NT>(hm, sp, g.s_h[l - 1]);
     zero_acc<NT>(acc);
-    gemm_seg_a0<W, NT>(acc, pk + g.t_trunk[l], W, W / 8, Hs, m, hh, a0);
+    CN_T(4)
+    gemm_pipe<W, NT, false>(acc, a0, a1, AP, (int)g.t_trunk[l], W, W / 8, Hs, m, hh,
+                            RowLoader<NT>{hm, sp + g.s_h[l - 1]});
+    if (l > 1) a_prefetch<NT>(a0, a1, AP, (int)g.t_trunk[l - 1], W, W / 8 - 1);
     __builtin_amdgcn_wave_barrier();
+    CN_T(2)
     mask_park<W, NT, true>(acc, hm, Hs, gp, g.g_z[l - 1], valid, m, hh);
     __builtin_amdgcn_wave_barrier();
+    CN_T(3)
   }
+  CN_TEND
 }
 
 template <int NT>
@@ -179,6 +211,10 @@ int launch(const BwdArgs& a, hipStream_t st) {
 }
 
 }  // namespace
+
+#ifdef CN_TIMING
+CN_TIMING_ACCESSOR(cnerf_debug_timing_bwd)
+#endif
 
 extern "C" int64_t cnerf_mlp_bwd_ws_floats(const cnerf_net* net, int64_t M) {
   NetGeom g;

@@ -18,6 +18,8 @@
 // D=8/W=256 incl. K padding).
 #include "mlp_common.hpp"
 
+#include "timing.hpp"
+
 namespace {
 
 struct FwdArgs {
@@ -83,6 +85,7 @@ __global__ __launch_bounds__(128, 2) void mlp_fwd_k(FwdArgs a) {
   const float* pk = a.packed;
   const int t0 = w * NTW;
 
+  CN_TINIT(2)
   float x[3] = {0.f, 0.f, 0.f};
   const float* const pre = a.emb != nullptr ? a.emb + pc * (g.in_ch + g.dir_ch) : nullptr;
   if (pre != nullptr) {
@@ -98,7 +101,9 @@ __global__ __launch_bounds__(128, 2) void mlp_fwd_k(FwdArgs a) {
   float* const sp = srow != nullptr ? srow + 4 * hh : nullptr;
 
   encode<W>(Hs, x, g.L, g.in_ch, g.in_chp, w, m, hh, srow != nullptr ? srow + g.s_enc : nullptr, valid, pre);
+  CN_T(0)
   __syncthreads();
+  CN_T(1)
 
   // Per layer: GEMM -> [queue the next panel's first A groups] -> barrier (tile fully read) -> park (ReLU, LDS,
   // stash) -> barrier -> next GEMM.  Biases ride on the panels (gemm_run<BIAS>), accumulators start at zero.
@@ -107,30 +112,44 @@ __global__ __launch_bounds__(128, 2) void mlp_fwd_k(FwdArgs a) {
   Ring<NTW> R;
   zero_acc<NTW>(acc);
   gemm_seg<W, NTW, true>(acc, pk + g.f_l0 + t0 * 256, W, g.in_chp / 8, Hs, m, hh);
+#if !(defined(CN_EXP) && (CN_EXP & 8))   // ablation: no skip partial (wrong results, frees 64 registers)
   if (g.skip >= 0) {
     zero_acc<NTW>(accs);
     gemm_seg<W, NTW, true>(accs, pk + g.f_skip + t0 * 256, W, g.in_chp / 8, Hs, m, hh);
   }
+#endif
+  CN_T(2)
   for (int l = 1; l < g.D; ++l) {
     const bool sk = l == g.skip + 1;
     const float* panel = pk + g.f_trunk[l] + t0 * 256;
     ring_start<NTW>(R, panel, W, sk ? W / 8 - 1 : W / 8, m, hh);
     __syncthreads();                                 // both waves finished reading the tile
+    CN_T(1)
     park<W, NTW, true>(acc, Hs, true, t0, m, hh, sp, g.s_h[l - 1], valid);
+    CN_T(3)
     __syncthreads();
+    CN_T(1)
     if (sk) {
+#if defined(CN_EXP) && (CN_EXP & 8)
+      zero_acc<NTW>(acc);
+#else
 #pragma unroll
       for (int t = 0; t < NTW; ++t) acc[t] = accs[t];
+#endif
       gemm_run<W, NTW, false>(acc, R, panel, W, W / 8, Hs, m, hh);
     } else {
       zero_acc<NTW>(acc);
       gemm_run<W, NTW, true>(acc, R, panel, W, W / 8, Hs, m, hh);
     }
+    CN_T(2)
   }
   if (VD) ring_start<NTW>(R, pk + g.f_feat + t0 * 256, W, W / 8, m, hh);
   __syncthreads();
+  CN_T(1)
   park<W, NTW, true>(acc, Hs, true, t0, m, hh, sp, g.s_h[g.D - 1], valid);
+  CN_T(3)
   __syncthreads();
+  CN_T(1)
 
   if (!VD) {
     // output_linear (H:127-128) on the VALU of wave 0: out[c] = b[c] + sum_k Wo[c][k] h[k]; each half-wave sums
@@ -154,6 +173,8 @@ __global__ __launch_bounds__(128, 2) void mlp_fwd_k(FwdArgs a) {
       if (valid && hh == 0)
         for (int c = 0; c < g.out_ch; ++c) a.raw[p * g.out_ch + c] = o[c] + pk[g.b_out + c];
     }
+    CN_T(4)
+    CN_TEND
     return;
   } else {
     // sigma head (alpha_linear, H:117) on the VALU of wave 0 while the trunk output is in LDS
@@ -168,10 +189,13 @@ __global__ __launch_bounds__(128, 2) void mlp_fwd_k(FwdArgs a) {
       sig += __shfl_xor(sig, 32, 64);
       sig += pk[g.b_alpha];
     }
+    CN_T(4)
     // feature_linear (H:118), no activation
     zero_acc<NTW>(acc);
     gemm_run<W, NTW, true>(acc, R, pk + g.f_feat + t0 * 256, W, W / 8, Hs, m, hh);
+    CN_T(2)
     __syncthreads();                                 // trunk output dead
+    CN_T(1)
     // gamma(viewdir) overwrites the trunk tile; its share of views_linears first
     float v[3] = {0.f, 0.f, 0.f};
     if (pre == nullptr) {
@@ -180,7 +204,9 @@ __global__ __launch_bounds__(128, 2) void mlp_fwd_k(FwdArgs a) {
     }
     encode<W>(Hs, v, g.Ld, g.dir_ch, g.dir_chp, w, m, hh, srow != nullptr ? srow + g.s_denc : nullptr, valid,
               pre != nullptr ? pre + g.in_ch : nullptr);
+    CN_T(0)
     __syncthreads();
+    CN_T(1)
     const int t0v = w * NTHW;
     const bool vact = t0v < NTH;                     // wave-uniform
     f32x16 accv[NTHW];
@@ -188,12 +214,17 @@ __global__ __launch_bounds__(128, 2) void mlp_fwd_k(FwdArgs a) {
       zero_acc<NTHW>(accv);
       gemm_seg<W, NTHW, true>(accv, pk + g.f_viewsd + t0v * 256, g.Wh, g.dir_chp / 8, Hs, m, hh);
     }
+    CN_T(2)
     __syncthreads();                                 // gamma(d) dead
+    CN_T(1)
     park<W, NTW, false>(acc, Hs, true, t0, m, hh, sp, g.s_feat, valid);
+    CN_T(3)
     __syncthreads();
+    CN_T(1)
     float o[3] = {0.f, 0.f, 0.f};
     if (vact) {
       gemm_seg<W, NTHW, false>(accv, pk + g.f_views + t0v * 256, g.Wh, W / 8, Hs, m, hh);
+      CN_T(2)
       park<W, NTHW, true>(accv, Hs, false, t0v, m, hh, sp, g.s_hv, valid);   // ReLU in registers (+ stash)
       // rgb_linear (H:125) straight from the accumulators: lane holds n = 32t + 8q + 4hh + j
 #pragma unroll
@@ -214,12 +245,16 @@ __global__ __launch_bounds__(128, 2) void mlp_fwd_k(FwdArgs a) {
     if (w == 1 && hh == 0) {
       scratch[4 * m + 0] = o[0]; scratch[4 * m + 1] = o[1]; scratch[4 * m + 2] = o[2];
     }
+    CN_T(4)
     __syncthreads();
+    CN_T(1)
     if (w == 0 && hh == 0 && valid) {
       *reinterpret_cast<float4*>(a.raw + p * 4) =
           make_float4(o[0] + scratch[4 * m + 0] + pk[g.b_rgb + 0], o[1] + scratch[4 * m + 1] + pk[g.b_rgb + 1],
                       o[2] + scratch[4 * m + 2] + pk[g.b_rgb + 2], sig);
     }
+    CN_T(4)
+    CN_TEND
   }
 }
 
@@ -234,6 +269,10 @@ int launch(const FwdArgs& a, hipStream_t st) {
 }
 
 }  // namespace
+
+#ifdef CN_TIMING
+CN_TIMING_ACCESSOR(cnerf_debug_timing)
+#endif
 
 extern "C" int cnerf_mlp_fwd(const cnerf_net* net, const float* packed, const float* pts, const float* rays,
                              int ray_stride, const float* dirs, const float* z, int64_t B, int S, float* raw,
