@@ -56,6 +56,14 @@ int cn_make_geom(const cnerf_net* net, NetGeom* g) {
     g->s_denc = r; r += g->dir_chp;
     g->s_hv = r; r += g->Wh;
   }
+  {
+    const int md = (g->NT + 1) / 2, mdv = (g->NT / 2 + 1) / 2;   // dwords per half-wave: trunk layer / view branch
+    int o = 0;
+    for (int l = 0; l < g->D; ++l) { g->s_mb[l] = o; o += 2 * md; }
+    g->s_mb[g->D] = o;
+    if (g->viewdirs) o += 2 * mdv;
+    g->s_mask = r; r += (int)cn_round_up(o, 4);
+  }
   g->s_rows = r;
   r = 0;
   for (int l = 0; l < g->D; ++l) { g->g_z[l] = r; r += g->W; }
@@ -147,13 +155,14 @@ struct PackJob {
   int groups;         // number of 8-wide groups along the contracted index
   int64_t dst;
   const float* bias;  // JOB_PANEL only: extra group `groups` with P[groups][n][0] = bias[n] (the bias MFMA step)
+  int zero_bias;      // JOB_PANEL with bias == nullptr: still write the extra group, as zeros
 };
 constexpr int MAX_JOBS = 56;
 struct PackArgs { PackJob job[MAX_JOBS]; float* packed; };
 
 __global__ void pack_k(PackArgs a) {
   const PackJob j = a.job[blockIdx.y];
-  const int ngroups = j.groups + (j.mode == JOB_PANEL && j.bias != nullptr ? 1 : 0);
+  const int ngroups = j.groups + (j.mode == JOB_PANEL && (j.bias != nullptr || j.zero_bias) ? 1 : 0);
   const int64_t n = j.mode == JOB_COPY ? (int64_t)j.N * j.K : (int64_t)ngroups * j.rows_p * 8;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     float v = 0.f;
@@ -166,7 +175,7 @@ __global__ void pack_k(PackArgs a) {
       const int grp = (int)((i >> 3) / j.rows_p);
       if (j.mode == JOB_PANEL) {          // P[kg][n][e] = W[n][col0 + 8kg + e]
         const int k = 8 * grp + e;
-        if (grp == j.groups) { if (e == 0 && row < j.N) v = j.bias[row]; }
+        if (grp == j.groups) { if (e == 0 && row < j.N && j.bias != nullptr) v = j.bias[row]; }
         else if (row < j.N && k < j.K) v = j.src[(int64_t)row * j.ld + j.col0 + k];
       } else {                            // PT[ng][k][e] = W[8ng + e][col0 + k]
         const int nn = 8 * grp + e;
@@ -192,16 +201,17 @@ extern "C" int cnerf_pack_weights(const cnerf_net* net, const cnerf_ptrs* params
   int nj = 0;
   const int W = g.W, Wh = g.Wh, D = g.D;
   // contracted width padded to a multiple of 32 (4 groups: the depth of the A-operand prefetch ring)
-  auto panel = [&](const float* src, int ld, int col0, int N, int K, int64_t dst, const float* bias = nullptr) {
+  auto panel = [&](const float* src, int ld, int col0, int N, int K, int64_t dst, const float* bias = nullptr,
+                   int zero_bias = 0) {
     a.job[nj++] = PackJob{src, ld, col0, N, K, JOB_PANEL, (int)cn_round_up(N, 32), (int)cn_round_up(K, 32) / 8, dst,
-                          bias};
+                          bias, zero_bias};
   };
   auto panel_t = [&](const float* src, int ld, int col0, int N, int K, int64_t dst) {
     a.job[nj++] = PackJob{src, ld, col0, N, K, JOB_PANEL_T, (int)cn_round_up(K, 32), (int)cn_div_up(N, 8), dst,
-                          nullptr};
+                          nullptr, 0};
   };
   auto copy = [&](const float* src, int N, int K, int64_t dst) {
-    a.job[nj++] = PackJob{src, K, 0, N, K, JOB_COPY, 0, 0, dst, nullptr};
+    a.job[nj++] = PackJob{src, K, 0, N, K, JOB_COPY, 0, 0, dst, nullptr, 0};
   };
   auto Wt = [&](int l) { return params->p[2 * l]; };
   auto Bt = [&](int l) { return params->p[2 * l + 1]; };
@@ -209,7 +219,7 @@ extern "C" int cnerf_pack_weights(const cnerf_net* net, const cnerf_ptrs* params
   for (int l = 1; l < D; ++l) {
     const bool sk = g.skip >= 0 && l == g.skip + 1;
     const int ld = sk ? W + g.in_ch : W, c0 = sk ? g.in_ch : 0;
-    panel(Wt(l), ld, c0, W, W, g.f_trunk[l], sk ? nullptr : Bt(l));   // skip layer: bias rides on f_skip
+    panel(Wt(l), ld, c0, W, W, g.f_trunk[l], sk ? nullptr : Bt(l), 1);   // skip layer: bias rides on f_skip (zeros here)
     panel_t(Wt(l), ld, c0, W, W, g.t_trunk[l]);
     if (sk) panel(Wt(l), ld, 0, W, g.in_ch, g.f_skip, Bt(l));
   }

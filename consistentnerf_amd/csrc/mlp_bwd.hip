@@ -1,11 +1,12 @@
 // Backward of the fused encoding+MLP (autograd of run_network R:37-52 / NeRF.forward H:107-130).
 // Three launches:
 //   1. dgrad (this file): one wave64 per 32 points walks the network backwards with the TRANSPOSED weight
-//      panels as the MFMA A operand and the gradient tile in LDS as B; it writes the gradient w.r.t. every
-//      layer's pre-activation, dZ_l, into the point-major gradient workspace G[Mp][g_rows].
+//      panels as the MFMA A operand and the previous gradient's accumulator registers as B (mlp_common.hpp: no
+//      LDS, no barriers); it writes the gradient w.r.t. every layer's pre-activation, dZ_l, into the point-major
+//      gradient workspace G[Mp][g_rows].
 //   2. wgrad (wgrad.hip): NT GEMMs contracted over points, dW_l = dZ_l^T . H_{l-1}, split over point ranges.
 //   3. a fixed-order reduction of the split partials into the parameter gradients (deterministic).
-// ReLU masks are re-derived from the forward stash (H > 0  <=>  pre-activation > 0).
+// ReLU masks come from the sign-bit words the forward packed into the stash (1 bit per hidden unit, s_mask).
 #include "mlp_common.hpp"
 #include "timing.hpp"
 
@@ -25,187 +26,136 @@ struct BwdArgs {
   int64_t M, Mp;
 };
 
-// Prefetch the stash block whose ReLU decides the mask (C-layout features of this lane = 4*NTO dwordx4 loads off
-// the point's stash row); issued BEFORE the GEMM that produces the gradient so the HBM latency hides under it.
-template <int NTO>
-__device__ __forceinline__ void load_rows(f32x16 (&h)[NTO], const float* __restrict__ sp, int col) {
-#pragma unroll
-  for (int t = 0; t < NTO; ++t)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(sp + col + 32 * t + 8 * q);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) h[t][4 * q + j] = v[j];
-    }
-}
-
-// The same loads as a `side` functor of gemm_pipe (one 16-byte load behind an MFMA each): slot i -> tile i/4, quad i%4.
-template <int NTO>
-struct RowLoader {
-  f32x16 (&h)[NTO];
-  const float* __restrict__ src;   // sp + col
-  __device__ __forceinline__ void operator()(int i) const {
-    const int t = i >> 2, q = i & 3;
-    if (t < NTO) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(src + 32 * t + 8 * q);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) h[t][4 * q + j] = v[j];
-    }
-  }
-};
-
-// mask (H>0) and park: acc <- acc * [h > 0]; the masked gradient goes to the LDS tile (B operand of the next
-// transposed GEMM) and, straight from the registers, to this point's row of the point-major gradient workspace
-// (`gp` = row + 4*hh, block column `col`): one 16-byte store per 4 consecutive features.  (Measured: routing the
-// stores through the LDS tile for 1 KiB-coalesced writes is SLOWER here — the ds_read -> store chain is exposed
-// latency on a one-wave-per-SIMD kernel, while L2 write-combines the 32-byte lane-pair pieces anyway.)
-// Padding points store zeros.
-template <int W, int NTO, bool MASK>
-__device__ __forceinline__ void mask_park(f32x16 (&acc)[NTO], const f32x16 (&h)[NTO], float* Hs,
-                                          float* __restrict__ gp, int col, bool valid, int m, int hh) {
-#pragma unroll
-  for (int t = 0; t < NTO; ++t)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      f32x4 v;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float x = acc[t][4 * q + j];
-        if (MASK) x = h[t][4 * q + j] > 0.f ? x : 0.f;
-        v[j] = x;
-      }
-      *reinterpret_cast<f32x4*>(Hs + hs_off<W>(m, 8 * t + 2 * q + hh)) = v;
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      *reinterpret_cast<f32x4*>(gp + col + 32 * t + 8 * q) = valid ? v : z;
-    }
-}
-
 template <int NT, bool VD>
 __global__ __launch_bounds__(64) void mlp_dgrad_k(BwdArgs a) {
   constexpr int W = NT * 32;
   constexpr int NTH = NT / 2 > 0 ? NT / 2 : 1;
-  extern __shared__ __attribute__((aligned(16))) float Hs[];
+  constexpr int MD = (NT + 1) / 2, MDV = (NTH + 1) / 2;
   const NetGeom& g = a.g;
   const int lane = threadIdx.x, m = lane & 31, hh = lane >> 5;
-  const int64_t p = (int64_t)blockIdx.x * 32 + m;
-  const bool valid = p < a.M;
-  const int64_t pc = valid ? p : a.M - 1;
-  const float* pk = a.packed;
-  const APanel AP{make_rsrc(a.packed, (unsigned)(g.total * 4)), (m * 8 + 4 * hh) * 4};
-  const float* const sp = a.stash + p * g.s_rows + 4 * hh;   // this point's stash row (+ this half's features)
-  float* const gp = a.G + p * g.g_rows + 4 * hh;             // this point's gradient row (+ this half's features)
-  f32x16 acc[NT];
-  f32x16 hm[NT];     // prefetched stash features for the next ReLU mask
-  f32x4 a0[NT], a1[NT];   // A-operand sets (even / odd K-groups) of the current / next transposed panel
+  const int64_t p0 = (int64_t)blockIdx.x * 32;
+  const int64_t p = p0 + m;
+  const int nvalid = a.M - p0 < 32 ? (int)(a.M - p0) : 32;
+  const int64_t pc = p < a.M ? p : a.M - 1;
   CN_TINIT(1)
+  const APanel AP{make_rsrc(a.packed, (unsigned)(g.total * 4)), (m * 8 + 4 * hh) * 4};
+  // this workgroup's 32 stash rows (sign bits) and 32 gradient rows; rows of padding points are out of range:
+  // their bits read as 0 and their stores are dropped (the launcher zero-fills those rows of G for the wgrad DMA)
+  const rsrc_t srs = make_rsrc(a.stash + p0 * g.s_rows, (unsigned)(nvalid * g.s_rows * 4));
+  const rsrc_t grs = make_rsrc(a.G + p0 * g.g_rows, (unsigned)(nvalid * g.g_rows * 4));
+  const int gvo = (m * g.g_rows + 4 * hh) * 4;
+  const int smo = (m * g.s_rows + hh * MD) * 4;
+  f32x16 X[NT], Y[NT];
+  f32x4 a0[NT], a1[NT];   // A-operand sets (even / odd K-groups) of the current transposed panel
+  unsigned bits[MD];
 
   if (VD) {
     const float4 d = *reinterpret_cast<const float4*>(a.d_raw + pc * 4);
     const float dc[4] = {d.x, d.y, d.z, d.w};
+    unsigned bv[MDV];
+    load_bits<MDV>(srs, (m * g.s_rows + hh * MDV) * 4, (g.s_mask + g.s_mb[g.D]) * 4, bv);
+    a_prefetch<NT>(a0, a1, AP, (int)g.t_views, W, g.Wh / 8 - 1);
+    if (hh == 0) buf_store(grs, m * g.g_rows * 4, g.g_out * 4, f32x4{d.x, d.y, d.z, d.w});
     // rgb_linear^T on the VALU, masked by the view-branch ReLU -> dZv (C-layout registers)
-    f32x16 accv[NTH];
-    f32x16 hv[NTH];
-    load_rows<NTH>(hv, sp, g.s_hv);
+    f32x16 V[NTH];
 #pragma unroll
     for (int t = 0; t < NTH; ++t)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int n0 = 32 * t + 8 * q + 4 * hh;
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          const f32x4 w = *reinterpret_cast<const f32x4*>(pk + g.v_rgb + (int64_t)c * g.Wh + n0);
+          const f32x4 w = buf_load(AP.rs, hh * 16, (int)(g.v_rgb + (int64_t)c * g.Wh + 32 * t + 8 * q) * 4);
 #pragma unroll
           for (int j = 0; j < 4; ++j) s[j] += w[j] * dc[c];
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) accv[t][4 * q + j] = s[j];
+        for (int j = 0; j < 4; ++j) V[t][4 * q + j] = s[j];
       }
+    mask_bits<NTH>(V, bv);
     CN_T(0)
-    mask_park<W, NTH, true>(accv, hv, Hs, gp, g.g_hv, valid, m, hh);
-    __builtin_amdgcn_wave_barrier();
-    CN_T(3)
-    a_prefetch<NT>(a0, a1, AP, (int)g.t_views, W, g.Wh / 8 - 1);
-    if (hh == 0) {
-      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      *reinterpret_cast<float4*>(a.G + p * g.g_rows + g.g_out) = valid ? d : z4;
-    }
-    // views_linears^T (feature columns only; gamma(d) needs no gradient) -> dF
-    zero_acc<NT>(acc);
-    CN_T(4)
-    gemm_pipe<W, NT, false>(acc, a0, a1, AP, (int)g.t_views, W, g.Wh / 8, Hs, m, hh);
-    a_prefetch<NT>(a0, a1, AP, (int)g.t_feat, W, W / 8 - 1);
-    __builtin_amdgcn_wave_barrier();
+    // dF = views_linears^T (feature columns only; gamma(d) needs no gradient) . dZv, no mask (feature_linear is linear)
+    gemm_reg<NTH, NT, false, true>(X, V, a0, a1, AP, (int)g.t_views, W, hh, TileStores<NTH, NT>{V, grs, gvo, g.g_hv * 4});
+    pin<NT>(X);
     CN_T(2)
-    mask_park<W, NT, false>(acc, hm, Hs, gp, g.g_feat, valid, m, hh);
-    __builtin_amdgcn_wave_barrier();
-    CN_T(3)
-    // feature_linear^T . dF  +  alpha_linear^T . dsigma, masked by the last trunk ReLU -> dZ_{D-1}
+    // dZ_{D-1} = relu'(h_{D-1}) * (feature_linear^T . dF + alpha_linear^T . dsigma)
+    a_prefetch<NT>(a0, a1, AP, (int)g.t_feat, W, W / 8 - 1);
+    load_bits<MD>(srs, smo, (g.s_mask + g.s_mb[g.D - 1]) * 4, bits);
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const f32x4 w = *reinterpret_cast<const f32x4*>(pk + g.v_alpha + 32 * t + 8 * q + 4 * hh);
+        const f32x4 w = buf_load(AP.rs, hh * 16, (int)(g.v_alpha + 32 * t + 8 * q) * 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[t][4 * q + j] = w[j] * dc[3];
+        for (int j = 0; j < 4; ++j) Y[t][4 * q + j] = w[j] * dc[3];
       }
     CN_T(4)
-    gemm_pipe<W, NT, false>(acc, a0, a1, AP, (int)g.t_feat, W, W / 8, Hs, m, hh,
-                            RowLoader<NT>{hm, sp + g.s_h[g.D - 1]});
+    gemm_reg<NT, NT, false, false>(Y, X, a0, a1, AP, (int)g.t_feat, W, hh, TileStores<NT, NT>{X, grs, gvo, g.g_feat * 4});
     CN_T(2)
   } else {
-    load_rows<NT>(hm, sp, g.s_h[g.D - 1]);
+    load_bits<MD>(srs, smo, (g.s_mask + g.s_mb[g.D - 1]) * 4, bits);
     float dc[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) dc[c] = c < g.out_ch ? a.d_raw[pc * g.out_ch + c] : 0.f;
+    if (hh == 0)
+      for (int c = 0; c < g.out_ch; ++c)
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dc[c]), grs, (m * g.g_rows + c) * 4,
+                                              g.g_out * 4, 0);
     // output_linear^T on the VALU
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int n0 = 32 * t + 8 * q + 4 * hh;
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < 8; ++c)
           if (c < g.out_ch) {
-            const f32x4 w = *reinterpret_cast<const f32x4*>(pk + g.v_out + (int64_t)c * W + n0);
+            const f32x4 w = buf_load(AP.rs, hh * 16, (int)(g.v_out + (int64_t)c * W + 32 * t + 8 * q) * 4);
 #pragma unroll
             for (int j = 0; j < 4; ++j) s[j] += w[j] * dc[c];
           }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[t][4 * q + j] = s[j];
+        for (int j = 0; j < 4; ++j) Y[t][4 * q + j] = s[j];
       }
-    if (hh == 0)
-      for (int c = 0; c < g.out_ch; ++c) a.G[p * g.g_rows + g.g_out + c] = valid ? dc[c] : 0.f;
+    CN_T(0)
   }
   if (g.D > 1) a_prefetch<NT>(a0, a1, AP, (int)g.t_trunk[g.D - 1], W, W / 8 - 1);
-  __builtin_amdgcn_wave_barrier();
-  CN_T(0)
-  mask_park<W, NT, true>(acc, hm, Hs, gp, g.g_z[g.D - 1], valid, m, hh);
-  __builtin_amdgcn_wave_barrier();
+  mask_bits<NT>(Y, bits);
   CN_T(3)
-  // trunk: dZ_{l-1} = relu'(.) * W_l^T dZ_l   (the gamma(x) columns of the skip layer get no gradient)
-  for (int l = g.D - 1; l >= 1; --l) {
-    zero_acc<NT>(acc);
-    CN_T(4)
-    gemm_pipe<W, NT, false>(acc, a0, a1, AP, (int)g.t_trunk[l], W, W / 8, Hs, m, hh,
-                            RowLoader<NT>{hm, sp + g.s_h[l - 1]});
+  // trunk: dZ_{l-1} = relu'(h_{l-1}) * (W_l^T . dZ_l) (the gamma(x) columns of the skip layer get no gradient); dZ_l
+  // goes out to the workspace while it is the B operand of this GEMM.  X / Y alternate as input and output.
+  auto layer = [&](f32x16 (&In)[NT], f32x16 (&Out)[NT], int l) __attribute__((always_inline)) {
+    load_bits<MD>(srs, smo, (g.s_mask + g.s_mb[l - 1]) * 4, bits);
+    gemm_reg<NT, NT, false, true>(Out, In, a0, a1, AP, (int)g.t_trunk[l], W, hh, TileStores<NT, NT>{In, grs, gvo, g.g_z[l] * 4});
     if (l > 1) a_prefetch<NT>(a0, a1, AP, (int)g.t_trunk[l - 1], W, W / 8 - 1);
-    __builtin_amdgcn_wave_barrier();
     CN_T(2)
-    mask_park<W, NT, true>(acc, hm, Hs, gp, g.g_z[l - 1], valid, m, hh);
-    __builtin_amdgcn_wave_barrier();
+    mask_bits<NT>(Out, bits);
     CN_T(3)
+  };
+  int l = g.D - 1;
+  for (; l >= 2; l -= 2) {
+    layer(Y, X, l);
+    layer(X, Y, l - 1);
   }
+  if (l == 1) {   // (a third instance of the layer body: cheaper than keeping both sets live behind a flag)
+    layer(Y, X, 1);
+    store_tiles<NT>(X, grs, gvo, g.g_z[0] * 4);
+  } else {
+    store_tiles<NT>(Y, grs, gvo, g.g_z[0] * 4);
+  }
+  CN_T(3)
   CN_TEND
 }
 
 template <int NT>
 int launch(const BwdArgs& a, hipStream_t st) {
   const unsigned grid = (unsigned)cn_div_up(a.M, 32);
-  const size_t lds = (size_t)NT * 32 * 32 * sizeof(float);
-  if (a.g.viewdirs) hipLaunchKernelGGL((mlp_dgrad_k<NT, true>), dim3(grid), dim3(64), lds, st, a);
-  else hipLaunchKernelGGL((mlp_dgrad_k<NT, false>), dim3(grid), dim3(64), lds, st, a);
+  if (a.Mp > a.M) {   // gradient rows of the padding points: the kernel drops their stores, wgrad reads them
+    hipError_t e = hipMemsetAsync(a.G + a.M * a.g.g_rows, 0, (size_t)(a.Mp - a.M) * a.g.g_rows * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+  }
+  if (a.g.viewdirs) hipLaunchKernelGGL((mlp_dgrad_k<NT, true>), dim3(grid), dim3(64), 0, st, a);
+  else hipLaunchKernelGGL((mlp_dgrad_k<NT, false>), dim3(grid), dim3(64), 0, st, a);
   CN_CHECK_LAUNCH();
   return CNERF_OK;
 }

@@ -1,258 +1,39 @@
-// Device helpers shared by the fused MLP forward (mlp_fwd.hip) and backward (mlp_bwd.hip) kernels.
-// Data-layout contract (also modelled lane-by-lane in tests/test_layout_model.py):
-//   * a workgroup of TWO wave64 owns 32 points; every layer is computed transposed, Out^T[N x 32] = A[N x K] .
-//     B[K x 32] with v_mfma_f32_32x32x2_f32, wave w producing output tiles [w*NT/2, (w+1)*NT/2) — 4 such
-//     workgroups per CU = 2 waves per SIMD (<= 256 registers each), so one wave's layer epilogue / operand
-//     latencies hide under the other's MFMAs;
+// Device helpers shared by the fused MLP forward (mlp_fwd.hip), dgrad (mlp_bwd.hip) and wgrad (wgrad.hip) kernels.
+//
+// Execution model of the forward / dgrad kernels (modelled lane-by-lane in tests/test_layout_model.py):
+//   * ONE wave64 owns 32 points and walks them through the whole network, one wave per SIMD (up to 512 registers);
+//     every layer is computed transposed, Out^T[N x 32] = A[N x K] . B[K x 32], with v_mfma_f32_32x32x2_f32;
 //   * A = a weight panel P[K/8][Np][8] (common.hpp): lane (i = lane&31, hh = lane>>5) loads 16 bytes at
-//     ((kg*Np + 32t + i)*8 + 4hh) and feeds its 4 floats to 4 consecutive MFMAs;
-//   * B = the workgroup's LDS tile Hs[m][k] (32 points x W), 16-byte chunks XOR-swizzled with (m&15);
-//   * D = C-layout: lane (m, hh), register r <-> row 32t + 8(r>>2) + 4hh + (r&3), column m.
+//     ((kg*Np + 32t + i)*8 + 4hh) and feeds its 4 floats to MFMAs j = 0..3 of K-group kg, so MFMA (kg, j) contracts
+//     the two k's 8kg + j (half-wave 0) and 8kg + 4 + j (half-wave 1);
+//   * D = C-layout: lane (m = lane&31, hh), register r of tile t <-> feature 32t + 8(r>>2) + 4hh + (r&3), point m —
+//     which is exactly the pairing above with kg = 4t + (r>>2), j = r&3.  Hence the accumulators of one layer ARE the
+//     B operand of the next: B(kg, j) = X[kg>>2][4(kg&3) + j].  Hidden activations never leave the register file
+//     (no LDS tile, no transposes, no barriers); only gamma(x) / gamma(d) go through a small LDS tile.
+//
+// Facts the schedules below are built on (scripts/coissue_probe.hip, scripts/opcost*_probe.hip; MI355X):
+//   * v_mfma_f32_32x32x2_f32 issues every 64-66 cycles back to back; VALU instructions of ANY wave on the SIMD do
+//     NOT overlap with it (fp32 MFMA and the VALU share the datapath: 157 TFLOP/s either way), so VALU work is a
+//     straight tax on the MFMA rate and a second wave per SIMD hides nothing but memory latency;
+//   * a 16-byte-per-lane load or store addressed as SGPR base + loop-invariant VGPR offset (buffer instructions)
+//     issues for free behind an MFMA; the same access through a per-lane 64-bit pointer bumped with
+//     v_add_co/v_addc costs ~25 cycles of MFMA issue; ds_read_b128 with an immediate offset is free as well;
+//   * left alone, the machine scheduler sinks loads towards their first use (shorter live ranges) and exposes an
+//     L2 round trip per K-group — hence the sched_barriers: the order written below is the order that executes.
 #pragma once
 #include "common.hpp"
+#include "timing.hpp"
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
 
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
-
-// LDS tile addressing: point row m, 16-byte chunk c of the K axis.
-template <int W>
-__device__ __forceinline__ int hs_off(int m, int c) { return m * W + ((c ^ (m & 15)) << 2); }
-
-// ---- variant used by the one-wave-per-tile backward kernel (mlp_bwd.hip): caller-visible first group ------------
-// First A-operand group of a panel.  Issued by the caller BEFORE it queues the epilogue stores of the previous
-// layer: vmcnt retires in order (stores included), so loads queued behind 32 KiB of stash stores would make the
-// first MFMA of the next layer wait for the HBM write acknowledgements (~2-4 us per layer, measured as +20 %).
-template <int NTO>
-__device__ __forceinline__ void load_a0(f32x4 (&a0)[NTO], const float* __restrict__ panel, int m, int hh) {
-  const float* pa = panel + ((int64_t)m * 8 + 4 * hh);
-#pragma unroll
-  for (int t = 0; t < NTO; ++t) a0[t] = *reinterpret_cast<const f32x4*>(pa + (int64_t)t * 256);
-}
-
-// acc[t] += sum_k P[k-panel][32t+i] * Hs[m][k]  for KG groups of 8 k's; panel rows per group = NP; a0 = group 0
-// (load_a0).
-template <int W, int NTO>
-__device__ __forceinline__ void gemm_seg_a0(f32x16 (&acc)[NTO], const float* __restrict__ panel, int NP, int KG,
-                                         const float* Hs, int m, int hh, f32x4 (&a0)[NTO]) {
-  const float* pa = panel + ((int64_t)m * 8 + 4 * hh);
-  f32x4 a1[NTO];
-  auto ldb = [&](int kg) -> f32x4 {
-    return *reinterpret_cast<const f32x4*>(Hs + hs_off<W>(m, 2 * (kg < KG ? kg : KG - 1) + hh));
-  };
-  auto fma4 = [&](f32x4 (&r)[NTO], const f32x4& b) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int t = 0; t < NTO; ++t) acc[t] = mfma(r[t][j], b[j], acc[t]);
-  };
-  // KG is even (all contracted widths are padded to multiples of 16).  Two register sets ping-pong: the A loads
-  // and the B read of group kg+1 are issued BEFORE the 4*NTO MFMAs (64 cycles each) of group kg.  The
-  // sched_barriers pin that order — left alone, the machine scheduler sinks loads towards their first use
-  // (shorter live ranges), which exposed an L2 round trip on every second group (measured: dgrad 99 TFLOP/s).
-  // The last prefetch is clamped (re-reads a valid group) to keep the loop branch-free for vmcnt counting.
-  f32x4 b0 = ldb(0);
-  for (int kg = 0; kg < KG; kg += 2) {
-    const float* p1 = pa + (int64_t)(kg + 1) * NP * 8;
-#pragma unroll
-    for (int t = 0; t < NTO; ++t) a1[t] = *reinterpret_cast<const f32x4*>(p1 + (int64_t)t * 256);
-    const f32x4 b1 = ldb(kg + 1);
-    __builtin_amdgcn_sched_barrier(0);
-    fma4(a0, b0);
-    __builtin_amdgcn_sched_barrier(0);
-    const int k2 = kg + 2 < KG ? kg + 2 : kg;
-    const float* p2 = pa + (int64_t)k2 * NP * 8;
-#pragma unroll
-    for (int t = 0; t < NTO; ++t) a0[t] = *reinterpret_cast<const f32x4*>(p2 + (int64_t)t * 256);
-    b0 = ldb(kg + 2);
-    __builtin_amdgcn_sched_barrier(0);
-    fma4(a1, b1);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-// ---- hand-scheduled GEMM core (one wave owns the whole 32-point tile: dgrad, forward) -------------------------------
-// Facts this schedule is built on (scripts/coissue_probe.hip, MI355X):
-//   * v_mfma_f32_32x32x2_f32 issues every ~66 cycles back to back; VALU instructions of ANY wave on the SIMD do not
-//     overlap with it (fp32 MFMA and the VALU share the datapath: 157 TFLOP/s either way), so VALU work is a
-//     straight tax and memory instructions are the only thing that can hide under an MFMA;
-//   * a 16-byte-per-lane global load takes ~16 cycles to issue, so 8 of them in a row stall the in-order wave for
-//     two MFMA slots; one load behind each MFMA is free;
-//   * the machine scheduler, left alone, sinks loads towards their first use (live ranges) and exposes an L2
-//     round trip per K-group — hence the sched_barriers: the order below is the order that executes.
-// Two A register sets, refilled IN PLACE: set `a0` holds the even K-groups, `a1` the odd ones; tile t of a set is
-// reloaded with group kg+2 right after its last MFMA of group kg (row j=3), i.e. 5*NTO-1 MFMAs (~2600 cycles at
-// NTO=8) before its next use.  Both sets are loaded by the caller (a_prefetch) BEFORE the previous layer's epilogue
-// stores: vmcnt retires in order, stores included, and loads queued behind 32 KiB of stores would wait for the HBM
-// write acknowledgements.  The B operand (this lane's 16-byte chunk of the LDS tile) is read one group ahead.
-// Groups past `last` are clamped (re-read): branch-free, so the compiler's vmcnt bookkeeping stays exact.
-// Buffer addressing.  A 16-byte-per-lane load whose address is an SGPR base + a loop-invariant 32-bit VGPR offset
-// (+ SGPR soffset) issues for free behind an MFMA; the same load through a per-lane 64-bit pointer that is bumped
-// with v_add_co/v_addc costs the wave ~25 cycles of MFMA issue (scripts/opcost_probe*.hip).  So the weight blob is
-// addressed through ONE buffer resource, panels and K-groups through the scalar offset.
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-
-__device__ __forceinline__ rsrc_t make_rsrc(const void* base, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00027000);
-}
-__device__ __forceinline__ f32x4 buf_load(rsrc_t r, int voff, int soff) {
-  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
-}
-__device__ __forceinline__ void buf_store(rsrc_t r, int voff, int soff, const f32x4& v) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
-}
-
-// A-operand source: the packed weight blob + this lane's byte offset inside a 32-row x 8-k tile piece
-struct APanel {
-  rsrc_t rs;
-  int lane;     // ((lane & 31) * 8 + 4 * (lane >> 5)) * 4
-};
-
-// tile t of K-group kg of the panel at float offset `poff` (rows per group NP): soffset carries panel, group and the
-// upper tile bit; the VGPR offset (lane + (t & 3) KiB) is loop invariant.
-template <int NTO>
-__device__ __forceinline__ void a_load(f32x4 (&a)[NTO], const APanel& P, int poff, int NP, int kg) {
-  const int s0 = (poff + kg * NP * 8) * 4;
-#pragma unroll
-  for (int t = 0; t < NTO; ++t) a[t] = buf_load(P.rs, P.lane + (t & 3) * 1024, s0 + (t >> 2) * 4096);
-}
-
-template <int NTO>
-__device__ __forceinline__ void a_prefetch(f32x4 (&a0)[NTO], f32x4 (&a1)[NTO], const APanel& P, int poff, int NP,
-                                           int last) {
-  a_load<NTO>(a0, P, poff, NP, 0);
-  a_load<NTO>(a1, P, poff, NP, last < 1 ? last : 1);
-}
-
-// acc[t] += sum_k P[k-group][32t+i] * Hs[m][k] over KG (even, >= 4) groups of 8 k's; panel rows per group = NP.
-// If BIAS, the panel carries one more group whose k=0 column is the bias: one extra MFMA per tile against B = (1, 0).
-// `side(i)`, i = 0 .. 4*NTO-1, is called once behind each MFMA of row j=1 of the first four groups: the caller's
-// slot for 4*NTO independent memory instructions (dgrad: the stash rows of the next ReLU mask) that then cost no
-// issue time.  The four groups are peeled so that `i` is a compile-time constant after unrolling.
-struct NoSide {
-  __device__ __forceinline__ void operator()(int) const {}
-};
-
-template <int W, int NTO, bool BIAS, class Side = NoSide>
-__device__ __forceinline__ void gemm_pipe(f32x16 (&acc)[NTO], f32x4 (&a0)[NTO], f32x4 (&a1)[NTO], const APanel& P,
-                                          int poff, int NP, int KG, const float* Hs, int m, int hh,
-                                          Side side = Side()) {
-  const int last = BIAS ? KG : KG - 1;
-  auto ldb = [&](int kg) -> f32x4 {
-    return *reinterpret_cast<const f32x4*>(Hs + hs_off<W>(m, 2 * (kg < KG ? kg : KG - 1) + hh));
-  };
-  // one K-group: 4*NTO MFMAs from set `a` / chunk `b`; reads the next chunk `bn` early, refills `a` late
-  auto step = [&](f32x4 (&a)[NTO], const f32x4& b, f32x4& bn, int kg, int sidx) {
-    const int sn = (poff + (kg + 2 < last ? kg + 2 : last) * NP * 8) * 4;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int t = 0; t < NTO; ++t) {
-        acc[t] = mfma(a[t][j], b[j], acc[t]);
-#if !(defined(CN_EXP) && (CN_EXP & 2))    // ablation 2: no LDS B reads
-        if (j == 0 && t == 0) bn = ldb(kg + 1);
-#endif
-#if !(defined(CN_EXP) && (CN_EXP & 16))   // ablation 16: no side loads
-        if (j == 1 && sidx >= 0) side(sidx * NTO + t);
-#endif
-#if !(defined(CN_EXP) && (CN_EXP & 1))    // ablation 1: no A-operand refills
-        if (j == 3) a[t] = buf_load(P.rs, P.lane + (t & 3) * 1024, sn + (t >> 2) * 4096);
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-      }
-  };
-  f32x4 b0 = ldb(0), b1 = b0;
-  __builtin_amdgcn_sched_barrier(0);
-  step(a0, b0, b1, 0, 0);
-  step(a1, b1, b0, 1, 1);
-  step(a0, b0, b1, 2, 2);
-  step(a1, b1, b0, 3, 3);
-  for (int kg = 4; kg < KG; kg += 2) {
-    step(a0, b0, b1, kg, -1);
-    step(a1, b1, b0, kg + 1, -1);
-  }
-  if (BIAS) {   // group KG (even) was refilled into a0 by the step of group KG-2
-    const float one = hh == 0 ? 1.f : 0.f;
-#pragma unroll
-    for (int t = 0; t < NTO; ++t) acc[t] = mfma(a0[t][0], one, acc[t]);
-  }
-}
-
-// A-operand prefetch ring: CN_RING register sets of NTO 16-byte pieces.  The A operand comes from L2 (weights are
-// streamed, never staged); ring_start() queues group 0 of a panel and is called BEFORE the layer-boundary
-// barriers / epilogue so their latency overlaps it; gemm_run() keeps group kg+1 in flight under the 4*NTO MFMAs
-// (64 cycles each) of group kg (a 4-deep ring measured no faster and spills at 2 waves/SIMD).  Loads past the
-// panel are clamped (re-read the last group) so the loop is branch-free and the compiler counts vmcnt exactly.
-#ifndef CN_RING
-#define CN_RING 2
-#endif
-template <int NTO>
-struct Ring {
-  f32x4 r[CN_RING][NTO];
-};
-
-template <int NTO>
-__device__ __forceinline__ void ring_load(f32x4 (&r)[NTO], const float* pa, int64_t gstride, int kg, int last) {
-  const float* pg = pa + (int64_t)(kg < last ? kg : last) * gstride;
-#pragma unroll
-  for (int t = 0; t < NTO; ++t) {
-#if defined(CN_EXP) && (CN_EXP & 1)   // ablation: no A-operand loads
-    (void)pg; const float q = (float)kg * 1e-3f; r[t] = f32x4{q, q + 1e-4f, q, q};
-#else
-    r[t] = *reinterpret_cast<const f32x4*>(pg + (int64_t)t * 256);
-#endif
-  }
-}
-
-// panel rows per group = NP; `last` = index of the last group of the panel (KG-1, or KG when it has a bias group)
-template <int NTO>
-__device__ __forceinline__ void ring_start(Ring<NTO>& R, const float* __restrict__ panel, int NP, int last, int m,
-                                           int hh) {
-  const float* pa = panel + ((int64_t)m * 8 + 4 * hh);
-#pragma unroll
-  for (int d = 0; d < CN_RING - 1; ++d) ring_load<NTO>(R.r[d], pa, (int64_t)NP * 8, d, last);
-}
-
-// acc[t] += sum_k P[k-group][32t+i] * Hs[m][k]  for KG groups of 8 k's (KG a multiple of CN_RING: every contracted
-// width is padded to a multiple of 32), then, if BIAS, acc += bias via the panel's extra group against the constant
-// B operand (1, 0): one more MFMA per tile instead of a bias vector in registers.
-template <int W, int NTO, bool BIAS>
-__device__ __forceinline__ void gemm_run(f32x16 (&acc)[NTO], Ring<NTO>& R, const float* __restrict__ panel, int NP,
-                                         int KG, const float* Hs, int m, int hh) {
-  const float* pa = panel + ((int64_t)m * 8 + 4 * hh);
-  const int64_t gs = (int64_t)NP * 8;
-  const int last = BIAS ? KG : KG - 1;
-  auto fma4 = [&](f32x4 (&r)[NTO], int kg) {
-    const f32x4 b = *reinterpret_cast<const f32x4*>(Hs + hs_off<W>(m, 2 * kg + hh));
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int t = 0; t < NTO; ++t) acc[t] = mfma(r[t][j], b[j], acc[t]);
-  };
-  // (Deliberately NOT pinned with sched_barriers: this two-waves-per-SIMD kernel measured slower with a dense MFMA
-  // stream — fp32 MFMA and VALU share the SIMD's datapath, so the partner wave's VALU phases only progress in
-  // the bubbles this loop leaves.  The one-wave kernels use gemm_pipe above.)
-  for (int kg = 0; kg < KG; kg += CN_RING) {
-#pragma unroll
-    for (int d = 0; d < CN_RING; ++d) {
-      ring_load<NTO>(R.r[(d + CN_RING - 1) % CN_RING], pa, gs, kg + d + CN_RING - 1, last);
-      fma4(R.r[d], kg + d);
-    }
-  }
-  if (BIAS) {   // group KG sits in r[0] (KG % CN_RING == 0): P[KG][n][0] = bias[n]
-    const float one = hh == 0 ? 1.f : 0.f;
-#pragma unroll
-    for (int t = 0; t < NTO; ++t) acc[t] = mfma(R.r[0][t][0], one, acc[t]);
-  }
-}
-
-template <int W, int NTO, bool BIAS>
-__device__ __forceinline__ void gemm_seg(f32x16 (&acc)[NTO], const float* __restrict__ panel, int NP, int KG,
-                                         const float* Hs, int m, int hh) {
-  Ring<NTO> R;
-  ring_start<NTO>(R, panel, NP, BIAS ? KG : KG - 1, m, hh);
-  gemm_run<W, NTO, BIAS>(acc, R, panel, NP, KG, Hs, m, hh);
+__device__ __forceinline__ f32x16 mfma_z(float a, float b) {   // C = inline constant 0: starts an accumulation
+  const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, z, 0, 0, 0);
 }
 
 template <int NTO>
@@ -263,40 +44,221 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[NTO]) {
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 }
 
-// ReLU (optional) the accumulators of output tiles t0..t0+NTO-1 and park them in the workgroup's LDS tile (B
-// operand of the next layer) and, when training, in the stash.  The stash is POINT-MAJOR, [Mp][s_rows]: everything
-// the backward needs about one point is one contiguous row, a lane's 4 consecutive features are ONE 16-byte store
-// (straight from the registers, immediate offsets off one per-lane pointer), and the wgrad kernel can DMA 32-point
-// slabs straight into LDS.  `sp` = this lane's (stash row + 4*hh) or nullptr; `col` = first column of the block.
-// Lanes past M (padding points) store zeros so the backward never has to mask them.
-template <int W, int NTO, bool RELU>
-__device__ __forceinline__ void park(f32x16 (&acc)[NTO], float* Hs, bool to_lds, int t0, int m, int hh,
-                                     float* __restrict__ sp, int col, bool valid) {
-  float* dst = sp != nullptr ? sp + col + 32 * t0 : nullptr;
+// ---- buffer addressing ---------------------------------------------------------------------------------------------
+// Raw buffer resource (stride 0): address = base + voffset + soffset + imm; accesses at or past `bytes` are dropped
+// (stores) or return 0 (loads) — used to discard the rows of padding points instead of masking every store.
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00027000);
+}
+__device__ __forceinline__ f32x4 buf_load(rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_store(rsrc_t r, int voff, int soff, const f32x4& v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
+}
+
+// ReLU sign-bit words of one layer for this lane: MD dwords (common.hpp: s_mask)
+template <int MD>
+__device__ __forceinline__ void store_bits(rsrc_t r, int voff, int soff, const unsigned (&b)[MD]) {
+  if (MD == 4) __builtin_amdgcn_raw_buffer_store_b128(u32x4{b[0], b[MD > 1 ? 1 : 0], b[MD > 2 ? 2 : 0], b[MD > 3 ? 3 : 0]},
+                                                      r, voff, soff, 0);
+  else if (MD == 2) __builtin_amdgcn_raw_buffer_store_b64(u32x2{b[0], b[MD > 1 ? 1 : 0]}, r, voff, soff, 0);
+  else __builtin_amdgcn_raw_buffer_store_b32(b[0], r, voff, soff, 0);
+}
+template <int MD>
+__device__ __forceinline__ void load_bits(rsrc_t r, int voff, int soff, unsigned (&b)[MD]) {
+  if (MD == 4) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
 #pragma unroll
-  for (int t = 0; t < NTO; ++t)
+    for (int i = 0; i < MD; ++i) b[i] = v[i < 4 ? i : 0];
+  } else if (MD == 2) {
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      f32x4 v;
+    for (int i = 0; i < MD; ++i) b[i] = v[i < 2 ? i : 0];
+  } else {
+    b[0] = __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
+  }
+}
+
+// ---- A operand -----------------------------------------------------------------------------------------------------
+// The packed weight blob behind ONE buffer resource + this lane's byte offset inside a 32-row x 8-k tile piece.
+struct APanel {
+  rsrc_t rs;
+  int lane;     // ((lane & 31) * 8 + 4 * (lane >> 5)) * 4
+};
+
+// tiles 0..NTO-1 of K-group kg of the panel at float offset `poff` (rows per group NP): the scalar offset carries
+// panel, group and tile (SALU adds are free); the one VGPR offset is this lane's position inside a tile piece.
+// (Constants added to the VGPR offset are NOT folded into the instruction's immediate by this compiler: they become
+// distinct long-lived VGPRs, which at 512 registers means spills reloaded inside the MFMA stream.)
+template <int NTO>
+__device__ __forceinline__ void a_load(f32x4 (&a)[NTO], const APanel& P, int poff, int NP, int kg) {
+  const int s0 = (poff + kg * NP * 8) * 4;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float x = acc[t][4 * q + j];
-        if (RELU) x = x > 0.f ? x : 0.f;
-        acc[t][4 * q + j] = x;
-        v[j] = x;
-      }
-#if defined(CN_EXP) && (CN_EXP & 4)   // ablation: no LDS tile writes
-      if (to_lds && v[0] == 12345.678f) *reinterpret_cast<f32x4*>(Hs + hs_off<W>(m, 8 * (t0 + t) + 2 * q + hh)) = v;
-#else
-      if (to_lds) *reinterpret_cast<f32x4*>(Hs + hs_off<W>(m, 8 * (t0 + t) + 2 * q + hh)) = v;
-#endif
-      if (dst != nullptr) {
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-#if defined(CN_NT)
-        __builtin_nontemporal_store(valid ? v : z, reinterpret_cast<f32x4*>(dst + 32 * t + 8 * q));
-#else
-        *reinterpret_cast<f32x4*>(dst + 32 * t + 8 * q) = valid ? v : z;
-#endif
+  for (int t = 0; t < NTO; ++t) a[t] = buf_load(P.rs, P.lane, s0 + t * 1024);
+}
+
+// Both A register sets of a panel: a0 <- group 0, a1 <- group 1.  Two sets are refilled IN PLACE by the GEMMs below:
+// set a0 holds the even K-groups, a1 the odd ones; tile t of a set is reloaded with group kg+2 right behind its last
+// MFMA of group kg (row j = 3), i.e. 5*NTO-1 MFMAs (~2600 cycles at NTO = 8) before its next use.  Groups past the
+// panel's last one are clamped (re-read): branch-free, so the compiler's vmcnt bookkeeping stays exact.
+template <int NTO>
+__device__ __forceinline__ void a_prefetch(f32x4 (&a0)[NTO], f32x4 (&a1)[NTO], const APanel& P, int poff, int NP,
+                                           int last) {
+  a_load<NTO>(a0, P, poff, NP, 0);
+  a_load<NTO>(a1, P, poff, NP, last < 1 ? last : 1);
+}
+
+struct NoSide {
+  __device__ __forceinline__ void operator()(int, int, int) const {}
+};
+
+// ---- GEMM with the B operand in registers ----------------------------------------------------------------------------
+// Q[t] (+)= sum_k Panel[k-group][32t + i] * X[k][m] for K = 32*NTI features held in C-layout registers X (see top).
+// Fully unrolled (register indices must be static): 16*NTI*NTO MFMAs of straight-line code.
+//   INIT   the first MFMA of every tile starts from 0 instead of Q
+//   BIAS   the panel carries one more group whose k=0 column is the bias: one extra MFMA per tile vs B = (1, 0)
+//   side(kg, j, t) is called once behind every MFMA: the caller's slots for independent memory instructions
+//                  (stash / gradient stores of X, which stays live) that then cost no issue time.
+template <int NTI, int NTO, bool BIAS, bool INIT, class Side = NoSide>
+__device__ __forceinline__ void gemm_reg(f32x16 (&Q)[NTO], const f32x16 (&X)[NTI], f32x4 (&a0)[NTO], f32x4 (&a1)[NTO],
+                                         const APanel& P, int poff, int NP, int hh, Side side = Side()) {
+  constexpr int KG = 4 * NTI;
+  constexpr int last = BIAS ? KG : KG - 1;
+#pragma unroll
+  for (int kg = 0; kg < KG; ++kg) {
+    f32x4 (&a)[NTO] = (kg & 1) ? a1 : a0;
+    const int sn = (poff + (kg + 2 < last ? kg + 2 : last) * NP * 8) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float b = X[kg >> 2][4 * (kg & 3) + j];
+#pragma unroll
+      for (int t = 0; t < NTO; ++t) {
+        if (INIT && kg == 0 && j == 0) Q[t] = mfma_z(a[t][j], b);
+        else Q[t] = mfma(a[t][j], b, Q[t]);
+        side(kg, j, t);
+        if (j == 3) a[t] = buf_load(P.rs, P.lane, sn + t * 1024);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
+  }
+  if (BIAS) {   // group KG (even) was refilled into a0 behind group KG-2
+    const float one = hh == 0 ? 1.f : 0.f;
+#pragma unroll
+    for (int t = 0; t < NTO; ++t) Q[t] = mfma(a0[t][0], one, Q[t]);
+  }
+}
+
+// ---- GEMM with the B operand in an LDS tile (encodings) ------------------------------------------------------------
+// Tile = 32 points x 64 floats, 16-byte chunks XOR-swizzled with (m & 15): conflict-free b128 for the wave.
+__device__ __forceinline__ int enc_off(int m, int c) { return m * 64 + ((c ^ (m & 15)) << 2); }
+
+// Q[t] (+)= sum_k Panel[k-group][32t + i] * T[m][k] over KG (even, >= 4) groups of 8 k's read from tile T; the chunk
+// of group kg+1 is read behind the first MFMA of group kg.  The first four groups are peeled (INIT, and so that the
+// loop carries no special cases).
+template <int NTO, bool BIAS, bool INIT>
+__device__ __forceinline__ void gemm_lds(f32x16 (&Q)[NTO], f32x4 (&a0)[NTO], f32x4 (&a1)[NTO], const APanel& P,
+                                         int poff, int NP, int KG, const float* T, int m, int hh) {
+  const int last = BIAS ? KG : KG - 1;
+  // chunk 2kg+hh of row m: enc_off(m, 2kg + hh) * 4 == lbase ^ (kg << 5) (the XOR swizzle commutes with the group
+  // bits), so one v_xor per group addresses it and no per-group address registers stay live
+  const int lbase = m * 256 + ((hh ^ (m & 15)) << 4);
+  auto ldb = [&](int kg) __attribute__((always_inline)) -> f32x4 {
+    int lb = lbase;
+    asm volatile("" : "+v"(lb));   // rematerialise the v_xor at every use: the hoisted addresses would be spilled
+    return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(T) + (lb ^ ((kg < KG ? kg : KG - 1) << 5)));
+  };
+  auto step = [&](f32x4 (&a)[NTO], const f32x4& b, f32x4& bn, int kg, bool first) __attribute__((always_inline)) {
+    const int sn = (poff + (kg + 2 < last ? kg + 2 : last) * NP * 8) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int t = 0; t < NTO; ++t) {
+        if (INIT && first && j == 0) Q[t] = mfma_z(a[t][j], b[j]);
+        else Q[t] = mfma(a[t][j], b[j], Q[t]);
+        if (j == 0 && t == 0) bn = ldb(kg + 1);
+        if (j == 3) a[t] = buf_load(P.rs, P.lane, sn + t * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+  };
+  f32x4 b0 = ldb(0), b1 = b0;
+  __builtin_amdgcn_sched_barrier(0);
+  step(a0, b0, b1, 0, true);
+  step(a1, b1, b0, 1, false);
+  step(a0, b0, b1, 2, false);
+  step(a1, b1, b0, 3, false);
+  for (int kg = 4; kg < KG; kg += 2) {
+    step(a0, b0, b1, kg, false);
+    step(a1, b1, b0, kg + 1, false);
+  }
+  if (BIAS) {
+    const float one = hh == 0 ? 1.f : 0.f;
+#pragma unroll
+    for (int t = 0; t < NTO; ++t) Q[t] = mfma(a0[t][0], one, Q[t]);
+  }
+}
+
+// Scheduling fence for a register tile set: an empty volatile asm that "rewrites" X.  SelectionDAG orders volatile asm
+// with the other side-effecting nodes (loads, stores, sched_barriers), so the MFMAs that produce X cannot sink below
+// this point and the ones that consume it cannot rise above it — without it, two back-to-back GEMMs in one basic
+// block get their MFMAs pooled at the second one while all the first one's operand loads stay live (spills).
+template <int NT>
+__device__ __forceinline__ void pin(f32x16 (&X)[NT]) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(X[t]));
+}
+
+// ---- epilogues -------------------------------------------------------------------------------------------------------
+// In-place ReLU of NT tiles; when BITS, also packs the sign bits (x > 0) into MD = ceil(NT/2) dwords per lane
+// (layout: common.hpp s_mask).  One v_max per element, plus v_cmp + v_addc (bits = 2*bits + carry) when BITS.
+template <int NT, bool BITS>
+__device__ __forceinline__ void relu_bits(f32x16 (&Q)[NT], unsigned (&bits)[(NT + 1) / 2]) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    if (BITS && (t & 1) == 0) bits[t >> 1] = 0u;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float x = Q[t][r];
+      if (BITS) asm("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits[t >> 1]) : "v"(x) : "vcc");
+      Q[t][r] = x > 0.f ? x : 0.f;
+    }
+  }
+}
+
+// Gradient mask: Q <- Q * [bit], consuming the words produced by relu_bits in the same element order
+// (v_add_co shifts the next bit into vcc, v_cndmask applies it).
+template <int NT>
+__device__ __forceinline__ void mask_bits(f32x16 (&Q)[NT], unsigned (&bits)[(NT + 1) / 2]) {
+  if (NT & 1) bits[NT >> 1] <<= 16;   // a single tile in the last word: its 16 bits sit in the low half
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      asm("v_add_co_u32 %0, vcc, %0, %0\n\tv_cndmask_b32 %1, 0, %1, vcc" : "+v"(bits[t >> 1]), "+v"(Q[t][r]) : : "vcc");
+}
+
+// 32-feature-tile stores of C-layout registers into a point-major row block, as a `side` functor of the GEMMs:
+// 4*NTI stores (tile i>>2, quad i&3), one behind each MFMA of row j = 1 of the first ceil(4*NTI/NTO) K-groups.
+// `voff` = (this point's row + 4*hh floats) in bytes relative to the resource base, `soff` = block column in bytes.
+template <int NTI, int NTO>
+struct TileStores {
+  const f32x16 (&X)[NTI];
+  rsrc_t rs;
+  int voff, soff;
+  __device__ __forceinline__ void operator()(int kg, int j, int t) const {
+    if (j != 1) return;
+    const int i = kg * NTO + t;
+    if (i >= 4 * NTI) return;
+    const int tt = i >> 2, q = i & 3;
+    buf_store(rs, voff, soff + (32 * tt + 8 * q) * 4, f32x4{X[tt][4 * q], X[tt][4 * q + 1], X[tt][4 * q + 2], X[tt][4 * q + 3]});
+  }
+};
+
+template <int NT>
+__device__ __forceinline__ void store_tiles(const f32x16 (&X)[NT], rsrc_t rs, int voff, int soff) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      buf_store(rs, voff, soff + (32 * t + 8 * q) * 4, f32x4{X[t][4 * q], X[t][4 * q + 1], X[t][4 * q + 2], X[t][4 * q + 3]});
 }

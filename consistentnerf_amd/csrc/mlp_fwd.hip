@@ -1,24 +1,19 @@
 // Fused positional-encoding + NeRF MLP forward on gfx950 matrix cores.
-// Replaces run_network (R:37-52), Embedder.embed (H:15-63) and NeRF.forward (H:107-130): the 90-wide
-// encodings and every [M,256] activation of the reference never reach HBM (inference), or reach it
-// exactly once as the training stash.
+// Replaces run_network (R:37-52), Embedder.embed (H:15-63) and NeRF.forward (H:107-130): the 90-wide encodings and
+// every [M,256] activation of the reference never reach HBM (inference), or reach it exactly once as the training
+// stash.
 //
-// Mapping.  A workgroup of two wave64 owns 32 points and walks them through the whole network; 4 workgroups per
-// CU = 2 waves per SIMD.  Every layer is computed TRANSPOSED, Out^T[N x 32] = W[N x K] . H^T[K x 32], with
-// v_mfma_f32_32x32x2_f32 (exact fp32, bit-equal to an fmaf chain); wave w produces output tiles
-// [w*NT/2, (w+1)*NT/2):
-//   A operand  = weights, lane (i = lane&31, hh = lane>>5) holds W[n0+i][k + hh'] — one 16-byte load of
-//                the packed panel (common.hpp) feeds 4 consecutive MFMAs; a wave reads 1 KiB contiguous.
-//   B operand  = activations of the 32 points, lane (m = lane&31, hh) holds H^T[k][m]; read from the workgroup's
-//                LDS tile Hs[m][k] (16-byte chunks XOR-swizzled by m&15: conflict-free b128).
-//   D (C-layout) lane (m, hh) holds rows n = 32t + 8(r>>2) + 4hh + (r&3): 4 consecutive n per float4,
-//                so ReLU'd accumulators go back to Hs with ds_write_b128 and straight into the next layer.
-// Two workgroup barriers per layer (tile fully read -> overwrite -> fully written); weights (2.4 MB/net) stay
-// L2-resident and are streamed once per 32 points; MFMA-bound by construction (593 920 MAC per point at
-// D=8/W=256 incl. K padding).
+// Mapping (mlp_common.hpp has the layouts).  One wave64 owns 32 points and walks them through the whole network, one
+// wave per SIMD.  Every layer is computed TRANSPOSED, Out^T[N x 32] = W[N x K] . H^T[K x 32], with
+// v_mfma_f32_32x32x2_f32 (exact fp32): the A operand is a weight panel streamed from L2 through a buffer resource
+// (one free 16-byte load behind an MFMA feeds 4 of them), the B operand is the PREVIOUS layer's accumulator registers
+// — the C layout of one layer is the B layout of the next — so hidden activations never leave the register file: no
+// LDS tile, no transposes, no barriers.  Two accumulator sets X / Y alternate as input and output; ReLU runs in place.
+// gamma(x) and gamma(d) are generated into a 2 x 8 KiB LDS tile (B operand of layer 0, of the skip segment and of the
+// view branch).  Training stores each activation tile to the stash from the registers while the NEXT layer's MFMAs
+// run (the tile is that GEMM's B operand, it stays live), plus 1 bit per hidden unit (ReLU sign) for the backward.
+// MFMA-bound by construction: 593 920 MAC per point at D=8/W=256 incl. K padding.
 #include "mlp_common.hpp"
-
-#include "timing.hpp"
 
 namespace {
 
@@ -36,223 +31,211 @@ struct FwdArgs {
   int S, rs;
 };
 
-// gamma(x) channels of one point into Hs[m][0..chp), split over the workgroup's two waves (w) and the two
-// half-waves (hh): wave w takes the frequencies l = w, w+2, ...; hh=0 lanes their sines, hh=1 their cosines;
-// wave 0 / hh 0 the identity channels, wave 1 / hh 1 the zero padding.
-// Channel order H:24-45: [x, sin(2^0 x), cos(2^0 x), ..., sin(2^(L-1) x), cos(..)].  `srow` = this point's stash
-// row + block column (training) or nullptr.
-template <int W>
-__device__ __forceinline__ void encode(float* Hs, const float (&x)[3], int L, int ch, int chp, int w, int m, int hh,
-                                       float* __restrict__ srow, bool valid, const float* __restrict__ pre = nullptr) {
-  auto put = [&](int k, float v) {
-    Hs[hs_off<W>(m, k >> 2) + (k & 3)] = v;
-    if (srow != nullptr) srow[k] = valid ? v : 0.f;
-  };
-  if (pre != nullptr) {   // NeRF.forward(x) on an already-embedded batch (H:107-109): copy this point's channels
-    for (int k = 2 * w + hh; k < chp; k += 4) put(k, k < ch ? pre[k] : 0.f);
+// gamma(v) of this lane's point into the LDS tile T[m][0..chp): half-wave hh takes the frequencies l = hh, hh+2, ...
+// (one sincos per coordinate: both channels of the pair), half-wave 0 the identity channels, half-wave 1 the zero
+// padding.  Channel order H:24-45: [v, sin(2^0 v), cos(2^0 v), ..., sin(2^(L-1) v), cos(..)].  With `pre`, the
+// channels are copied from an already-embedded row instead (NeRF.forward(x), H:107-109).
+__device__ __forceinline__ void encode(float* T, const float (&v)[3], int L, int ch, int chp, int m, int hh,
+                                       const float* __restrict__ pre) {
+  auto put = [&](int k, float x) { T[enc_off(m, k >> 2) + (k & 3)] = x; };
+  if (pre != nullptr) {
+    for (int k = hh; k < chp; k += 2) put(k, k < ch ? pre[k] : 0.f);
     return;
   }
-  if (w == 0 && hh == 0) {
-    put(0, x[0]); put(1, x[1]); put(2, x[2]);
-  }
-  if (w == 1 && hh == 1) {
+  if (hh == 0) {
+    put(0, v[0]); put(1, v[1]); put(2, v[2]);
+  } else {
     for (int k = ch; k < chp; ++k) put(k, 0.f);
   }
-  float f = w ? 2.f : 1.f;
-  for (int l = w; l < L; l += 2) {
+  float f = hh ? 2.f : 1.f;
+  for (int l = hh; l < L; l += 2) {
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-      const float arg = x[d] * f;
-      put(3 + 6 * l + 3 * hh + d, hh ? cosf(arg) : sinf(arg));
+      const float arg = v[d] * f;
+      put(3 + 6 * l + d, sinf(arg));
+      put(3 + 6 * l + 3 + d, cosf(arg));
     }
     f *= 4.f;
   }
 }
 
-template <int NT, bool VD>
-__global__ __launch_bounds__(128, 2) void mlp_fwd_k(FwdArgs a) {
+// Copy this lane's chunks of an encoding tile to its stash block (lane (m, hh) owns columns 8c + 4hh .. +3)
+__device__ __forceinline__ void stash_tile(const float* T, int chp, rsrc_t srs, int svo, int col, int m, int hh) {
+  for (int c = 0; c < chp / 8; ++c)
+    buf_store(srs, svo, (col + 8 * c) * 4, *reinterpret_cast<const f32x4*>(T + enc_off(m, 2 * c + hh)));
+}
+
+template <int NT, bool VD, bool TRAIN>
+__global__ __launch_bounds__(64) void mlp_fwd_k(FwdArgs a) {
   constexpr int W = NT * 32;
-  constexpr int NTW = NT / 2;                       // trunk / feature tiles per wave
-  constexpr int NTH = NT / 2;                       // view-branch tiles (W/2 wide)
-  constexpr int NTHW = NTH / 2 > 0 ? NTH / 2 : 1;   // ... per wave (W=64: one tile, wave 0 only)
-  extern __shared__ __attribute__((aligned(16))) float Hs[];   // [32][W] tile + 128 floats of head scratch
+  constexpr int NTH = NT / 2 > 0 ? NT / 2 : 1;   // view-branch tiles (W/2 wide)
+  constexpr int MD = (NT + 1) / 2, MDV = (NTH + 1) / 2;
+  __shared__ __attribute__((aligned(16))) float Tx[32 * 64];   // gamma(x)
+  __shared__ __attribute__((aligned(16))) float Td[32 * 64];   // gamma(d) (32 columns used)
   const NetGeom& g = a.g;
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, m = lane & 31, hh = lane >> 5;
-  const int64_t p = (int64_t)blockIdx.x * 32 + m;
-  const bool valid = p < a.M;
-  const int64_t pc = valid ? p : a.M - 1;
+  const int lane = threadIdx.x, m = lane & 31, hh = lane >> 5;
+  const int64_t p0 = (int64_t)blockIdx.x * 32;
+  const int64_t p = p0 + m;
+  const int nvalid = a.M - p0 < 32 ? (int)(a.M - p0) : 32;
+  const int64_t pc = p < a.M ? p : a.M - 1;
   const int64_t ray = pc / a.S;
-  const float* pk = a.packed;
-  const int t0 = w * NTW;
+  CN_TINIT(1)
 
-  CN_TINIT(2)
-  float x[3] = {0.f, 0.f, 0.f};
+  const APanel AP{make_rsrc(a.packed, (unsigned)(g.total * 4)), (m * 8 + 4 * hh) * 4};
+  // this workgroup's 32 stash rows; rows of padding points are out of range: their stores are dropped (the
+  // launcher zero-fills them once, the wgrad DMA reads them)
+  const rsrc_t srs = make_rsrc(TRAIN ? a.stash + p0 * g.s_rows : nullptr, TRAIN ? (unsigned)(nvalid * g.s_rows * 4) : 0u);
+  const int svo = (m * g.s_rows + 4 * hh) * 4;
+  const int smo = (m * g.s_rows + hh * MD) * 4;              // sign-bit words of this lane: + (s_mask + s_mb[l]) * 4
+
+  float x[3] = {0.f, 0.f, 0.f}, v[3] = {0.f, 0.f, 0.f};
   const float* const pre = a.emb != nullptr ? a.emb + pc * (g.in_ch + g.dir_ch) : nullptr;
-  if (pre != nullptr) {
-  } else if (a.pts != nullptr) {
-    x[0] = a.pts[pc * 3 + 0]; x[1] = a.pts[pc * 3 + 1]; x[2] = a.pts[pc * 3 + 2];
-  } else {
-    const float* r = a.rays + ray * a.rs;
-    const float zz = a.z[pc];
-    x[0] = r[0] + r[3] * zz; x[1] = r[1] + r[4] * zz; x[2] = r[2] + r[5] * zz;   // R:384 (no FMA contraction)
-  }
-  // training: this point's stash row (point-major [Mp][s_rows]); padding points p in [M, Mp) are stored as zeros
-  float* const srow = a.stash != nullptr ? a.stash + p * g.s_rows : nullptr;
-  float* const sp = srow != nullptr ? srow + 4 * hh : nullptr;
-
-  encode<W>(Hs, x, g.L, g.in_ch, g.in_chp, w, m, hh, srow != nullptr ? srow + g.s_enc : nullptr, valid, pre);
-  CN_T(0)
-  __syncthreads();
-  CN_T(1)
-
-  // Per layer: GEMM -> [queue the next panel's first A groups] -> barrier (tile fully read) -> park (ReLU, LDS,
-  // stash) -> barrier -> next GEMM.  Biases ride on the panels (gemm_run<BIAS>), accumulators start at zero.
-  f32x16 acc[NTW];
-  f32x16 accs[NTW];   // gamma(x) part (+ bias) of the skip layer, computed while gamma(x) is still in LDS
-  Ring<NTW> R;
-  zero_acc<NTW>(acc);
-  gemm_seg<W, NTW, true>(acc, pk + g.f_l0 + t0 * 256, W, g.in_chp / 8, Hs, m, hh);
-#if !(defined(CN_EXP) && (CN_EXP & 8))   // ablation: no skip partial (wrong results, frees 64 registers)
-  if (g.skip >= 0) {
-    zero_acc<NTW>(accs);
-    gemm_seg<W, NTW, true>(accs, pk + g.f_skip + t0 * 256, W, g.in_chp / 8, Hs, m, hh);
-  }
-#endif
-  CN_T(2)
-  for (int l = 1; l < g.D; ++l) {
-    const bool sk = l == g.skip + 1;
-    const float* panel = pk + g.f_trunk[l] + t0 * 256;
-    ring_start<NTW>(R, panel, W, sk ? W / 8 - 1 : W / 8, m, hh);
-    __syncthreads();                                 // both waves finished reading the tile
-    CN_T(1)
-    park<W, NTW, true>(acc, Hs, true, t0, m, hh, sp, g.s_h[l - 1], valid);
-    CN_T(3)
-    __syncthreads();
-    CN_T(1)
-    if (sk) {
-#if defined(CN_EXP) && (CN_EXP & 8)
-      zero_acc<NTW>(acc);
-#else
-#pragma unroll
-      for (int t = 0; t < NTW; ++t) acc[t] = accs[t];
-#endif
-      gemm_run<W, NTW, false>(acc, R, panel, W, W / 8, Hs, m, hh);
+  if (pre == nullptr) {
+    if (a.pts != nullptr) {
+      x[0] = a.pts[pc * 3 + 0]; x[1] = a.pts[pc * 3 + 1]; x[2] = a.pts[pc * 3 + 2];
     } else {
-      zero_acc<NTW>(acc);
-      gemm_run<W, NTW, true>(acc, R, panel, W, W / 8, Hs, m, hh);
+      const float* r = a.rays + ray * a.rs;
+      const float zz = a.z[pc];
+      x[0] = r[0] + r[3] * zz; x[1] = r[1] + r[4] * zz; x[2] = r[2] + r[5] * zz;   // R:384 (no FMA contraction)
+    }
+    if (VD) {
+      const float* dsrc = a.dirs != nullptr ? a.dirs + ray * 3 : a.rays + ray * a.rs + (a.rs - 3);
+      v[0] = dsrc[0]; v[1] = dsrc[1]; v[2] = dsrc[2];
+    }
+  }
+  f32x4 a0[NT], a1[NT];
+  a_prefetch<NT>(a0, a1, AP, (int)g.f_l0, W, g.in_chp / 8);
+  encode(Tx, x, g.L, g.in_ch, g.in_chp, m, hh, pre);
+  if (VD) encode(Td, v, g.Ld, g.dir_ch, g.dir_chp, m, hh, pre != nullptr ? pre + g.in_ch : nullptr);
+  if (TRAIN) {
+    stash_tile(Tx, g.in_chp, srs, svo, g.s_enc, m, hh);
+    if (VD) stash_tile(Td, g.dir_chp, srs, svo, g.s_denc, m, hh);
+  }
+  CN_T(0)
+
+  f32x16 X[NT], Y[NT];
+  unsigned bits[MD];
+  // layer 0 (gamma(x) from LDS) -> Y
+  gemm_lds<NT, true, true>(Y, a0, a1, AP, (int)g.f_l0, W, g.in_chp / 8, Tx, m, hh);
+  CN_T(2)
+  // One W x W layer, l = 1..D-1 trunk, l = D feature_linear (VD): ReLU the input set in place (+ sign bits), queue
+  // the panel, GEMM into the other set while the input tiles go out to the stash.  The skip layer adds the gamma(x)
+  // segment (and its bias) from LDS; the sigma head (alpha_linear, H:117) reads the trunk output on the VALU.
+  float sig = 0.f;
+  auto layer = [&](f32x16 (&In)[NT], f32x16 (&Out)[NT], int l) __attribute__((always_inline)) {
+    const int poff = (int)(l < g.D ? g.f_trunk[l] : g.f_feat);
+    a_prefetch<NT>(a0, a1, AP, poff, W, W / 8);
+    relu_bits<NT, TRAIN>(In, bits);
+    if (TRAIN) store_bits<MD>(srs, smo, (g.s_mask + g.s_mb[l - 1]) * 4, bits);
+    if (VD && l == g.D) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 wv = buf_load(AP.rs, hh * 16, (int)(g.v_alpha + 32 * t + 8 * q) * 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) sig = __builtin_fmaf(In[t][4 * q + j], wv[j], sig);
+        }
+      sig += __shfl_xor(sig, 32, 64);
+      sig += a.packed[g.b_alpha];
+    }
+    CN_T(3)
+    if (TRAIN)
+      gemm_reg<NT, NT, true, true>(Out, In, a0, a1, AP, poff, W, hh, TileStores<NT, NT>{In, srs, svo, g.s_h[l - 1] * 4});
+    else
+      gemm_reg<NT, NT, true, true>(Out, In, a0, a1, AP, poff, W, hh);
+    if (l == g.skip + 1) {
+      a_prefetch<NT>(a0, a1, AP, (int)g.f_skip, W, g.in_chp / 8);
+      gemm_lds<NT, true, false>(Out, a0, a1, AP, (int)g.f_skip, W, g.in_chp / 8, Tx, m, hh);
     }
     CN_T(2)
+  };
+  // layer 0 wrote Y; layers alternate Y -> X -> Y ...; an odd layer count ends in X, an even one in Y.  The view
+  // branch reads Y and the no-viewdirs head X: D = 8 needs no copy either way.
+  const int nl = VD ? g.D : g.D - 1;
+  for (int l = 1; l <= nl; l += 2) {
+    layer(Y, X, l);
+    if (l + 1 <= nl) layer(X, Y, l + 1);
   }
-  if (VD) ring_start<NTW>(R, pk + g.f_feat + t0 * 256, W, W / 8, m, hh);
-  __syncthreads();
-  CN_T(1)
-  park<W, NTW, true>(acc, Hs, true, t0, m, hh, sp, g.s_h[g.D - 1], valid);
-  CN_T(3)
-  __syncthreads();
-  CN_T(1)
+  if (VD && (nl & 1)) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) Y[t] = X[t];
+  }
+  if (!VD && !(nl & 1)) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) X[t] = Y[t];
+  }
+  const rsrc_t ors = make_rsrc(a.raw + p0 * (VD ? 4 : g.out_ch), (unsigned)(nvalid * (VD ? 4 : g.out_ch) * 4));
 
   if (!VD) {
-    // output_linear (H:127-128) on the VALU of wave 0: out[c] = b[c] + sum_k Wo[c][k] h[k]; each half-wave sums
-    // half the chunks
-    if (w == 0) {
-      float o[8];
+    // trunk output h_{D-1} = relu(X); output_linear (H:127-128) on the VALU: out[c] = b[c] + sum_n Wo[c][n] h[n],
+    // each lane sums its own features
+    relu_bits<NT, TRAIN>(X, bits);
+    if (TRAIN) {
+      store_bits<MD>(srs, smo, (g.s_mask + g.s_mb[g.D - 1]) * 4, bits);
+      store_tiles<NT>(X, srs, svo, g.s_h[g.D - 1] * 4);
+    }
+    float o[8];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) o[c] = 0.f;
-      for (int i = 0; i < W / 8; ++i) {
-        const int ck = 2 * i + hh;
-        const f32x4 h = *reinterpret_cast<const f32x4*>(Hs + hs_off<W>(m, ck));
+    for (int c = 0; c < 8; ++c) o[c] = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int c = 0; c < 8; ++c)
           if (c < g.out_ch) {
-            const f32x4 wv = *reinterpret_cast<const f32x4*>(pk + g.v_out + (int64_t)c * W + 4 * ck);
-            o[c] += h[0] * wv[0] + h[1] * wv[1] + h[2] * wv[2] + h[3] * wv[3];
-          }
-      }
+            const f32x4 wv = buf_load(AP.rs, hh * 16, (int)(g.v_out + (int64_t)c * W + 32 * t + 8 * q) * 4);
 #pragma unroll
-      for (int c = 0; c < 8; ++c) o[c] += __shfl_xor(o[c], 32, 64);
-      if (valid && hh == 0)
-        for (int c = 0; c < g.out_ch; ++c) a.raw[p * g.out_ch + c] = o[c] + pk[g.b_out + c];
-    }
+            for (int j = 0; j < 4; ++j) o[c] = __builtin_fmaf(X[t][4 * q + j], wv[j], o[c]);
+          }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) o[c] += __shfl_xor(o[c], 32, 64);
+    if (hh == 0)
+      for (int c = 0; c < g.out_ch; ++c)
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o[c] + a.packed[g.b_out + c]), ors,
+                                              (m * g.out_ch + c) * 4, 0, 0);
     CN_T(4)
     CN_TEND
     return;
   } else {
-    // sigma head (alpha_linear, H:117) on the VALU of wave 0 while the trunk output is in LDS
-    float sig = 0.f;
-    if (w == 0) {
-      for (int i = 0; i < W / 8; ++i) {
-        const int ck = 2 * i + hh;
-        const f32x4 h = *reinterpret_cast<const f32x4*>(Hs + hs_off<W>(m, ck));
-        const f32x4 wv = *reinterpret_cast<const f32x4*>(pk + g.v_alpha + 4 * ck);
-        sig += h[0] * wv[0] + h[1] * wv[1] + h[2] * wv[2] + h[3] * wv[3];
-      }
-      sig += __shfl_xor(sig, 32, 64);
-      sig += pk[g.b_alpha];
-    }
-    CN_T(4)
-    // feature_linear (H:118), no activation
-    zero_acc<NTW>(acc);
-    gemm_run<W, NTW, true>(acc, R, pk + g.f_feat + t0 * 256, W, W / 8, Hs, m, hh);
+    // views_linears (H:120-123) on cat([feature, gamma(d)]): Y (K = W, registers) + Td (K = dir_chp, LDS, + bias)
+    f32x16 V[NTH];
+    f32x4 v0[NTH], v1[NTH];
+    a_prefetch<NTH>(v0, v1, AP, (int)g.f_views, g.Wh, W / 8 - 1);
+    if (TRAIN)
+      gemm_reg<NT, NTH, false, true>(V, Y, v0, v1, AP, (int)g.f_views, g.Wh, hh,
+                                     TileStores<NT, NTH>{Y, srs, svo, g.s_feat * 4});
+    else
+      gemm_reg<NT, NTH, false, true>(V, Y, v0, v1, AP, (int)g.f_views, g.Wh, hh);
+    pin<NTH>(V);
+    a_prefetch<NTH>(v0, v1, AP, (int)g.f_viewsd, g.Wh, g.dir_chp / 8);
+    gemm_lds<NTH, true, false>(V, v0, v1, AP, (int)g.f_viewsd, g.Wh, g.dir_chp / 8, Td, m, hh);
     CN_T(2)
-    __syncthreads();                                 // trunk output dead
-    CN_T(1)
-    // gamma(viewdir) overwrites the trunk tile; its share of views_linears first
-    float v[3] = {0.f, 0.f, 0.f};
-    if (pre == nullptr) {
-      const float* dsrc = a.dirs != nullptr ? a.dirs + ray * 3 : a.rays + ray * a.rs + (a.rs - 3);
-      v[0] = dsrc[0]; v[1] = dsrc[1]; v[2] = dsrc[2];
+    unsigned bv[MDV];
+    relu_bits<NTH, TRAIN>(V, bv);
+    if (TRAIN) {
+      store_bits<MDV>(srs, (m * g.s_rows + hh * MDV) * 4, (g.s_mask + g.s_mb[g.D]) * 4, bv);
+      store_tiles<NTH>(V, srs, svo, g.s_hv * 4);
     }
-    encode<W>(Hs, v, g.Ld, g.dir_ch, g.dir_chp, w, m, hh, srow != nullptr ? srow + g.s_denc : nullptr, valid,
-              pre != nullptr ? pre + g.in_ch : nullptr);
-    CN_T(0)
-    __syncthreads();
-    CN_T(1)
-    const int t0v = w * NTHW;
-    const bool vact = t0v < NTH;                     // wave-uniform
-    f32x16 accv[NTHW];
-    if (vact) {
-      zero_acc<NTHW>(accv);
-      gemm_seg<W, NTHW, true>(accv, pk + g.f_viewsd + t0v * 256, g.Wh, g.dir_chp / 8, Hs, m, hh);
-    }
-    CN_T(2)
-    __syncthreads();                                 // gamma(d) dead
-    CN_T(1)
-    park<W, NTW, false>(acc, Hs, true, t0, m, hh, sp, g.s_feat, valid);
     CN_T(3)
-    __syncthreads();
-    CN_T(1)
+    // rgb_linear (H:125) straight from the registers: lane holds n = 32t + 8q + 4hh + j
     float o[3] = {0.f, 0.f, 0.f};
-    if (vact) {
-      gemm_seg<W, NTHW, false>(accv, pk + g.f_views + t0v * 256, g.Wh, W / 8, Hs, m, hh);
-      CN_T(2)
-      park<W, NTHW, true>(accv, Hs, false, t0v, m, hh, sp, g.s_hv, valid);   // ReLU in registers (+ stash)
-      // rgb_linear (H:125) straight from the accumulators: lane holds n = 32t + 8q + 4hh + j
 #pragma unroll
-      for (int t = 0; t < NTHW; ++t)
+    for (int t = 0; t < NTH; ++t)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+      for (int q = 0; q < 4; ++q)
 #pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            const f32x4 wv = *reinterpret_cast<const f32x4*>(pk + g.v_rgb + (int64_t)c * g.Wh + 32 * (t0v + t) +
-                                                             8 * q + 4 * hh);
+        for (int c = 0; c < 3; ++c) {
+          const f32x4 wv = buf_load(AP.rs, hh * 16, (int)(g.v_rgb + (int64_t)c * g.Wh + 32 * t + 8 * q) * 4);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[c] += accv[t][4 * q + j] * wv[j];
-          }
+          for (int j = 0; j < 4; ++j) o[c] = __builtin_fmaf(V[t][4 * q + j], wv[j], o[c]);
+        }
 #pragma unroll
-      for (int c = 0; c < 3; ++c) o[c] += __shfl_xor(o[c], 32, 64);
-    }
-    float* scratch = Hs + 32 * W;                    // 32 points x 4 floats, outside the tile
-    if (w == 1 && hh == 0) {
-      scratch[4 * m + 0] = o[0]; scratch[4 * m + 1] = o[1]; scratch[4 * m + 2] = o[2];
-    }
-    CN_T(4)
-    __syncthreads();
-    CN_T(1)
-    if (w == 0 && hh == 0 && valid) {
-      *reinterpret_cast<float4*>(a.raw + p * 4) =
-          make_float4(o[0] + scratch[4 * m + 0] + pk[g.b_rgb + 0], o[1] + scratch[4 * m + 1] + pk[g.b_rgb + 1],
-                      o[2] + scratch[4 * m + 2] + pk[g.b_rgb + 2], sig);
-    }
+    for (int c = 0; c < 3; ++c) o[c] += __shfl_xor(o[c], 32, 64);
+    if (hh == 0)
+      buf_store(ors, m * 16, 0, f32x4{o[0] + a.packed[g.b_rgb + 0], o[1] + a.packed[g.b_rgb + 1],
+                                      o[2] + a.packed[g.b_rgb + 2], sig});
     CN_T(4)
     CN_TEND
   }
@@ -261,11 +244,28 @@ __global__ __launch_bounds__(128, 2) void mlp_fwd_k(FwdArgs a) {
 template <int NT>
 int launch(const FwdArgs& a, hipStream_t st) {
   const unsigned grid = (unsigned)cn_div_up(a.M, 32);
-  const size_t lds = (size_t)(NT * 32 * 32 + 128) * sizeof(float);
-  if (a.g.viewdirs) hipLaunchKernelGGL((mlp_fwd_k<NT, true>), dim3(grid), dim3(128), lds, st, a);
-  else hipLaunchKernelGGL((mlp_fwd_k<NT, false>), dim3(grid), dim3(128), lds, st, a);
+  if (a.stash != nullptr) {
+    if (a.Mp > a.M) {   // rows of the padding points: the kernel drops their stores, wgrad reads them
+      hipError_t e = hipMemsetAsync(a.stash + a.M * a.g.s_rows, 0, (size_t)(a.Mp - a.M) * a.g.s_rows * sizeof(float), st);
+      if (e != hipSuccess) return (int)e;
+    }
+    if (a.g.viewdirs) hipLaunchKernelGGL((mlp_fwd_k<NT, true, true>), dim3(grid), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((mlp_fwd_k<NT, false, true>), dim3(grid), dim3(64), 0, st, a);
+  } else {
+    if (a.g.viewdirs) hipLaunchKernelGGL((mlp_fwd_k<NT, true, false>), dim3(grid), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((mlp_fwd_k<NT, false, false>), dim3(grid), dim3(64), 0, st, a);
+  }
   CN_CHECK_LAUNCH();
   return CNERF_OK;
+}
+
+int dispatch(const FwdArgs& a, void* stream) {
+  switch (a.g.NT) {
+    case 2: return launch<2>(a, cn_stream(stream));
+    case 4: return launch<4>(a, cn_stream(stream));
+    case 8: return launch<8>(a, cn_stream(stream));
+  }
+  return CNERF_E_UNSUPPORTED;
 }
 
 }  // namespace
@@ -287,12 +287,7 @@ extern "C" int cnerf_mlp_fwd(const cnerf_net* net, const float* packed, const fl
   a.packed = packed; a.pts = pts; a.rays = rays; a.dirs = dirs; a.z = z; a.emb = nullptr; a.raw = raw;
   a.stash = stash;
   a.M = B * S; a.Mp = cn_round_up(a.M, 32); a.S = S; a.rs = ray_stride;
-  switch (a.g.NT) {
-    case 2: return launch<2>(a, cn_stream(stream));
-    case 4: return launch<4>(a, cn_stream(stream));
-    case 8: return launch<8>(a, cn_stream(stream));
-  }
-  return CNERF_E_UNSUPPORTED;
+  return dispatch(a, stream);
 }
 
 extern "C" int cnerf_mlp_fwd_embedded(const cnerf_net* net, const float* packed, const float* x_embedded, int64_t M,
@@ -305,10 +300,5 @@ extern "C" int cnerf_mlp_fwd_embedded(const cnerf_net* net, const float* packed,
   a.packed = packed; a.pts = nullptr; a.rays = nullptr; a.dirs = nullptr; a.z = nullptr; a.emb = x_embedded;
   a.raw = raw; a.stash = stash;
   a.M = M; a.Mp = cn_round_up(M, 32); a.S = 1; a.rs = 0;
-  switch (a.g.NT) {
-    case 2: return launch<2>(a, cn_stream(stream));
-    case 4: return launch<4>(a, cn_stream(stream));
-    case 8: return launch<8>(a, cn_stream(stream));
-  }
-  return CNERF_E_UNSUPPORTED;
+  return dispatch(a, stream);
 }

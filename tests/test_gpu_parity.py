@@ -90,9 +90,10 @@ def check_param_grads(model, g, prefix_full, prefix_sum, rtol=5e-2, l2tol=5e-3):
     assert not bad, f"gradient mismatch in {bad}"
 
 
-def stash_blocks(stash, M, D, W, vd):
+def stash_blocks(stash, M, D, W, vd, in_chp=64):
     """point-major [Mp][rows] training stash of cnerf_mlp_fwd -> dict of [M, cols] float64 CPU tensors (common.hpp).
-    Padding points [M, Mp) must have been stored as zeros (the wgrad DMA relies on it)."""
+    Padding points [M, Mp) must be zero rows (the wgrad DMA relies on it).  The last block holds the ReLU sign-bit
+    words the backward masks with; they are decoded and checked against the stored activations (bit == h > 0)."""
     Mp = (M + 31) // 32 * 32
     full = stash.reshape(Mp, -1)
     assert float(full[M:].abs().max()) == 0.0 if Mp > M else True
@@ -103,12 +104,32 @@ def stash_blocks(stash, M, D, W, vd):
         nonlocal r
         out[name] = s[:, r:r + n]
         r += n
-    take("enc", 64)
+    take("enc", in_chp)
     for l in range(D):
         take(f"h{l}", W)
     if vd:
         take("feat", W); take("denc", 32); take("hv", W // 2)
-    assert r == s.shape[1]
+    nt = W // 32
+    md, mdv = (nt + 1) // 2, (nt // 2 + 1) // 2
+    nmask = (D * 2 * md + (2 * mdv if vd else 0) + 3) // 4 * 4
+    assert r + nmask == s.shape[1], (r, nmask, s.shape)
+    words = full[:M, r:].contiguous().view(torch.int32).cpu().numpy().astype(np.int64) & 0xffffffff
+
+    def decode(col0, tiles, m_d):
+        """-> [M, 32*tiles] bool in feature order n = 32t + 8(r>>2) + 4hh + (r&3)"""
+        bits = np.zeros((M, 32 * tiles), dtype=bool)
+        for hh in range(2):
+            for t in range(tiles):
+                wd = words[:, col0 + hh * m_d + (t >> 1)]
+                single = (tiles & 1) and (t >> 1) == tiles >> 1
+                for rr in range(16):
+                    pos = (15 - rr) if single else 31 - (16 * (t & 1) + rr)
+                    bits[:, 32 * t + 8 * (rr >> 2) + 4 * hh + (rr & 3)] = (wd >> pos) & 1
+        return bits
+    for l in range(D):
+        assert np.array_equal(decode(l * 2 * md, nt, md), out[f"h{l}"].numpy() > 0), f"sign bits of layer {l}"
+    if vd:
+        assert np.array_equal(decode(D * 2 * md, max(nt // 2, 1), mdv), out["hv"].numpy() > 0), "sign bits (view branch)"
     return out
 
 

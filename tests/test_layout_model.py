@@ -3,9 +3,9 @@
 `mfma_32x32x2` below is the documented gfx950 semantics of v_mfma_f32_32x32x2_f32
 (A: lane l holds A[i=l&31][k=l>>5]; B: lane l holds B[k=l>>5][j=l&31]; C/D: lane l, reg r holds
 D[row=(r&3)+8*(r>>2)+4*(l>>5)][col=l&31]).  The tests re-state, per lane, the address arithmetic of
-csrc/geom.hip (panels), csrc/mlp_fwd.hip (gemm_seg / init_bias / park / LDS swizzle),
-csrc/mlp_bwd.hip (transposed panels) and csrc/wgrad.hip (point-contracted NT GEMM), run them through
-the model and compare with dense matmuls.  They pin the layout CONTRACT between the pack kernel and
+csrc/geom.hip (panels, bias group), csrc/mlp_common.hpp (gemm_lds over the swizzled encoding tile, gemm_reg with
+the previous layer's accumulators as the B operand, the ReLU sign-bit words), csrc/mlp_bwd.hip (transposed panels)
+and csrc/wgrad.hip (point-contracted NT GEMM), run them through the model and compare with dense matmuls.  They pin the layout CONTRACT between the pack kernel and
 the compute kernels; the GPU parity tests then pin the kernels themselves.
 """
 import numpy as np
@@ -55,39 +55,6 @@ def hs_off(W, m, c):
     return m * W + ((c ^ (m & 15)) << 2)
 
 
-def lds_store_tile(Hs, W, acc, nt):
-    """park(): lane (m,hh) writes float4 (acc[t][4q..4q+3]) at chunk 8t+2q+hh of row m."""
-    for t in range(nt):
-        for q in range(4):
-            for lane in LANES:
-                m, hh = lane & 31, lane >> 5
-                o = hs_off(W, m, 8 * t + 2 * q + hh)
-                Hs[o:o + 4] = acc[t][lane, 4 * q:4 * q + 4]
-
-
-def gemm_seg(acc, P, Hs, W, KG, nto):
-    """mlp_fwd.hip gemm_seg: A = 16-byte piece of the panel, B = 16-byte chunk 2kg+hh of the LDS row."""
-    flat = P.reshape(-1)
-    NP = P.shape[1]
-    for kg in range(KG):
-        b4 = np.stack([Hs[hs_off(W, m, 2 * kg + hh):hs_off(W, m, 2 * kg + hh) + 4] for m, hh in zip(I31, HH)])
-        for t in range(nto):
-            base = ((kg * NP + 32 * t + I31) * 8 + 4 * HH)
-            a4 = np.stack([flat[o:o + 4] for o in base])
-            for j in range(4):
-                acc[t] = mfma_32x32x2(a4[:, j], b4[:, j], acc[t])
-    return acc
-
-
-def init_bias(bias, nto):
-    acc = [np.zeros((64, 16)) for _ in range(nto)]
-    for t in range(nto):
-        for q in range(4):
-            for j in range(4):
-                acc[t][:, 4 * q + j] = bias[32 * t + 8 * q + 4 * HH + j]
-    return acc
-
-
 def acc_to_dense(acc, nto):
     """C-layout -> dense [N, 32 points]."""
     out = np.zeros((32 * nto, 32))
@@ -104,25 +71,109 @@ def test_mfma_model_is_a_matmul():
     assert np.allclose(acc_to_dense([c], 1), A @ B)
 
 
+def pack_bias_group(P, bias):
+    """geom.hip: forward panels of biased layers carry one more group, P[KG][n][0] = bias[n]."""
+    extra = np.zeros((1,) + P.shape[1:])
+    extra[0, :len(bias), 0] = bias
+    return np.concatenate([P, extra], 0)
+
+
+def a_piece(P, kg, t):
+    """a_load: lane (i, hh) reads 16 bytes at ((kg*Np + 32t + i)*8 + 4hh) floats of the panel."""
+    flat, NP = P.reshape(-1), P.shape[1]
+    base = ((kg * NP + 32 * t + I31) * 8 + 4 * HH)
+    return np.stack([flat[o:o + 4] for o in base])
+
+
+def bias_step(acc, P, KG, nto):
+    """the extra MFMA per tile against the constant B operand (1 for half-wave 0, 0 for half-wave 1)."""
+    one = (HH == 0).astype(np.float64)
+    for t in range(nto):
+        acc[t] = mfma_32x32x2(a_piece(P, KG, t)[:, 0], one, acc[t])
+    return acc
+
+
+def gemm_reg(P, X, nti, nto):
+    """mlp_common.hpp gemm_reg: B(kg, j) = X[kg>>2][:, 4(kg&3) + j] — the C layout of the producing layer."""
+    acc = [np.zeros((64, 16)) for _ in range(nto)]
+    for kg in range(4 * nti):
+        for t in range(nto):
+            a4 = a_piece(P, kg, t)
+            for j in range(4):
+                acc[t] = mfma_32x32x2(a4[:, j], X[kg >> 2][:, 4 * (kg & 3) + j], acc[t])
+    return acc
+
+
+def enc_byte_off(m, hh, kg):
+    """gemm_lds: byte address of chunk 2kg+hh of row m == lbase ^ (kg << 5)."""
+    return (m * 256 + ((hh ^ (m & 15)) << 4)) ^ (kg << 5)
+
+
 def test_forward_layer_chain():
-    """two layers through panels + swizzled LDS tile == relu(W2 relu(W1 x + b1) + b2)."""
+    """layer 0 from the swizzled encoding tile (gemm_lds), then two layers with the accumulators as the B operand
+    (gemm_reg): == W3 relu(W2 relu(W1 x + b1) + b2) + b3, no LDS round trip in between."""
     rs = np.random.RandomState(1)
     W = 64; nt = W // 32; K0 = 27; K0p = 32
     x = rs.normal(size=(K0, 32))                      # gamma(x)^T, 32 points
     W1, b1 = rs.normal(size=(W, K0 + 5)), rs.normal(size=W)   # uses columns 5.. (col0 offset like the skip layer)
     W2, b2 = rs.normal(size=(W, W)), rs.normal(size=W)
-    Hs = np.zeros(32 * W)
-    for m in range(32):                                # encode(): element k of point m
+    W3, b3 = rs.normal(size=(32, W)), rs.normal(size=32)      # narrower output (view branch: NTO != NTI)
+    T = np.zeros(32 * 64)
+    for m in range(32):                                # encode(): element k of point m, tile rows are 64 floats
         for k in range(K0p):
-            Hs[hs_off(W, m, k >> 2) + (k & 3)] = x[k, m] if k < K0 else 0.0
-    acc = gemm_seg(init_bias(b1, nt), pack_panel(W1, 5, W, K0), Hs, W, K0p // 8, nt)
+            T[hs_off(64, m, k >> 2) + (k & 3)] = x[k, m] if k < K0 else 0.0
+    for m in range(32):                                # the XOR addressing used by gemm_lds
+        for hh in range(2):
+            for kg in range(8):
+                assert enc_byte_off(m, hh, kg) == 4 * hs_off(64, m, 2 * kg + hh)
+    P1 = pack_bias_group(pack_panel(W1, 5, W, K0), b1)
+    acc = [np.zeros((64, 16)) for _ in range(nt)]
+    for kg in range(K0p // 8):
+        b4 = np.stack([T[enc_byte_off(m, hh, kg) // 4: enc_byte_off(m, hh, kg) // 4 + 4] for m, hh in zip(I31, HH)])
+        for t in range(nt):
+            a4 = a_piece(P1, kg, t)
+            for j in range(4):
+                acc[t] = mfma_32x32x2(a4[:, j], b4[:, j], acc[t])
+    acc = bias_step(acc, P1, K0p // 8, nt)
     h1 = np.maximum(W1[:, 5:] @ x + b1[:, None], 0)
-    assert np.allclose(np.maximum(acc_to_dense(acc, nt), 0), h1)
-    for t in range(nt):
-        acc[t] = np.maximum(acc[t], 0)
-    lds_store_tile(Hs, W, acc, nt)
-    acc2 = gemm_seg(init_bias(b2, nt), pack_panel(W2, 0, W, W), Hs, W, W // 8, nt)
-    assert np.allclose(acc_to_dense(acc2, nt), W2 @ h1 + b2[:, None])
+    X = [np.maximum(a, 0) for a in acc]                # relu_bits: in place on the registers
+    assert np.allclose(acc_to_dense(X, nt), h1)
+    P2 = pack_bias_group(pack_panel(W2, 0, W, W), b2)
+    Y = bias_step(gemm_reg(P2, X, nt, nt), P2, W // 8, nt)
+    h2 = np.maximum(W2 @ h1 + b2[:, None], 0)
+    Y = [np.maximum(a, 0) for a in Y]
+    assert np.allclose(acc_to_dense(Y, nt), h2)
+    P3 = pack_bias_group(pack_panel(W3, 0, 32, W), b3)
+    V = bias_step(gemm_reg(P3, Y, nt, 1), P3, W // 8, 1)
+    assert np.allclose(acc_to_dense(V, 1), W3 @ h2 + b3[:, None])
+
+
+def test_relu_sign_bit_words():
+    """relu_bits / mask_bits (mlp_common.hpp): element (tile t, register r) of a lane -> bit 31 - (16*(t&1) + r) of
+    dword t>>1 (15 - r when the last dword holds a single tile); mask_bits consumes them MSB first in the same
+    element order."""
+    rs = np.random.RandomState(5)
+    for nt in (1, 2, 4, 8):
+        x = rs.normal(size=(nt, 16))
+        words = [0] * ((nt + 1) // 2)
+        for t in range(nt):                              # v_cmp + v_addc: bits = 2*bits + (x > 0)
+            for r in range(16):
+                words[t >> 1] = ((words[t >> 1] << 1) | int(x[t, r] > 0)) & 0xffffffff
+        for t in range(nt):
+            single = (nt & 1) and (t >> 1) == nt >> 1
+            for r in range(16):
+                pos = (15 - r) if single else 31 - (16 * (t & 1) + r)
+                assert (words[t >> 1] >> pos) & 1 == int(x[t, r] > 0)
+        w = list(words)
+        if nt & 1:
+            w[nt >> 1] = (w[nt >> 1] << 16) & 0xffffffff
+        g = np.ones((nt, 16))
+        for t in range(nt):                              # v_add_co (carry = top bit) + v_cndmask
+            for r in range(16):
+                carry = w[t >> 1] >> 31
+                w[t >> 1] = (w[t >> 1] << 1) & 0xffffffff
+                g[t, r] = g[t, r] if carry else 0.0
+        assert np.array_equal(g, (x > 0).astype(np.float64))
 
 
 def test_lds_swizzle_is_conflict_free():
@@ -130,7 +181,7 @@ def test_lds_swizzle_is_conflict_free():
     (bank slot = (byte_addr/16) % 16).  Same for the 8-lane groups of ds_write_b128."""
     groups_r = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27],
                 [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
-    for W in (64, 128, 256):
+    for W in (64,):                                     # the encoding tiles: 32 points x 64 floats
         for c in range(W // 4):
             for g in groups_r:
                 slots = {(hs_off(W, m, c) // 4) % 16 for m in g}
@@ -144,17 +195,19 @@ def test_lds_swizzle_is_conflict_free():
 
 
 def test_dgrad_transposed_panel():
-    """mlp_bwd.hip: dIn^T[K x 32] = W^T . dZ^T with the transposed panel as the A operand."""
+    """mlp_bwd.hip: dIn^T[K x 32] = W^T . dZ^T with the transposed panel as the A operand and the gradient's
+    C-layout registers as B."""
     rs = np.random.RandomState(2)
     N, K = 64, 96                                       # W is [N out, K in]; dgrad contracts over n
     Wm, dZ = rs.normal(size=(N, K + 3)), rs.normal(size=(N, 32))
-    Wd = 96
-    Hs = np.zeros(32 * Wd)
-    for m in range(32):
-        for n in range(N):
-            Hs[hs_off(Wd, m, n >> 2) + (n & 3)] = dZ[n, m]
+    X = []
+    for t in range(N // 32):                            # dZ in C layout: lane (m, hh), reg r <-> n = 32t + 8(r>>2) + 4hh + (r&3)
+        a = np.zeros((64, 16))
+        for r in range(16):
+            a[:, r] = dZ[32 * t + (r & 3) + 8 * (r >> 2) + 4 * HH, I31]
+        X.append(a)
     PT = pack_panel_t(Wm, 3, N, K)                     # [N/8][Kp][8]
-    acc = gemm_seg([np.zeros((64, 16)) for _ in range(K // 32)], PT, Hs, Wd, N // 8, K // 32)
+    acc = gemm_reg(PT, X, N // 32, K // 32)
     assert np.allclose(acc_to_dense(acc, K // 32), Wm[:, 3:].T @ dZ)
 
 
