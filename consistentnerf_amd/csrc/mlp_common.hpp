@@ -238,7 +238,9 @@ __device__ __forceinline__ void mask_bits(f32x16 (&Q)[NT], unsigned (&bits)[(NT 
 }
 
 // 32-feature-tile stores of C-layout registers into a point-major row block, as a `side` functor of the GEMMs:
-// 4*NTI stores (tile i>>2, quad i&3), one behind each MFMA of row j = 1 of the first ceil(4*NTI/NTO) K-groups.
+// 4*NTI stores (tile i>>2, quad i&3), ONE PER K-GROUP (the GEMM has exactly 4*NTI groups).  Spreading matters:
+// vmcnt retires in order, stores included, so the A-operand loads issued behind a burst of stores cannot be consumed
+// before the whole burst is acknowledged (measured: 8 stores per group in the first 4 groups cost the forward 12 %).
 // `voff` = (this point's row + 4*hh floats) in bytes relative to the resource base, `soff` = block column in bytes.
 template <int NTI, int NTO>
 struct TileStores {
@@ -246,9 +248,11 @@ struct TileStores {
   rsrc_t rs;
   int voff, soff;
   __device__ __forceinline__ void operator()(int kg, int j, int t) const {
-    if (j != 1) return;
-    const int i = kg * NTO + t;
-    if (i >= 4 * NTI) return;
+    if (j != 1 || t != 0) return;
+#if defined(CN_EXP) && (CN_EXP & 32)     // ablation 32: no tile stores
+    if (kg >= 0) return;
+#endif
+    const int i = kg;
     const int tt = i >> 2, q = i & 3;
     buf_store(rs, voff, soff + (32 * tt + 8 * q) * 4, f32x4{X[tt][4 * q], X[tt][4 * q + 1], X[tt][4 * q + 2], X[tt][4 * q + 3]});
   }

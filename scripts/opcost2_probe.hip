@@ -9,11 +9,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-enum { NONE = 0, G_V64 = 1, G_SADDR = 2, B_OFFEN = 3, B_TID = 4, B_LDS = 5, DS128 = 6, B_OFF = 7 };
+enum { NONE = 0, G_V64 = 1, G_SADDR = 2, B_OFFEN = 3, B_TID = 4, B_LDS = 5, DS128 = 6, B_OFF = 7, B_STORE = 8, B_STORE_LD = 9, DS_WRITE = 10 };
 
 template <int KIND, int N>
 __global__ __launch_bounds__(256) void probe(float* out, unsigned long long* cyc, const float* wts, int iters, float a,
-                                             float b) {
+                                             float b, float* big) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < 16384; i += 256) lds[i] = i * 1e-4f;
@@ -39,6 +39,13 @@ __global__ __launch_bounds__(256) void probe(float* out, unsigned long long* cyc
     rsrc = i32x4{lo, hi & 0xffff, (int)0x7fffffff, 0x00027000};
     rsrc_tid = i32x4{lo, (hi & 0xffff) | (16 << 16), (int)0x7fffffff, 0x00027000 | (1 << 23)};
   }
+  i32x4 orsrc;   // this wave's private 32 MiB slice of the output buffer (streaming writes, like the stash)
+  {
+    const unsigned long long ba = (unsigned long long)(big + ((size_t)blockIdx.x * 4 + w) * (8u << 20));
+    const int lo = __builtin_amdgcn_readfirstlane((int)(ba & 0xffffffffu));
+    const int hi = __builtin_amdgcn_readfirstlane((int)(ba >> 32));
+    orsrc = i32x4{lo, hi & 0xffff, (int)0x7fffffff, 0x00027000};
+  }
   const unsigned ldsaddr = (unsigned)(size_t)(lds) + w * 16384 + lane * 16;   // LDS byte address of this lane's slot
   const unsigned long long t0 = __builtin_readcyclecounter();
   for (int i = 0; i < iters; ++i) {
@@ -58,6 +65,9 @@ __global__ __launch_bounds__(256) void probe(float* out, unsigned long long* cyc
           if (KIND == B_TID) asm volatile("buffer_load_dwordx4 %0, off, %1, %2 offset:%3" : "=v"(sink[s]) : "s"(rsrc_tid), "s"(so), "n"(s * 128));
           if (KIND == B_OFF) asm volatile("buffer_load_dwordx4 %0, off, %1, %2 offset:%3" : "=v"(sink[s]) : "s"(rsrc), "s"(so), "n"(s * 128));
           if (KIND == B_LDS) asm volatile("buffer_load_dword %0, %1, %2 offen offset:%3 lds" ::"v"(voff / 4), "s"(rsrc), "s"(so), "n"(s * 128) : "memory");
+          if (KIND == B_STORE || (KIND == B_STORE_LD && (s & 1))) asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:%4" ::"v"(sink[s]), "v"(voff), "s"(orsrc), "s"(so + (unsigned)(i >> 4) * 262144u), "n"(s * 128) : "memory");
+          if (KIND == B_STORE_LD && !(s & 1)) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=v"(sink[s]) : "v"(voff), "s"(rsrc), "s"(so), "n"(s * 128));
+          if (KIND == DS_WRITE) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(ldsaddr), "v"(sink[s]), "n"(s * 1024) : "memory");
           if (KIND == DS128) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(sink[s]) : "v"(ldsaddr), "n"(s * 1024));
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -72,13 +82,14 @@ __global__ __launch_bounds__(256) void probe(float* out, unsigned long long* cyc
   if (lane == 0) cyc[blockIdx.x * 4 + w] = t1 - t0;
 }
 
+static float* g_big;
 template <int KIND, int N>
 void run(const char* name, float* out, unsigned long long* cyc, const float* wts) {
   const int blocks = 256, iters = 2000;
   (void)hipFuncSetAttribute((const void*)probe<KIND, N>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
   std::vector<unsigned long long> h(blocks * 4);
   for (int rep = 0; rep < 2; ++rep) {
-    hipLaunchKernelGGL((probe<KIND, N>), dim3(blocks), dim3(256), 128 * 1024, 0, out, cyc, wts, iters, 1e-3f, 1e-3f);
+    hipLaunchKernelGGL((probe<KIND, N>), dim3(blocks), dim3(256), 128 * 1024, 0, out, cyc, wts, iters, 1e-3f, 1e-3f, g_big);
     if (hipDeviceSynchronize() != hipSuccess) { printf("%s N=%d: launch failed\n", name, N); return; }
   }
   (void)hipMemcpy(h.data(), cyc, blocks * 4 * 8, hipMemcpyDeviceToHost);
@@ -93,6 +104,10 @@ int main(int argc, char** argv) {
   float *out, *wts; unsigned long long* cyc;
   (void)hipMalloc(&out, 256 * 256 * 4); (void)hipMalloc(&cyc, 256 * 4 * 8);
   (void)hipMalloc(&wts, 4 * 65536 * 4 + 65536); (void)hipMemset(wts, 0, 4 * 65536 * 4 + 65536);
+  (void)hipMalloc(&g_big, (size_t)1024 * (32u << 20));   // 32 GiB: 1024 waves x 32 MiB
+  if (which < 0 || which == B_STORE) { run<B_STORE, 1>("buffer store", out, cyc, wts); run<B_STORE, 2>("buffer store", out, cyc, wts); run<B_STORE, 4>("buffer store", out, cyc, wts); run<B_STORE, 8>("buffer store", out, cyc, wts); }
+  if (which < 0 || which == B_STORE_LD) { run<B_STORE_LD, 4>("store+load", out, cyc, wts); run<B_STORE_LD, 8>("store+load", out, cyc, wts); run<B_STORE_LD, 16>("store+load", out, cyc, wts); }
+  if (which < 0 || which == DS_WRITE) { run<DS_WRITE, 4>("ds_write_b128", out, cyc, wts); run<DS_WRITE, 8>("ds_write_b128", out, cyc, wts); }
   if (which < 0 || which == NONE) run<NONE, 0>("none", out, cyc, wts);
   if (which < 0 || which == G_V64) { run<G_V64, 4>("global v64", out, cyc, wts); run<G_V64, 8>("global v64", out, cyc, wts); run<G_V64, 16>("global v64", out, cyc, wts); }
   if (which < 0 || which == G_SADDR) { run<G_SADDR, 4>("global saddr", out, cyc, wts); run<G_SADDR, 8>("global saddr", out, cyc, wts); run<G_SADDR, 16>("global saddr", out, cyc, wts); }
