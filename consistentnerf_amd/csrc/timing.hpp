@@ -13,7 +13,7 @@ static __device__ unsigned long long cn_tbuf[CN_TSLOTS * 65536];   // one per tr
   unsigned long long t_acc[6] = {0, 0, 0, 0, 0, 0};                                       \
   unsigned long long t_ev[30];                                                          \
   int t_n = 0;                                                                          \
-  const unsigned t_slot = blockIdx.x * (WPB) + (threadIdx.x >> 6);                      \
+  const unsigned t_slot = (blockIdx.y * gridDim.x + blockIdx.x) * (WPB) + (threadIdx.x >> 6);                      \
   const unsigned long long t_rt0 = wall_clock64();                                      \
   unsigned long long t_last = __builtin_readcyclecounter();                             \
   const unsigned long long t_begin = t_last;

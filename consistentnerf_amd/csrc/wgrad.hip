@@ -3,13 +3,16 @@
 // Y = that layer's input (columns of the point-major stash[Mp][s_rows]).  GEMMs on v_mfma_f32_32x32x2_f32 whose
 // contraction runs over up to ~10^6 points.
 //
-// A workgroup (4 waves, one per SIMD) owns one GEMM's whole (<=256 x <=256) output and one of `nsplit` point
-// ranges.  The 4 waves tile the output as a gn x gk grid chosen per GEMM so that all four have work
-// (256x256 -> 2x2 waves of 4x4 MFMA tiles; 128x256 -> 4x2 tiles each; 256x64 -> 2x2 each; 1x256 -> 1x2 ...).
-// Operands move HBM -> LDS by DMA (`global_load_lds_dwordx4`, no VGPR staging): a 32-point slab of X is
-// 32 x (N*4 B) contiguous pieces that land as the LDS image Xs[m][n]; the MFMA A operand of step s is then the
-// conflict-free `ds_read_b32` Xs[2s+hh][32x + lane&31] (B likewise from Ys).  Two LDS buffers: the DMA of slab
-// s+1 runs under the 16 steps x (an x ak) MFMAs of slab s; one barrier per slab.
+// A workgroup (4 waves, one per SIMD, <= 512 registers each) owns one GEMM's whole (<=256 x <=256) output and one of
+// `nsplit` point ranges.  The 4 waves tile the output as a gn x gk grid chosen per GEMM so that all four have work
+// (256x256 -> 2x2 waves of 4x4 MFMA tiles; 128x256 -> 2x4 tiles each; 256x64 -> 2x2 each; 4x256 -> 1x2 ...).
+// Operands move HBM -> LDS by DMA (buffer_load ... lds, 16 bytes per lane, no VGPR staging, scalar addressing: one
+// instruction per point row, so the LDS image is Xs[m][256] whatever the operand's width); the MFMA A operand of
+// step s is the `ds_read_b32` Xs[2s+hh][32x + lane&31] (B likewise from Ys) at an IMMEDIATE offset from one
+// per-lane base.  The inner loop is VALU-free apart from the bias column sums: fp32 MFMA and the VALU share the
+// SIMD's datapath (mlp_common.hpp), every VALU instruction is MFMA time lost.  Reads run one step ahead of the
+// MFMAs that consume them (sched_barriers pin the order).  Two LDS buffers: the DMA of slab s+1 runs under the
+// 16 steps x (an x ak) MFMAs of slab s; one barrier per slab.
 // GEMMs are launched largest-first over many small point ranges so the tail of the grid is short; split
 // partials are reduced in a fixed order by a second kernel (bit-reproducible run to run).
 #include "mlp_common.hpp"
@@ -17,9 +20,10 @@
 namespace {
 
 constexpr int MAX_WG_JOBS = 48;
-constexpr int NWAVES = 8;                   // waves per workgroup (2 per SIMD)
+constexpr int NWAVES = 4;                   // waves per workgroup (1 per SIMD)
 constexpr int TM = 32;                      // points per LDS slab
-constexpr int TILE_FLOATS = TM * 256;       // one operand slab at full width
+constexpr int ROWF = 256;                   // floats per LDS row (one point of one operand)
+constexpr int TILE_FLOATS = TM * ROWF;      // one operand slab
 
 struct WgJob {
   int xcol, ycol;     // first column of X in G rows, of Y in stash rows
@@ -29,7 +33,6 @@ struct WgJob {
   int ld, col0;       // its row stride and first column
   int bias_tensor;    // -1: none
   int gk, an, ak;     // wave grid: wave w -> (wn, wk) = (w / gk, w % gk) owns an x ak tiles of 32x32
-  int lgx, lgy;       // log2 of the LDS row length (floats) of the X / Y slab = log2(32 * #tiles)
 };
 
 struct WgArgs {
@@ -43,37 +46,51 @@ struct WgArgs {
   int s_rows, g_rows;
 };
 
-typedef __attribute__((address_space(3))) void* lds_ptr;
-typedef const __attribute__((address_space(1))) void* glb_ptr;
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-// DMA one operand slab: TM points x RL=2^lg floats, global rows `stride` floats apart, into lds[m][RL].
-// A wave-instruction moves 1 KiB (lane l -> floats 4l..4l+3 of a 256-float chunk); chunks round-robin over waves.
-__device__ __forceinline__ void dma_slab(const float* __restrict__ src, int64_t stride, int lg, float* dst, int wv,
-                                         int lane) {
-  const int nchunk = (TM << lg) >> 8;
-  const int e0 = 4 * lane;
-  for (int c = wv; c < nchunk; c += NWAVES) {
-    const int e = (c << 8) + e0;
-    const int pt = e >> lg, col = e & ((1 << lg) - 1);
-    __builtin_amdgcn_global_load_lds((glb_ptr)(src + (int64_t)pt * stride + col), (lds_ptr)(dst + (c << 8)), 16, 0, 0);
-  }
+// One LDS-DMA instruction: 64 lanes x 16 bytes from (resource + voff + soff) to LDS bytes [lds_addr, +1 KiB), lane
+// linear.  Inline asm on purpose: through the builtin the compiler treats every later ds_read as possibly aliasing
+// the DMA target and drains vmcnt inside the first MFMA step of each slab — i.e. it waits for the prefetch of the
+// NEXT slab — which serialises the double buffering.  Completion is awaited explicitly (vmcnt(0)) before the
+// barrier that publishes the slab.
+__device__ __forceinline__ void dma16(const i32x4& rs, unsigned lds_addr, int voff, int soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :
+               : "s"(__builtin_amdgcn_readfirstlane((int)lds_addr)), "v"(voff), "s"(rs),
+                 "s"(__builtin_amdgcn_readfirstlane(soff))
+               : "memory");
+}
+__device__ __forceinline__ i32x4 dma_rsrc(const float* base, unsigned bytes) {
+  const unsigned long long ba = (unsigned long long)base;
+  return i32x4{__builtin_amdgcn_readfirstlane((int)(ba & 0xffffffffu)),
+               __builtin_amdgcn_readfirstlane((int)((ba >> 32) & 0xffff)), __builtin_amdgcn_readfirstlane((int)bytes),
+               0x00027000};
 }
 
-// Body for a compile-time per-wave tile block AN x AK (<= 4 x 4): straight-line MFMA steps the compiler can
-// software-pipeline (runtime tile-count guards inside the step loop fragment it into one basic block per MFMA).
-template <int AN, int AK>
+// Body for a compile-time per-wave tile block AN x AK (<= 4 x 4); BS: this wave also sums the X columns (bias).
+template <int AN, int AK, bool BS>
 __device__ __forceinline__ void wgrad_body(const WgArgs& a, const WgJob& jb, float* lds) {
   const int split = blockIdx.x;
-  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, i31 = lane & 31, hh = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, i31 = lane & 31, hh = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform on the scalar unit: addresses stay SALU
   const int wn = wv / jb.gk, wk = wv - wn * jb.gk;
+  // (the by-value argument struct is indexed dynamically, so it lives in scratch: anything the slab loop needs is
+  // pulled into SGPRs here — a scratch_load inside the loop would also drain vmcnt, i.e. wait for the DMA in flight)
+  const int g_rows4 = __builtin_amdgcn_readfirstlane(a.g_rows * 4), s_rows4 = __builtin_amdgcn_readfirstlane(a.s_rows * 4);
   const int64_t m_begin = (int64_t)split * a.chunk;
   const int64_t m_end = m_begin + a.chunk < a.Mp ? m_begin + a.chunk : a.Mp;
-  const float* X = a.G + jb.xcol;
-  const float* Y = a.stash + jb.ycol;
+  const int nslab = __builtin_amdgcn_readfirstlane(m_end > m_begin ? (int)((m_end - m_begin) / TM) : 0);
   const int ntn = (jb.N + 31) >> 5, ntk = (jb.K + 31) >> 5;
   const int tn0 = wn * AN, tk0 = wk * AK;          // first n / k tile of this wave
-  const bool active = tn0 < ntn && tk0 < ntk;      // wave-uniform (tile counts are powers of two: all-or-nothing)
-  const int RLx = 1 << jb.lgx, RLy = 1 << jb.lgy;
+  const bool active = tn0 < ntn && tk0 < ntk;      // wave-uniform
+  // this split's rows of the two operands behind buffer resources; a lane past the operand's width reads out of
+  // range (zeros land in the unused columns of the LDS row)
+  const i32x4 xr = dma_rsrc(a.G + m_begin * a.g_rows + jb.xcol, (unsigned)((m_end - m_begin) * a.g_rows * 4));
+  const i32x4 yr = dma_rsrc(a.stash + m_begin * a.s_rows + jb.ycol, (unsigned)((m_end - m_begin) * a.s_rows * 4));
+  const unsigned lds0 = (unsigned)(size_t)lds;
+  const int vox = lane * 4 < ntn * 32 ? lane * 16 : 0x7ffffff0;
+  const int voy = lane * 4 < ntk * 32 ? lane * 16 : 0x7ffffff0;
+  CN_TINIT(NWAVES)
   f32x16 acc[AN][AK];
 #pragma unroll
   for (int x = 0; x < AN; ++x)
@@ -85,46 +102,72 @@ __device__ __forceinline__ void wgrad_body(const WgArgs& a, const WgJob& jb, flo
 #pragma unroll
   for (int x = 0; x < AN; ++x) bsum[x] = 0.f;
 
-  auto issue = [&](int64_t m0, int buf) {
-    float* b = lds + buf * 2 * TILE_FLOATS;
-    dma_slab(X + m0 * a.g_rows, a.g_rows, jb.lgx, b, wv, lane);
-    dma_slab(Y + m0 * a.s_rows, a.s_rows, jb.lgy, b + TILE_FLOATS, wv, lane);
+  // DMA of slab `sl` into buffer `buf`: point rows round-robin over the waves, 2 x 8 instructions per wave; piece i
+  // (0..15) is row wv + 4*(i>>1) of X (i even) or Y (i odd).  A slab past the end reads out of range (zeros).
+  auto piece = [&](int sl, int buf, int i) __attribute__((always_inline)) {
+    const unsigned b = lds0 + (unsigned)(buf * 2 * TILE_FLOATS * 4);
+    const int r = wv + NWAVES * (i >> 1);
+    const int row = sl < nslab ? sl * TM + r : 0x100000;
+    if (i & 1) dma16(yr, b + (TILE_FLOATS + r * ROWF) * 4, voy, row * s_rows4);
+    else dma16(xr, b + r * ROWF * 4, vox, row * g_rows4);
+  };
+  auto issue = [&](int sl, int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2 * TM / NWAVES; ++i) piece(sl, buf, i);
   };
 
-  int cur = 0;
-  if (m_begin < m_end) {
-    issue(m_begin, 0);
+  if (nslab > 0) {
+    issue(0, 0);
     __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's DMA pieces have landed
     __syncthreads();
   }
-  for (int64_t m0 = m_begin; m0 < m_end; m0 += TM) {
-    if (m0 + TM < m_end) issue(m0 + TM, cur ^ 1);   // other buffer: all its readers passed the previous barrier
-    if (active) {
-      const float* Xs = lds + cur * 2 * TILE_FLOATS + 32 * tn0 + i31 + hh * RLx;
-      const float* Ys = lds + cur * 2 * TILE_FLOATS + TILE_FLOATS + 32 * tk0 + i31 + hh * RLy;
-#pragma unroll 4
-      for (int st = 0; st < TM / 2; ++st) {
-        float av[AN], bv[AK];
-#pragma unroll
-        for (int x = 0; x < AN; ++x) av[x] = Xs[2 * st * RLx + 32 * x];
-#pragma unroll
-        for (int y = 0; y < AK; ++y) bv[y] = Ys[2 * st * RLy + 32 * y];
-        if (wk == 0) {
-#pragma unroll
-          for (int x = 0; x < AN; ++x) bsum[x] += av[x];
-        }
-#pragma unroll
-        for (int x = 0; x < AN; ++x)
-#pragma unroll
-          for (int y = 0; y < AK; ++y) acc[x][y] = mfma(av[x], bv[y], acc[x][y]);
-      }
+  CN_T(0)
+  if (!active) {   // idle wave of a narrow GEMM: it still moves its share of the slabs and meets the barriers
+    for (int sl = 0; sl < nslab; ++sl) {
+      if (sl + 1 < nslab) issue(sl + 1, (sl & 1) ^ 1);
+      __builtin_amdgcn_s_waitcnt(0x0f70);
+      __syncthreads();
     }
-    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0) before the barrier publishes the next slab
-    __syncthreads();
-    cur ^= 1;
+    return;
   }
-  if (!active) return;
-
+  for (int sl = 0; sl < nslab; ++sl) {
+    const int cur = sl & 1;
+    const float* Xs = lds + cur * 2 * TILE_FLOATS + hh * ROWF + 32 * tn0 + i31;
+    const float* Ys = lds + cur * 2 * TILE_FLOATS + TILE_FLOATS + hh * ROWF + 32 * tk0 + i31;
+    float av[2][AN], bv[2][AK];
+    auto rd = [&](int st, int o) __attribute__((always_inline)) {
+#pragma unroll
+      for (int x = 0; x < AN; ++x) av[o][x] = Xs[2 * st * ROWF + 32 * x];
+#pragma unroll
+      for (int y = 0; y < AK; ++y) bv[o][y] = Ys[2 * st * ROWF + 32 * y];
+    };
+    rd(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int st = 0; st < TM / 2; ++st) {
+      const int o = st & 1;
+      if (st + 1 < TM / 2) rd(st + 1, o ^ 1);
+      // one piece of the NEXT slab's DMA per step (other buffer: all its readers passed the previous barrier).  In a
+      // burst, the 16 KiB a wave requests exceed what the memory pipeline accepts at once and the in-order wave sits in
+      // the issue queue instead of feeding the MFMA pipe (measured: 25 % of the kernel).
+      piece(sl + 1, cur ^ 1, st);
+      __builtin_amdgcn_sched_barrier(0);
+      if (BS) {
+#pragma unroll
+        for (int x = 0; x < AN; ++x) bsum[x] += av[o][x];
+      }
+#pragma unroll
+      for (int x = 0; x < AN; ++x)
+#pragma unroll
+        for (int y = 0; y < AK; ++y) acc[x][y] = mfma(av[o][x], bv[o][y], acc[x][y]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    CN_T(2)
+    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0) before the barrier publishes the next slab
+    CN_T(3)
+    __syncthreads();
+    CN_T(1)
+  }
   float* out = a.partials + (int64_t)split * a.pstride;
   float* Wout = out + a.toff[jb.tensor];
 #pragma unroll
@@ -138,7 +181,9 @@ __device__ __forceinline__ void wgrad_body(const WgArgs& a, const WgJob& jb, flo
         if (n >= jb.n_lo && n < jb.N && k < jb.K) Wout[(int64_t)(n - jb.n_lo) * jb.ld + jb.col0 + k] = acc[x][y][r];
       }
     }
-  if (jb.bias_tensor >= 0 && wk == 0) {
+  CN_T(0)
+  CN_TEND
+  if (BS) {
     float* Bout = out + a.toff[jb.bias_tensor];
 #pragma unroll
     for (int x = 0; x < AN; ++x) {
@@ -149,18 +194,26 @@ __device__ __forceinline__ void wgrad_body(const WgArgs& a, const WgJob& jb, flo
   }
 }
 
-__global__ __launch_bounds__(64 * NWAVES, 2) void wgrad_k(WgArgs a) {
+template <int AN, int AK>
+__device__ __forceinline__ void wgrad_disp(const WgArgs& a, const WgJob& jb, float* lds) {
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (jb.bias_tensor >= 0 && wv % jb.gk == 0) wgrad_body<AN, AK, true>(a, jb, lds);
+  else wgrad_body<AN, AK, false>(a, jb, lds);
+}
+
+__global__ __launch_bounds__(64 * NWAVES) void wgrad_k(WgArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];   // [2 buffers][X slab | Y slab]
   const WgJob& jb = a.job[blockIdx.y];
   switch (jb.an * 8 + jb.ak) {     // block-uniform
-    case 4 * 8 + 2: wgrad_body<4, 2>(a, jb, lds); break;
-    case 2 * 8 + 4: wgrad_body<2, 4>(a, jb, lds); break;
-    case 4 * 8 + 1: wgrad_body<4, 1>(a, jb, lds); break;
-    case 1 * 8 + 4: wgrad_body<1, 4>(a, jb, lds); break;
-    case 2 * 8 + 2: wgrad_body<2, 2>(a, jb, lds); break;
-    case 2 * 8 + 1: wgrad_body<2, 1>(a, jb, lds); break;
-    case 1 * 8 + 2: wgrad_body<1, 2>(a, jb, lds); break;
-    default: wgrad_body<1, 1>(a, jb, lds); break;
+    case 4 * 8 + 4: wgrad_disp<4, 4>(a, jb, lds); break;
+    case 4 * 8 + 2: wgrad_disp<4, 2>(a, jb, lds); break;
+    case 2 * 8 + 4: wgrad_disp<2, 4>(a, jb, lds); break;
+    case 4 * 8 + 1: wgrad_disp<4, 1>(a, jb, lds); break;
+    case 1 * 8 + 4: wgrad_disp<1, 4>(a, jb, lds); break;
+    case 2 * 8 + 2: wgrad_disp<2, 2>(a, jb, lds); break;
+    case 2 * 8 + 1: wgrad_disp<2, 1>(a, jb, lds); break;
+    case 1 * 8 + 2: wgrad_disp<1, 2>(a, jb, lds); break;
+    default: wgrad_disp<1, 1>(a, jb, lds); break;
   }
 }
 
@@ -189,13 +242,11 @@ __global__ void wgrad_reduce_k(RedArgs a) {
   }
 }
 
-int ilog2(int v) {
-  int l = 0;
-  while ((1 << l) < v) ++l;
-  return l;
-}
-
 }  // namespace
+
+#ifdef CN_TIMING
+CN_TIMING_ACCESSOR(cnerf_debug_timing_wgrad)
+#endif
 
 int64_t cn_param_floats(const NetGeom& g) {
   cnerf_net net{g.D, g.W, g.L, g.Ld, g.viewdirs, g.out_ch, g.skip};
@@ -248,15 +299,13 @@ int cn_wgrad_launch(const NetGeom& g, const float* stash, const float* G, int64_
     for (int gn = 1; gn <= NWAVES; gn *= 2) {
       const int gk = NWAVES / gn;
       const int an = (ntn + gn - 1) / gn, ak = (ntk + gk - 1) / gk;
-      if (an > 4 || ak > 4 || an * ak > 8) continue;   // <= 128 accumulator registers per wave
+      if (an > 4 || ak > 4) continue;                  // <= 256 accumulator registers per wave
       const int cost = an * ak * 16 + an + ak;
       if (cost < best_cost) { best_cost = cost; best_gk = gk; best_an = an; best_ak = ak; }
     }
-    const int lgx = ilog2(ntn * 32), lgy = ilog2(ntk * 32);
-    // slab rows are DMA'd as 2^lg floats: the tile count must be a power of two and the slab a multiple of 1 KiB
-    if (best_gk == 0 || (1 << lgx) != ntn * 32 || (1 << lgy) != ntk * 32 || best_an == 3 || best_ak == 3) ok = false;
+    if (best_gk == 0 || best_an == 3 || best_ak == 3 || ntn > 8 || ntk > 8) ok = false;
     a.job[nj++] = WgJob{xcol, ycol, N, K, n_lo, tensor, ld, col0, bias_tensor, best_gk ? best_gk : 2, best_an,
-                        best_ak, lgx, lgy};
+                        best_ak};
     r.touched[tensor] = 1;
     if (bias_tensor >= 0) r.touched[bias_tensor] = 1;
   };

@@ -9,7 +9,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-enum { NONE = 0, G_V64 = 1, G_SADDR = 2, B_OFFEN = 3, B_TID = 4, B_LDS = 5, DS128 = 6, B_OFF = 7, B_STORE = 8, B_STORE_LD = 9, DS_WRITE = 10 };
+enum { NONE = 0, G_V64 = 1, G_SADDR = 2, B_OFFEN = 3, B_TID = 4, B_LDS = 5, DS128 = 6, B_OFF = 7, B_STORE = 8, B_STORE_LD = 9, DS_WRITE = 10, B_LDS_M0 = 11, B_LDS4 = 12, B_LDS4_M0 = 13, B_LDS4_STREAM = 14, B_OFFEN_STREAM = 15 };
 
 template <int KIND, int N>
 __global__ __launch_bounds__(256) void probe(float* out, unsigned long long* cyc, const float* wts, int iters, float a,
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void probe(float* out, unsigned long long* cyc
   for (int i = 0; i < iters; ++i) {
     const unsigned so = ((i * 16) & 255) * 1024;    // wave-uniform byte offset of this iteration's first load
     const float* sbase = base + so / 4;
-    if (KIND == B_LDS) asm volatile("s_mov_b32 m0, %0" ::"s"(__builtin_amdgcn_readfirstlane((int)(w * 16384 + 32768))));
+    if (KIND == B_LDS || KIND == B_LDS4 || KIND == B_LDS4_STREAM) asm volatile("s_mov_b32 m0, %0" ::"s"(__builtin_amdgcn_readfirstlane((int)(w * 16384 + 32768))));
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -65,6 +65,11 @@ __global__ __launch_bounds__(256) void probe(float* out, unsigned long long* cyc
           if (KIND == B_TID) asm volatile("buffer_load_dwordx4 %0, off, %1, %2 offset:%3" : "=v"(sink[s]) : "s"(rsrc_tid), "s"(so), "n"(s * 128));
           if (KIND == B_OFF) asm volatile("buffer_load_dwordx4 %0, off, %1, %2 offset:%3" : "=v"(sink[s]) : "s"(rsrc), "s"(so), "n"(s * 128));
           if (KIND == B_LDS) asm volatile("buffer_load_dword %0, %1, %2 offen offset:%3 lds" ::"v"(voff / 4), "s"(rsrc), "s"(so), "n"(s * 128) : "memory");
+          if (KIND == B_LDS_M0) asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dword %0, %1, %2 offen offset:%3 lds" ::"v"(voff / 4), "s"(rsrc), "s"(so), "n"(s * 128), "s"(__builtin_amdgcn_readfirstlane((int)(w * 16384 + 32768 + s * 256))) : "memory");
+          if (KIND == B_LDS4) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:%3 lds" ::"v"(voff), "s"(rsrc), "s"(so), "n"((s & 3) * 1024) : "memory");
+          if (KIND == B_LDS4_STREAM) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:%3 lds" ::"v"(voff), "s"(orsrc), "s"((unsigned)i * 16384u + (unsigned)(s >> 2) * 4096u), "n"((s & 3) * 1024) : "memory");
+          if (KIND == B_OFFEN_STREAM) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=v"(sink[s]) : "v"(voff), "s"(orsrc), "s"((unsigned)i * 16384u + (unsigned)(s >> 2) * 4096u), "n"((s & 3) * 1024));
+          if (KIND == B_LDS4_M0) asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen offset:%3 lds" ::"v"(voff), "s"(rsrc), "s"(so), "n"((s & 3) * 1024), "s"(__builtin_amdgcn_readfirstlane((int)(w * 16384 + 32768 + (s & 3) * 1024))) : "memory");
           if (KIND == B_STORE || (KIND == B_STORE_LD && (s & 1))) asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:%4" ::"v"(sink[s]), "v"(voff), "s"(orsrc), "s"(so + (unsigned)(i >> 4) * 262144u), "n"(s * 128) : "memory");
           if (KIND == B_STORE_LD && !(s & 1)) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=v"(sink[s]) : "v"(voff), "s"(rsrc), "s"(so), "n"(s * 128));
           if (KIND == DS_WRITE) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(ldsaddr), "v"(sink[s]), "n"(s * 1024) : "memory");
@@ -115,6 +120,11 @@ int main(int argc, char** argv) {
   if (which < 0 || which == B_OFF) run<B_OFF, 8>("buffer off", out, cyc, wts);
   if (which < 0 || which == B_TID) { run<B_TID, 4>("buffer tid", out, cyc, wts); run<B_TID, 8>("buffer tid", out, cyc, wts); run<B_TID, 16>("buffer tid", out, cyc, wts); }
   if (which < 0 || which == B_LDS) { run<B_LDS, 8>("buffer->lds", out, cyc, wts); run<B_LDS, 16>("buffer->lds", out, cyc, wts); }
+  if (which < 0 || which == B_LDS_M0) { run<B_LDS_M0, 8>("buf->lds m0 each", out, cyc, wts); run<B_LDS_M0, 16>("buf->lds m0 each", out, cyc, wts); }
+  if (which < 0 || which == B_LDS4) { run<B_LDS4, 4>("buf->lds x4", out, cyc, wts); run<B_LDS4, 8>("buf->lds x4", out, cyc, wts); run<B_LDS4, 16>("buf->lds x4", out, cyc, wts); }
+  if (which < 0 || which == B_LDS4_M0) { run<B_LDS4_M0, 4>("buf->lds x4 m0 each", out, cyc, wts); run<B_LDS4_M0, 8>("buf->lds x4 m0 each", out, cyc, wts); run<B_LDS4_M0, 16>("buf->lds x4 m0 each", out, cyc, wts); }
+  if (which < 0 || which == B_LDS4_STREAM) { run<B_LDS4_STREAM, 1>("lds-dma x4 stream", out, cyc, wts); run<B_LDS4_STREAM, 2>("lds-dma x4 stream", out, cyc, wts); run<B_LDS4_STREAM, 4>("lds-dma x4 stream", out, cyc, wts); run<B_LDS4_STREAM, 8>("lds-dma x4 stream", out, cyc, wts); }
+  if (which < 0 || which == B_OFFEN_STREAM) { run<B_OFFEN_STREAM, 1>("vgpr load stream", out, cyc, wts); run<B_OFFEN_STREAM, 2>("vgpr load stream", out, cyc, wts); run<B_OFFEN_STREAM, 4>("vgpr load stream", out, cyc, wts); run<B_OFFEN_STREAM, 8>("vgpr load stream", out, cyc, wts); }
   if (which < 0 || which == DS128) { run<DS128, 4>("ds_read_b128", out, cyc, wts); run<DS128, 8>("ds_read_b128", out, cyc, wts); run<DS128, 16>("ds_read_b128", out, cyc, wts); }
   return 0;
 }
