@@ -46,7 +46,7 @@ __global__ __launch_bounds__(64) void mlp_dgrad_k(BwdArgs a) {
   const int gvo = (m * g.g_rows + 4 * hh) * 4;
   const int smo = (m * g.s_rows + hh * MD) * 4;
   f32x16 X[NT], Y[NT];
-  f32x4 a0[NT], a1[NT];   // A-operand sets (even / odd K-groups) of the current transposed panel
+  f32x4 A[3][NT];   // A-operand register sets of the current transposed panel
   unsigned bits[MD];
 
   if (VD) {
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(64) void mlp_dgrad_k(BwdArgs a) {
     const float dc[4] = {d.x, d.y, d.z, d.w};
     unsigned bv[MDV];
     load_bits<MDV>(srs, (m * g.s_rows + hh * MDV) * 4, (g.s_mask + g.s_mb[g.D]) * 4, bv);
-    a_prefetch<NT>(a0, a1, AP, (int)g.t_views, W, g.Wh / 8 - 1);
+    a_prefetch3<NT>(A, AP, (int)g.t_views, W, g.Wh / 8 - 1);
     if (hh == 0) buf_store(grs, m * g.g_rows * 4, g.g_out * 4, f32x4{d.x, d.y, d.z, d.w});
     // rgb_linear^T on the VALU, masked by the view-branch ReLU -> dZv (C-layout registers)
     f32x16 V[NTH];
@@ -75,11 +75,11 @@ __global__ __launch_bounds__(64) void mlp_dgrad_k(BwdArgs a) {
     mask_bits<NTH>(V, bv);
     CN_T(0)
     // dF = views_linears^T (feature columns only; gamma(d) needs no gradient) . dZv, no mask (feature_linear is linear)
-    gemm_reg<NTH, NT, false, true>(X, V, a0, a1, AP, (int)g.t_views, W, hh, TileStores<NTH, NT>{V, grs, gvo, g.g_hv * 4});
+    gemm_reg3<NTH, NT, false, true>(X, V, A, AP, (int)g.t_views, W, hh, TileStores<NTH, NT>{V, grs, gvo, g.g_hv * 4});
     pin<NT>(X);
     CN_T(2)
     // dZ_{D-1} = relu'(h_{D-1}) * (feature_linear^T . dF + alpha_linear^T . dsigma)
-    a_prefetch<NT>(a0, a1, AP, (int)g.t_feat, W, W / 8 - 1);
+    a_prefetch3<NT>(A, AP, (int)g.t_feat, W, W / 8 - 1);
     load_bits<MD>(srs, smo, (g.s_mask + g.s_mb[g.D - 1]) * 4, bits);
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(64) void mlp_dgrad_k(BwdArgs a) {
         for (int j = 0; j < 4; ++j) Y[t][4 * q + j] = w[j] * dc[3];
       }
     CN_T(4)
-    gemm_reg<NT, NT, false, false>(Y, X, a0, a1, AP, (int)g.t_feat, W, hh, TileStores<NT, NT>{X, grs, gvo, g.g_feat * 4});
+    gemm_reg3<NT, NT, false, false>(Y, X, A, AP, (int)g.t_feat, W, hh, TileStores<NT, NT>{X, grs, gvo, g.g_feat * 4});
     CN_T(2)
   } else {
     load_bits<MD>(srs, smo, (g.s_mask + g.s_mb[g.D - 1]) * 4, bits);
@@ -119,15 +119,15 @@ __global__ __launch_bounds__(64) void mlp_dgrad_k(BwdArgs a) {
       }
     CN_T(0)
   }
-  if (g.D > 1) a_prefetch<NT>(a0, a1, AP, (int)g.t_trunk[g.D - 1], W, W / 8 - 1);
+  if (g.D > 1) a_prefetch3<NT>(A, AP, (int)g.t_trunk[g.D - 1], W, W / 8 - 1);
   mask_bits<NT>(Y, bits);
   CN_T(3)
   // trunk: dZ_{l-1} = relu'(h_{l-1}) * (W_l^T . dZ_l) (the gamma(x) columns of the skip layer get no gradient); dZ_l
   // goes out to the workspace while it is the B operand of this GEMM.  X / Y alternate as input and output.
   auto layer = [&](f32x16 (&In)[NT], f32x16 (&Out)[NT], int l) __attribute__((always_inline)) {
     load_bits<MD>(srs, smo, (g.s_mask + g.s_mb[l - 1]) * 4, bits);
-    gemm_reg<NT, NT, false, true>(Out, In, a0, a1, AP, (int)g.t_trunk[l], W, hh, TileStores<NT, NT>{In, grs, gvo, g.g_z[l] * 4});
-    if (l > 1) a_prefetch<NT>(a0, a1, AP, (int)g.t_trunk[l - 1], W, W / 8 - 1);
+    gemm_reg3<NT, NT, false, true>(Out, In, A, AP, (int)g.t_trunk[l], W, hh, TileStores<NT, NT>{In, grs, gvo, g.g_z[l] * 4});
+    if (l > 1) a_prefetch3<NT>(A, AP, (int)g.t_trunk[l - 1], W, W / 8 - 1);
     CN_T(2)
     mask_bits<NT>(Out, bits);
     CN_T(3)

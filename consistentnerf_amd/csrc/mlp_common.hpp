@@ -109,6 +109,16 @@ __device__ __forceinline__ void a_prefetch(f32x4 (&a0)[NTO], f32x4 (&a1)[NTO], c
   a_load<NTO>(a1, P, poff, NP, last < 1 ? last : 1);
 }
 
+// Three-set variant for the register-operand GEMMs (prefetch distance 9*NTO-1 MFMAs): set s holds the groups
+// kg == s (mod 3).  The extra distance is for the training kernels: a load issued behind a stash/gradient store is
+// only consumable once that store is acknowledged (vmcnt is in order), and 2600 cycles do not always cover it.
+template <int NTO>
+__device__ __forceinline__ void a_prefetch3(f32x4 (&A)[3][NTO], const APanel& P, int poff, int NP, int last) {
+  a_load<NTO>(A[0], P, poff, NP, 0);
+  a_load<NTO>(A[1], P, poff, NP, last < 1 ? last : 1);
+  a_load<NTO>(A[2], P, poff, NP, last < 2 ? last : 2);
+}
+
 struct NoSide {
   __device__ __forceinline__ void operator()(int, int, int) const {}
 };
@@ -146,6 +156,35 @@ __device__ __forceinline__ void gemm_reg(f32x16 (&Q)[NTO], const f32x16 (&X)[NTI
     const float one = hh == 0 ? 1.f : 0.f;
 #pragma unroll
     for (int t = 0; t < NTO; ++t) Q[t] = mfma(a0[t][0], one, Q[t]);
+  }
+}
+
+template <int NTI, int NTO, bool BIAS, bool INIT, class Side = NoSide>
+__device__ __forceinline__ void gemm_reg3(f32x16 (&Q)[NTO], const f32x16 (&X)[NTI], f32x4 (&A)[3][NTO], const APanel& P,
+                                          int poff, int NP, int hh, Side side = Side()) {
+  constexpr int KG = 4 * NTI;
+  constexpr int last = BIAS ? KG : KG - 1;
+#pragma unroll
+  for (int kg = 0; kg < KG; ++kg) {
+    f32x4 (&a)[NTO] = A[kg % 3];
+    const int sn = (poff + (kg + 3 < last ? kg + 3 : last) * NP * 8) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float b = X[kg >> 2][4 * (kg & 3) + j];
+#pragma unroll
+      for (int t = 0; t < NTO; ++t) {
+        if (INIT && kg == 0 && j == 0) Q[t] = mfma_z(a[t][j], b);
+        else Q[t] = mfma(a[t][j], b, Q[t]);
+        side(kg, j, t);
+        if (j == 3) a[t] = buf_load(P.rs, P.lane, sn + t * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  if (BIAS) {   // group KG was refilled into set KG % 3 behind group KG-3
+    const float one = hh == 0 ? 1.f : 0.f;
+#pragma unroll
+    for (int t = 0; t < NTO; ++t) Q[t] = mfma(A[KG % 3][t][0], one, Q[t]);
   }
 }
 

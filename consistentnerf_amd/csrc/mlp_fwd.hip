@@ -103,8 +103,8 @@ __global__ __launch_bounds__(64) void mlp_fwd_k(FwdArgs a) {
       v[0] = dsrc[0]; v[1] = dsrc[1]; v[2] = dsrc[2];
     }
   }
-  f32x4 a0[NT], a1[NT];
-  a_prefetch<NT>(a0, a1, AP, (int)g.f_l0, W, g.in_chp / 8);
+  f32x4 A[3][NT];   // A-operand register sets
+  a_prefetch<NT>(A[0], A[1], AP, (int)g.f_l0, W, g.in_chp / 8);
   encode(Tx, x, g.L, g.in_ch, g.in_chp, m, hh, pre);
   if (VD) encode(Td, v, g.Ld, g.dir_ch, g.dir_chp, m, hh, pre != nullptr ? pre + g.in_ch : nullptr);
   if (TRAIN) {
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(64) void mlp_fwd_k(FwdArgs a) {
   f32x16 X[NT], Y[NT];
   unsigned bits[MD];
   // layer 0 (gamma(x) from LDS) -> Y
-  gemm_lds<NT, true, true>(Y, a0, a1, AP, (int)g.f_l0, W, g.in_chp / 8, Tx, m, hh);
+  gemm_lds<NT, true, true>(Y, A[0], A[1], AP, (int)g.f_l0, W, g.in_chp / 8, Tx, m, hh);
   CN_T(2)
   // One W x W layer, l = 1..D-1 trunk, l = D feature_linear (VD): ReLU the input set in place (+ sign bits), queue
   // the panel, GEMM into the other set while the input tiles go out to the stash.  The skip layer adds the gamma(x)
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(64) void mlp_fwd_k(FwdArgs a) {
   float sig = 0.f;
   auto layer = [&](f32x16 (&In)[NT], f32x16 (&Out)[NT], int l) __attribute__((always_inline)) {
     const int poff = (int)(l < g.D ? g.f_trunk[l] : g.f_feat);
-    a_prefetch<NT>(a0, a1, AP, poff, W, W / 8);
+    a_prefetch3<NT>(A, AP, poff, W, W / 8);
     relu_bits<NT, TRAIN>(In, bits);
     if (TRAIN) store_bits<MD>(srs, smo, (g.s_mask + g.s_mb[l - 1]) * 4, bits);
     if (VD && l == g.D) {
@@ -141,12 +141,12 @@ __global__ __launch_bounds__(64) void mlp_fwd_k(FwdArgs a) {
     }
     CN_T(3)
     if (TRAIN)
-      gemm_reg<NT, NT, true, true>(Out, In, a0, a1, AP, poff, W, hh, TileStores<NT, NT>{In, srs, svo, g.s_h[l - 1] * 4});
+      gemm_reg3<NT, NT, true, true>(Out, In, A, AP, poff, W, hh, TileStores<NT, NT>{In, srs, svo, g.s_h[l - 1] * 4});
     else
-      gemm_reg<NT, NT, true, true>(Out, In, a0, a1, AP, poff, W, hh);
+      gemm_reg3<NT, NT, true, true>(Out, In, A, AP, poff, W, hh);
     if (l == g.skip + 1) {
-      a_prefetch<NT>(a0, a1, AP, (int)g.f_skip, W, g.in_chp / 8);
-      gemm_lds<NT, true, false>(Out, a0, a1, AP, (int)g.f_skip, W, g.in_chp / 8, Tx, m, hh);
+      a_prefetch<NT>(A[0], A[1], AP, (int)g.f_skip, W, g.in_chp / 8);
+      gemm_lds<NT, true, false>(Out, A[0], A[1], AP, (int)g.f_skip, W, g.in_chp / 8, Tx, m, hh);
     }
     CN_T(2)
   };
