@@ -15,6 +15,8 @@
 // 16 steps x (an x ak) MFMAs of slab s; one barrier per slab.
 // GEMMs are launched largest-first over many small point ranges so the tail of the grid is short; split
 // partials are reduced in a fixed order by a second kernel (bit-reproducible run to run).
+#include <stdlib.h>
+
 #include "mlp_common.hpp"
 
 namespace {
@@ -227,17 +229,42 @@ struct RedArgs {
   int nsplit, accumulate;
 };
 
-__global__ void wgrad_reduce_k(RedArgs a) {
+// Fixed-order sum of the split partials (bit-reproducible).  Bandwidth-bound (nsplit x ~2.4 MB): 16-byte loads, 8
+// independent partial streams in flight per thread, enough blocks to cover the chip.
+__global__ __launch_bounds__(256) void wgrad_reduce_k(RedArgs a) {
   const int t = blockIdx.y;
   float* g = a.grad[t];
   if (g == nullptr) return;
-  const int64_t n = a.numel[t];
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    float s = 0.f;
+  const int64_t n = a.numel[t], n4 = n >> 2;
+  const float* p0 = a.partials + a.toff[t];   // tensor offsets are multiples of 4 floats, pstride of 64
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (a.touched[t]) {
-      const float* p = a.partials + a.toff[t] + i;
-      for (int k = 0; k < a.nsplit; ++k) s += p[(int64_t)k * a.pstride];
+      const f32x4* p = reinterpret_cast<const f32x4*>(p0) + i;
+      const int64_t st = a.pstride >> 2;
+      int k = 0;
+      for (; k + 8 <= a.nsplit; k += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(k + u) * st];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];   // in split order
+      }
+      for (; k < a.nsplit; ++k) s += p[(int64_t)k * st];
     }
+    f32x4* gp = reinterpret_cast<f32x4*>(g) + i;
+    if ((reinterpret_cast<uintptr_t>(g) & 15) == 0) {
+      *gp = a.accumulate ? *gp + s : s;
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) g[4 * i + c] = a.accumulate ? g[4 * i + c] + s[c] : s[c];
+    }
+  }
+  // tail (numel not a multiple of 4)
+  for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    if (a.touched[t])
+      for (int k = 0; k < a.nsplit; ++k) s += p0[i + (int64_t)k * a.pstride];
     g[i] = a.accumulate ? g[i] + s : s;
   }
 }
@@ -267,6 +294,10 @@ int cn_wgrad_nsplit(int64_t Mp) {
   int64_t s = Mp / 4096;
   if (s < 1) s = 1;
   if (s > 128) s = 128;
+  if (const char* e = getenv("CNERF_WGRAD_NSPLIT")) {   // tuning knob (scripts/kbench.py); both callers see the same value
+    const int v = atoi(e);
+    if (v >= 1 && v <= 256) s = v;
+  }
   return (int)s;
 }
 
@@ -342,7 +373,7 @@ int cn_wgrad_launch(const NetGeom& g, const float* stash, const float* G, int64_
   hipLaunchKernelGGL(wgrad_k, dim3(nsplit, nj), dim3(64 * NWAVES), lds_bytes, st, a);
   CN_CHECK_LAUNCH();
   r.partials = partials; r.pstride = pstride; r.nsplit = nsplit; r.accumulate = accumulate;
-  hipLaunchKernelGGL(wgrad_reduce_k, dim3(32, nt), dim3(256), 0, st, r);
+  hipLaunchKernelGGL(wgrad_reduce_k, dim3(64, nt), dim3(256), 0, st, r);
   CN_CHECK_LAUNCH();
   return CNERF_OK;
 }
