@@ -61,14 +61,17 @@ struct NetGeom {
   int64_t b_trunk[16];      // biases [W] each, l=0..D-1
   int64_t b_feat, b_views, b_alpha, b_rgb, b_out;
   int64_t total;
-  // stash (training): POINT-MAJOR [Mp][s_rows], Mp = M rounded up to 32; column offsets of each block of a row.
+  // stash (training): logically [Mp][s_rows], Mp = M rounded up to 32, column offsets of each block below; stored
+  // TILE-MAJOR: tiles of 32 points x 8 columns (1 KiB, point-major inside), element (p, c) at float index
+  // ((p/32 * s_rows/8 + c/8) * 32 + p%32) * 8 + c%8 — the 64 lanes of a producing wave write one tile with one
+  // 16-byte store each, 1 KiB contiguous, and the wgrad DMA moves a tile with one instruction.
   // s_mask: ReLU sign bits of every hidden layer (1 = pre-activation > 0), packed per lane of the producing wave:
   // layer block b (trunk l = 0..D-1, then the view branch) starts at s_mask + s_mb[b]; inside it half-wave hh owns
   // md dwords (md = tiles/2 rounded up), dword d = tiles 2d, 2d+1, element (tile t, register r) at bit
   // 31 - (16*(t&1) + r) (15 - r when the dword holds a single tile).  The backward reads masks from here, not from
   // the activations.
   int s_enc, s_h[16], s_feat, s_denc, s_hv, s_mask, s_mb[17], s_rows;
-  // backward workspace (gradient wrt pre-activations), point-major [Mp][g_rows]
+  // backward workspace (gradient wrt pre-activations), logically [Mp][g_rows], same tile-major storage
   int g_z[16], g_feat, g_hv, g_out, g_rows;
 };
 

@@ -62,7 +62,7 @@ int cn_make_geom(const cnerf_net* net, NetGeom* g) {
     for (int l = 0; l < g->D; ++l) { g->s_mb[l] = o; o += 2 * md; }
     g->s_mb[g->D] = o;
     if (g->viewdirs) o += 2 * mdv;
-    g->s_mask = r; r += (int)cn_round_up(o, 4);
+    g->s_mask = r; r += (int)cn_round_up(o, 8);   // every block starts on a column octet (tile-major storage)
   }
   g->s_rows = r;
   r = 0;

@@ -39,12 +39,14 @@ __global__ __launch_bounds__(64) void mlp_dgrad_k(BwdArgs a) {
   const int64_t pc = p < a.M ? p : a.M - 1;
   CN_TINIT(1)
   const APanel AP{make_rsrc(a.packed, (unsigned)(g.total * 4)), (m * 8 + 4 * hh) * 4};
-  // this workgroup's 32 stash rows (sign bits) and 32 gradient rows; rows of padding points are out of range:
-  // their bits read as 0 and their stores are dropped (the launcher zero-fills those rows of G for the wgrad DMA)
-  const rsrc_t srs = make_rsrc(a.stash + p0 * g.s_rows, (unsigned)(nvalid * g.s_rows * 4));
-  const rsrc_t grs = make_rsrc(a.G + p0 * g.g_rows, (unsigned)(nvalid * g.g_rows * 4));
-  const int gvo = (m * g.g_rows + 4 * hh) * 4;
-  const int smo = (m * g.s_rows + hh * MD) * 4;
+  // this workgroup's stash tile row (sign bits) and gradient tile row (tile-major, mlp_common.hpp); lanes of padding
+  // points address out of range: their bits read as 0 and their stores are dropped (the launcher zero-fills the last
+  // tile row of G for the wgrad DMA)
+  const rsrc_t srs = make_rsrc(a.stash + p0 * g.s_rows, (unsigned)(32 * g.s_rows * 4));
+  const rsrc_t grs = make_rsrc(a.G + p0 * g.g_rows, (unsigned)(32 * g.g_rows * 4));
+  const bool valid = p < a.M;
+  const int gvo = valid ? m * 32 + hh * 16 : TM_OOB;
+  const int smo = valid ? m * 32 + hh * MD * 4 : TM_OOB;
   f32x16 X[NT], Y[NT];
   f32x4 A[3][NT];   // A-operand register sets of the current transposed panel
   unsigned bits[MD];
@@ -53,9 +55,9 @@ __global__ __launch_bounds__(64) void mlp_dgrad_k(BwdArgs a) {
     const float4 d = *reinterpret_cast<const float4*>(a.d_raw + pc * 4);
     const float dc[4] = {d.x, d.y, d.z, d.w};
     unsigned bv[MDV];
-    load_bits<MDV>(srs, (m * g.s_rows + hh * MDV) * 4, (g.s_mask + g.s_mb[g.D]) * 4, bv);
+    load_bits<MDV>(srs, valid ? m * 32 + hh * MDV * 4 : TM_OOB, tm_col(g.s_mask + g.s_mb[g.D]), bv);
     a_prefetch3<NT>(A, AP, (int)g.t_views, W, g.Wh / 8 - 1);
-    if (hh == 0) buf_store(grs, m * g.g_rows * 4, g.g_out * 4, f32x4{d.x, d.y, d.z, d.w});
+    if (hh == 0) buf_store(grs, valid ? m * 32 : TM_OOB, tm_col(g.g_out), f32x4{d.x, d.y, d.z, d.w});
     // rgb_linear^T on the VALU, masked by the view-branch ReLU -> dZv (C-layout registers)
     f32x16 V[NTH];
 #pragma unroll
@@ -75,12 +77,12 @@ __global__ __launch_bounds__(64) void mlp_dgrad_k(BwdArgs a) {
     mask_bits<NTH>(V, bv);
     CN_T(0)
     // dF = views_linears^T (feature columns only; gamma(d) needs no gradient) . dZv, no mask (feature_linear is linear)
-    gemm_reg3<NTH, NT, false, true>(X, V, A, AP, (int)g.t_views, W, hh, TileStores<NTH, NT>{V, grs, gvo, g.g_hv * 4});
+    gemm_reg3<NTH, NT, false, true>(X, V, A, AP, (int)g.t_views, W, hh, TileStores<NTH, NT>{V, grs, gvo, tm_col(g.g_hv)});
     pin<NT>(X);
     CN_T(2)
     // dZ_{D-1} = relu'(h_{D-1}) * (feature_linear^T . dF + alpha_linear^T . dsigma)
     a_prefetch3<NT>(A, AP, (int)g.t_feat, W, W / 8 - 1);
-    load_bits<MD>(srs, smo, (g.s_mask + g.s_mb[g.D - 1]) * 4, bits);
+    load_bits<MD>(srs, smo, tm_col(g.s_mask + g.s_mb[g.D - 1]), bits);
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -90,17 +92,17 @@ __global__ __launch_bounds__(64) void mlp_dgrad_k(BwdArgs a) {
         for (int j = 0; j < 4; ++j) Y[t][4 * q + j] = w[j] * dc[3];
       }
     CN_T(4)
-    gemm_reg3<NT, NT, false, false>(Y, X, A, AP, (int)g.t_feat, W, hh, TileStores<NT, NT>{X, grs, gvo, g.g_feat * 4});
+    gemm_reg3<NT, NT, false, false>(Y, X, A, AP, (int)g.t_feat, W, hh, TileStores<NT, NT>{X, grs, gvo, tm_col(g.g_feat)});
     CN_T(2)
   } else {
-    load_bits<MD>(srs, smo, (g.s_mask + g.s_mb[g.D - 1]) * 4, bits);
+    load_bits<MD>(srs, smo, tm_col(g.s_mask + g.s_mb[g.D - 1]), bits);
     float dc[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) dc[c] = c < g.out_ch ? a.d_raw[pc * g.out_ch + c] : 0.f;
     if (hh == 0)
       for (int c = 0; c < g.out_ch; ++c)
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dc[c]), grs, (m * g.g_rows + c) * 4,
-                                              g.g_out * 4, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dc[c]), grs, valid ? m * 32 : TM_OOB,
+                                              tm_col(g.g_out + c), 0);
     // output_linear^T on the VALU
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -125,8 +127,8 @@ __global__ __launch_bounds__(64) void mlp_dgrad_k(BwdArgs a) {
   // trunk: dZ_{l-1} = relu'(h_{l-1}) * (W_l^T . dZ_l) (the gamma(x) columns of the skip layer get no gradient); dZ_l
   // goes out to the workspace while it is the B operand of this GEMM.  X / Y alternate as input and output.
   auto layer = [&](f32x16 (&In)[NT], f32x16 (&Out)[NT], int l) __attribute__((always_inline)) {
-    load_bits<MD>(srs, smo, (g.s_mask + g.s_mb[l - 1]) * 4, bits);
-    gemm_reg3<NT, NT, false, true>(Out, In, A, AP, (int)g.t_trunk[l], W, hh, TileStores<NT, NT>{In, grs, gvo, g.g_z[l] * 4});
+    load_bits<MD>(srs, smo, tm_col(g.s_mask + g.s_mb[l - 1]), bits);
+    gemm_reg3<NT, NT, false, true>(Out, In, A, AP, (int)g.t_trunk[l], W, hh, TileStores<NT, NT>{In, grs, gvo, tm_col(g.g_z[l])});
     if (l > 1) a_prefetch3<NT>(A, AP, (int)g.t_trunk[l - 1], W, W / 8 - 1);
     CN_T(2)
     mask_bits<NT>(Out, bits);
@@ -139,9 +141,9 @@ __global__ __launch_bounds__(64) void mlp_dgrad_k(BwdArgs a) {
   }
   if (l == 1) {   // (a third instance of the layer body: cheaper than keeping both sets live behind a flag)
     layer(Y, X, 1);
-    store_tiles<NT>(X, grs, gvo, g.g_z[0] * 4);
+    store_tiles<NT>(X, grs, gvo, tm_col(g.g_z[0]));
   } else {
-    store_tiles<NT>(Y, grs, gvo, g.g_z[0] * 4);
+    store_tiles<NT>(Y, grs, gvo, tm_col(g.g_z[0]));
   }
   CN_T(3)
   CN_TEND
@@ -150,8 +152,8 @@ __global__ __launch_bounds__(64) void mlp_dgrad_k(BwdArgs a) {
 template <int NT>
 int launch(const BwdArgs& a, hipStream_t st) {
   const unsigned grid = (unsigned)cn_div_up(a.M, 32);
-  if (a.Mp > a.M) {   // gradient rows of the padding points: the kernel drops their stores, wgrad reads them
-    hipError_t e = hipMemsetAsync(a.G + a.M * a.g.g_rows, 0, (size_t)(a.Mp - a.M) * a.g.g_rows * sizeof(float), st);
+  if (a.Mp > a.M) {   // last gradient tile row holds padding points: the kernel drops their stores, wgrad reads them
+    hipError_t e = hipMemsetAsync(a.G + (a.Mp - 32) * a.g.g_rows, 0, (size_t)32 * a.g.g_rows * sizeof(float), st);
     if (e != hipSuccess) return (int)e;
   }
   if (a.g.viewdirs) hipLaunchKernelGGL((mlp_dgrad_k<NT, true>), dim3(grid), dim3(64), 0, st, a);

@@ -57,6 +57,13 @@ __device__ __forceinline__ void buf_store(rsrc_t r, int voff, int soff, const f3
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
 }
 
+// Tile-major row blocks (common.hpp): inside a workgroup's 32-point tile row, column c of point m sits at byte
+// tm_col(c) + m*32.  tm_col is wave-uniform (scalar unit); the per-lane part m*32 (+ 16 for the upper half-wave's
+// 4 columns of an octet) is one loop-invariant VGPR, set out of range for padding points so that the hardware drops
+// their stores and returns 0 for their loads.
+__device__ __forceinline__ int tm_col(int c) { return (c >> 3) * 1024 + (c & 7) * 4; }
+constexpr int TM_OOB = 0x7ffffff0;
+
 // ReLU sign-bit words of one layer for this lane: MD dwords (common.hpp: s_mask)
 template <int MD>
 __device__ __forceinline__ void store_bits(rsrc_t r, int voff, int soff, const unsigned (&b)[MD]) {
@@ -276,11 +283,12 @@ __device__ __forceinline__ void mask_bits(f32x16 (&Q)[NT], unsigned (&bits)[(NT 
       asm("v_add_co_u32 %0, vcc, %0, %0\n\tv_cndmask_b32 %1, 0, %1, vcc" : "+v"(bits[t >> 1]), "+v"(Q[t][r]) : : "vcc");
 }
 
-// 32-feature-tile stores of C-layout registers into a point-major row block, as a `side` functor of the GEMMs:
+// 32-feature-tile stores of C-layout registers into a tile-major row block, as a `side` functor of the GEMMs:
 // 4*NTI stores (tile i>>2, quad i&3), ONE PER K-GROUP (the GEMM has exactly 4*NTI groups).  Spreading matters:
 // vmcnt retires in order, stores included, so the A-operand loads issued behind a burst of stores cannot be consumed
 // before the whole burst is acknowledged (measured: 8 stores per group in the first 4 groups cost the forward 12 %).
-// `voff` = (this point's row + 4*hh floats) in bytes relative to the resource base, `soff` = block column in bytes.
+// `voff` = m*32 + hh*16 (TM_OOB for padding points), `soff` = tm_col(first column of the block): store (tile tt, quad
+// q) is octet 4tt+q of the block = 1 KiB contiguous for the wave.
 template <int NTI, int NTO>
 struct TileStores {
   const f32x16 (&X)[NTI];
@@ -293,7 +301,11 @@ struct TileStores {
 #endif
     const int i = kg;
     const int tt = i >> 2, q = i & 3;
-    buf_store(rs, voff, soff + (32 * tt + 8 * q) * 4, f32x4{X[tt][4 * q], X[tt][4 * q + 1], X[tt][4 * q + 2], X[tt][4 * q + 3]});
+#if defined(CN_EXP) && (CN_EXP & 128)   // ablation 128: 1 KiB-contiguous (tile-major) store addresses; layout is then wrong
+    buf_store(rs, (int)(threadIdx.x & 63) * 16, soff + (4 * tt + q) * 1024, f32x4{X[tt][4 * q], X[tt][4 * q + 1], X[tt][4 * q + 2], X[tt][4 * q + 3]});
+#else
+    buf_store(rs, voff, soff + (4 * tt + q) * 1024, f32x4{X[tt][4 * q], X[tt][4 * q + 1], X[tt][4 * q + 2], X[tt][4 * q + 3]});
+#endif
   }
 };
 
@@ -303,5 +315,5 @@ __device__ __forceinline__ void store_tiles(const f32x16 (&X)[NT], rsrc_t rs, in
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-      buf_store(rs, voff, soff + (32 * t + 8 * q) * 4, f32x4{X[t][4 * q], X[t][4 * q + 1], X[t][4 * q + 2], X[t][4 * q + 3]});
+      buf_store(rs, voff, soff + (4 * t + q) * 1024, f32x4{X[t][4 * q], X[t][4 * q + 1], X[t][4 * q + 2], X[t][4 * q + 3]});
 }

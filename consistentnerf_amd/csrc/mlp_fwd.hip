@@ -62,7 +62,7 @@ __device__ __forceinline__ void encode(float* T, const float (&v)[3], int L, int
 // Copy this lane's chunks of an encoding tile to its stash block (lane (m, hh) owns columns 8c + 4hh .. +3)
 __device__ __forceinline__ void stash_tile(const float* T, int chp, rsrc_t srs, int svo, int col, int m, int hh) {
   for (int c = 0; c < chp / 8; ++c)
-    buf_store(srs, svo, (col + 8 * c) * 4, *reinterpret_cast<const f32x4*>(T + enc_off(m, 2 * c + hh)));
+    buf_store(srs, svo, tm_col(col) + c * 1024, *reinterpret_cast<const f32x4*>(T + enc_off(m, 2 * c + hh)));
 }
 
 template <int NT, bool VD, bool TRAIN>
@@ -82,11 +82,11 @@ __global__ __launch_bounds__(64) void mlp_fwd_k(FwdArgs a) {
   CN_TINIT(1)
 
   const APanel AP{make_rsrc(a.packed, (unsigned)(g.total * 4)), (m * 8 + 4 * hh) * 4};
-  // this workgroup's 32 stash rows; rows of padding points are out of range: their stores are dropped (the
-  // launcher zero-fills them once, the wgrad DMA reads them)
-  const rsrc_t srs = make_rsrc(TRAIN ? a.stash + p0 * g.s_rows : nullptr, TRAIN ? (unsigned)(nvalid * g.s_rows * 4) : 0u);
-  const int svo = (m * g.s_rows + 4 * hh) * 4;
-  const int smo = (m * g.s_rows + hh * MD) * 4;              // sign-bit words of this lane: + (s_mask + s_mb[l]) * 4
+  // this workgroup's stash tile row (tile-major, mlp_common.hpp); lanes of padding points address out of range: their
+  // stores are dropped (the launcher zero-fills the last tile row once, the wgrad DMA reads it)
+  const rsrc_t srs = make_rsrc(TRAIN ? a.stash + p0 * g.s_rows : nullptr, TRAIN ? (unsigned)(32 * g.s_rows * 4) : 0u);
+  const int svo = p < a.M ? m * 32 + hh * 16 : TM_OOB;
+  const int smo = p < a.M ? m * 32 + hh * MD * 4 : TM_OOB;   // sign-bit words of this lane: + tm_col(s_mask + s_mb[l])
 
   float x[3] = {0.f, 0.f, 0.f}, v[3] = {0.f, 0.f, 0.f};
   const float* const pre = a.emb != nullptr ? a.emb + pc * (g.in_ch + g.dir_ch) : nullptr;
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(64) void mlp_fwd_k(FwdArgs a) {
     const int poff = (int)(l < g.D ? g.f_trunk[l] : g.f_feat);
     a_prefetch3<NT>(A, AP, poff, W, W / 8);
     relu_bits<NT, TRAIN>(In, bits);
-    if (TRAIN) store_bits<MD>(srs, smo, (g.s_mask + g.s_mb[l - 1]) * 4, bits);
+    if (TRAIN) store_bits<MD>(srs, smo, tm_col(g.s_mask + g.s_mb[l - 1]), bits);
     if (VD && l == g.D) {
 #pragma unroll
       for (int t = 0; t < NT; ++t)
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(64) void mlp_fwd_k(FwdArgs a) {
     }
     CN_T(3)
     if (TRAIN)
-      gemm_reg3<NT, NT, true, true>(Out, In, A, AP, poff, W, hh, TileStores<NT, NT>{In, srs, svo, g.s_h[l - 1] * 4});
+      gemm_reg3<NT, NT, true, true>(Out, In, A, AP, poff, W, hh, TileStores<NT, NT>{In, srs, svo, tm_col(g.s_h[l - 1])});
     else
       gemm_reg3<NT, NT, true, true>(Out, In, A, AP, poff, W, hh);
     if (l == g.skip + 1) {
@@ -172,8 +172,8 @@ __global__ __launch_bounds__(64) void mlp_fwd_k(FwdArgs a) {
     // each lane sums its own features
     relu_bits<NT, TRAIN>(X, bits);
     if (TRAIN) {
-      store_bits<MD>(srs, smo, (g.s_mask + g.s_mb[g.D - 1]) * 4, bits);
-      store_tiles<NT>(X, srs, svo, g.s_h[g.D - 1] * 4);
+      store_bits<MD>(srs, smo, tm_col(g.s_mask + g.s_mb[g.D - 1]), bits);
+      store_tiles<NT>(X, srs, svo, tm_col(g.s_h[g.D - 1]));
     }
     float o[8];
 #pragma unroll
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(64) void mlp_fwd_k(FwdArgs a) {
     a_prefetch<NTH>(v0, v1, AP, (int)g.f_views, g.Wh, W / 8 - 1);
     if (TRAIN)
       gemm_reg<NT, NTH, false, true>(V, Y, v0, v1, AP, (int)g.f_views, g.Wh, hh,
-                                     TileStores<NT, NTH>{Y, srs, svo, g.s_feat * 4});
+                                     TileStores<NT, NTH>{Y, srs, svo, tm_col(g.s_feat)});
     else
       gemm_reg<NT, NTH, false, true>(V, Y, v0, v1, AP, (int)g.f_views, g.Wh, hh);
     pin<NTH>(V);
@@ -215,8 +215,8 @@ __global__ __launch_bounds__(64) void mlp_fwd_k(FwdArgs a) {
     unsigned bv[MDV];
     relu_bits<NTH, TRAIN>(V, bv);
     if (TRAIN) {
-      store_bits<MDV>(srs, (m * g.s_rows + hh * MDV) * 4, (g.s_mask + g.s_mb[g.D]) * 4, bv);
-      store_tiles<NTH>(V, srs, svo, g.s_hv * 4);
+      store_bits<MDV>(srs, p < a.M ? m * 32 + hh * MDV * 4 : TM_OOB, tm_col(g.s_mask + g.s_mb[g.D]), bv);
+      store_tiles<NTH>(V, srs, svo, tm_col(g.s_hv));
     }
     CN_T(3)
     // rgb_linear (H:125) straight from the registers: lane holds n = 32t + 8q + 4hh + j
@@ -245,8 +245,8 @@ template <int NT>
 int launch(const FwdArgs& a, hipStream_t st) {
   const unsigned grid = (unsigned)cn_div_up(a.M, 32);
   if (a.stash != nullptr) {
-    if (a.Mp > a.M) {   // rows of the padding points: the kernel drops their stores, wgrad reads them
-      hipError_t e = hipMemsetAsync(a.stash + a.M * a.g.s_rows, 0, (size_t)(a.Mp - a.M) * a.g.s_rows * sizeof(float), st);
+    if (a.Mp > a.M) {   // last tile row holds padding points: the kernel drops their stores, wgrad reads them
+      hipError_t e = hipMemsetAsync(a.stash + (a.Mp - 32) * a.g.s_rows, 0, (size_t)32 * a.g.s_rows * sizeof(float), st);
       if (e != hipSuccess) return (int)e;
     }
     if (a.g.viewdirs) hipLaunchKernelGGL((mlp_fwd_k<NT, true, true>), dim3(grid), dim3(64), 0, st, a);

@@ -6,10 +6,11 @@
 // A workgroup (4 waves, one per SIMD, <= 512 registers each) owns one GEMM's whole (<=256 x <=256) output and one of
 // `nsplit` point ranges.  The 4 waves tile the output as a gn x gk grid chosen per GEMM so that all four have work
 // (256x256 -> 2x2 waves of 4x4 MFMA tiles; 128x256 -> 2x4 tiles each; 256x64 -> 2x2 each; 4x256 -> 1x2 ...).
-// Operands move HBM -> LDS by DMA (buffer_load ... lds, 16 bytes per lane, no VGPR staging, scalar addressing: one
-// instruction per point row, so the LDS image is Xs[m][256] whatever the operand's width); the MFMA A operand of
-// step s is the `ds_read_b32` Xs[2s+hh][32x + lane&31] (B likewise from Ys) at an IMMEDIATE offset from one
-// per-lane base.  The inner loop is VALU-free apart from the bias column sums: fp32 MFMA and the VALU share the
+// Operands move HBM -> LDS by DMA (buffer_load ... lds, 16 bytes per lane, no VGPR staging, scalar addressing): the
+// stash / gradient workspace are stored as 32-point x 8-column blocks (common.hpp), one instruction moves one block
+// (1 KiB contiguous) into a padded slot of the LDS image; the MFMA A operand of step s is one `ds_read_b32` per tile
+// (column 32x + lane&31 of point 2s+hh; B likewise from Ys) at an IMMEDIATE offset from one per-lane base,
+// conflict-free.  The inner loop is VALU-free apart from the bias column sums: fp32 MFMA and the VALU share the
 // SIMD's datapath (mlp_common.hpp), every VALU instruction is MFMA time lost.  Reads run one step ahead of the
 // MFMAs that consume them (sched_barriers pin the order).  Two LDS buffers: the DMA of slab s+1 runs under the
 // 16 steps x (an x ak) MFMAs of slab s; one barrier per slab.
@@ -24,8 +25,8 @@ namespace {
 constexpr int MAX_WG_JOBS = 48;
 constexpr int NWAVES = 4;                   // waves per workgroup (1 per SIMD)
 constexpr int TM = 32;                      // points per LDS slab
-constexpr int ROWF = 256;                   // floats per LDS row (one point of one operand)
-constexpr int TILE_FLOATS = TM * ROWF;      // one operand slab
+constexpr int OCTF = 264;                   // LDS pitch (floats) of one 32-point x 8-column block: 256 + 8 (banks)
+constexpr int TILE_FLOATS = 32 * OCTF;      // one operand slab: up to 32 column octets
 
 struct WgJob {
   int xcol, ycol;     // first column of X in G rows, of Y in stash rows
@@ -87,11 +88,11 @@ __device__ __forceinline__ void wgrad_body(const WgArgs& a, const WgJob& jb, flo
   const bool active = tn0 < ntn && tk0 < ntk;      // wave-uniform
   // this split's rows of the two operands behind buffer resources; a lane past the operand's width reads out of
   // range (zeros land in the unused columns of the LDS row)
-  const i32x4 xr = dma_rsrc(a.G + m_begin * a.g_rows + jb.xcol, (unsigned)((m_end - m_begin) * a.g_rows * 4));
-  const i32x4 yr = dma_rsrc(a.stash + m_begin * a.s_rows + jb.ycol, (unsigned)((m_end - m_begin) * a.s_rows * 4));
+  // this split's tile rows of the two operands (tile-major storage, common.hpp), from the operand's first column octet
+  const i32x4 xr = dma_rsrc(a.G + m_begin * a.g_rows + (jb.xcol >> 3) * 256, (unsigned)((m_end - m_begin) * a.g_rows * 4));
+  const i32x4 yr = dma_rsrc(a.stash + m_begin * a.s_rows + (jb.ycol >> 3) * 256, (unsigned)((m_end - m_begin) * a.s_rows * 4));
   const unsigned lds0 = (unsigned)(size_t)lds;
-  const int vox = lane * 4 < ntn * 32 ? lane * 16 : 0x7ffffff0;
-  const int voy = lane * 4 < ntk * 32 ? lane * 16 : 0x7ffffff0;
+  const int vo = lane * 16;
   CN_TINIT(NWAVES)
   f32x16 acc[AN][AK];
 #pragma unroll
@@ -104,14 +105,15 @@ __device__ __forceinline__ void wgrad_body(const WgArgs& a, const WgJob& jb, flo
 #pragma unroll
   for (int x = 0; x < AN; ++x) bsum[x] = 0.f;
 
-  // DMA of slab `sl` into buffer `buf`: point rows round-robin over the waves, 2 x 8 instructions per wave; piece i
-  // (0..15) is row wv + 4*(i>>1) of X (i even) or Y (i odd).  A slab past the end reads out of range (zeros).
+  // DMA of slab `sl` (= one 32-point tile row) into buffer `buf`: one instruction moves one 32-point x 8-column block
+  // (1 KiB contiguous in HBM) to its padded slot of the LDS image; blocks round-robin over the waves, 2 x 8
+  // instructions per wave: piece i (0..15) is column octet wv + 4*(i>>1) of X (i even) or Y (i odd).  Octets past the
+  // operand's width and slabs past the end read out of range (zeros).
   auto piece = [&](int sl, int buf, int i) __attribute__((always_inline)) {
     const unsigned b = lds0 + (unsigned)(buf * 2 * TILE_FLOATS * 4);
-    const int r = wv + NWAVES * (i >> 1);
-    const int row = sl < nslab ? sl * TM + r : 0x100000;
-    if (i & 1) dma16(yr, b + (TILE_FLOATS + r * ROWF) * 4, voy, row * s_rows4);
-    else dma16(xr, b + r * ROWF * 4, vox, row * g_rows4);
+    const int o = wv + NWAVES * (i >> 1);
+    if (i & 1) dma16(yr, b + (TILE_FLOATS + o * OCTF) * 4, vo, sl < nslab && o < 4 * ntk ? sl * s_rows4 * 32 + o * 1024 : 0x7ffffc00);
+    else dma16(xr, b + o * OCTF * 4, vo, sl < nslab && o < 4 * ntn ? sl * g_rows4 * 32 + o * 1024 : 0x7ffffc00);
   };
   auto issue = [&](int sl, int buf) __attribute__((always_inline)) {
 #pragma unroll
@@ -134,14 +136,18 @@ __device__ __forceinline__ void wgrad_body(const WgArgs& a, const WgJob& jb, flo
   }
   for (int sl = 0; sl < nslab; ++sl) {
     const int cur = sl & 1;
-    const float* Xs = lds + cur * 2 * TILE_FLOATS + hh * ROWF + 32 * tn0 + i31;
-    const float* Ys = lds + cur * 2 * TILE_FLOATS + TILE_FLOATS + hh * ROWF + 32 * tk0 + i31;
+    // LDS image: block of column octet o at o*OCTF floats, inside it point m, column c at m*8 + c.  Lane (i, hh) of
+    // step st reads column 32x + i of point 2*st + hh: one per-lane base + the immediate (4x*OCTF + 16 st) floats;
+    // the 8-float pad makes the 32 lanes of a half-wave hit 32 distinct banks.
+    const int lbase = (i31 >> 3) * OCTF + hh * 8 + (i31 & 7);
+    const float* Xs = lds + cur * 2 * TILE_FLOATS + 4 * tn0 * OCTF + lbase;
+    const float* Ys = lds + cur * 2 * TILE_FLOATS + TILE_FLOATS + 4 * tk0 * OCTF + lbase;
     float av[2][AN], bv[2][AK];
     auto rd = [&](int st, int o) __attribute__((always_inline)) {
 #pragma unroll
-      for (int x = 0; x < AN; ++x) av[o][x] = Xs[2 * st * ROWF + 32 * x];
+      for (int x = 0; x < AN; ++x) av[o][x] = Xs[16 * st + 4 * x * OCTF];
 #pragma unroll
-      for (int y = 0; y < AK; ++y) bv[o][y] = Ys[2 * st * ROWF + 32 * y];
+      for (int y = 0; y < AK; ++y) bv[o][y] = Ys[16 * st + 4 * y * OCTF];
     };
     rd(0, 0);
     __builtin_amdgcn_sched_barrier(0);

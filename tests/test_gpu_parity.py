@@ -91,11 +91,13 @@ def check_param_grads(model, g, prefix_full, prefix_sum, rtol=5e-2, l2tol=5e-3):
 
 
 def stash_blocks(stash, M, D, W, vd, in_chp=64):
-    """point-major [Mp][rows] training stash of cnerf_mlp_fwd -> dict of [M, cols] float64 CPU tensors (common.hpp).
+    """training stash of cnerf_mlp_fwd (logically [Mp][rows]) -> dict of [M, cols] float64 CPU tensors (common.hpp).
     Padding points [M, Mp) must be zero rows (the wgrad DMA relies on it).  The last block holds the ReLU sign-bit
     words the backward masks with; they are decoded and checked against the stored activations (bit == h > 0)."""
     Mp = (M + 31) // 32 * 32
-    full = stash.reshape(Mp, -1)
+    rows = stash.numel() // Mp
+    # tile-major storage (common.hpp): tiles of 32 points x 8 columns -> logical [Mp][rows]
+    full = stash.reshape(Mp // 32, rows // 8, 32, 8).permute(0, 2, 1, 3).reshape(Mp, rows)
     assert float(full[M:].abs().max()) == 0.0 if Mp > M else True
     s = full[:M].double().cpu()
     out, r = {}, 0
@@ -111,7 +113,7 @@ def stash_blocks(stash, M, D, W, vd, in_chp=64):
         take("feat", W); take("denc", 32); take("hv", W // 2)
     nt = W // 32
     md, mdv = (nt + 1) // 2, (nt // 2 + 1) // 2
-    nmask = (D * 2 * md + (2 * mdv if vd else 0) + 3) // 4 * 4
+    nmask = (D * 2 * md + (2 * mdv if vd else 0) + 7) // 8 * 8
     assert r + nmask == s.shape[1], (r, nmask, s.shape)
     words = full[:M, r:].contiguous().view(torch.int32).cpu().numpy().astype(np.int64) & 0xffffffff
 

@@ -211,6 +211,33 @@ def test_dgrad_transposed_panel():
     assert np.allclose(acc_to_dense(acc, K // 32), Wm[:, 3:].T @ dZ)
 
 
+def test_tile_major_storage_and_wgrad_lds_image():
+    """common.hpp tile-major storage + wgrad.hip LDS image: a producing lane (m, hh) writes 16 bytes at
+    tm_col(c0) + m*32 + hh*16 of its workgroup's tile row; the wgrad DMA copies each 1 KiB block to o*OCTF floats;
+    lane (i, hh) of step st then reads column 32x + i of point 2st + hh at lbase + 16 st + 4x*OCTF — every half-wave
+    on 32 distinct banks."""
+    OCTF, rows = 264, 96
+    rs = np.random.RandomState(7)
+    A = rs.normal(size=(32, rows))                           # one 32-point tile row, logical [m][c]
+    mem = np.zeros(32 * rows)
+    for t in range(rows // 32):                              # producer: TileStores of a block starting at column 32t
+        for q in range(4):
+            for m in range(32):
+                for hh in range(2):
+                    byte = ((32 * t) >> 3) * 1024 + (4 * 0 + q) * 1024 + m * 32 + hh * 16
+                    mem[byte // 4: byte // 4 + 4] = A[m, 32 * t + 8 * q + 4 * hh: 32 * t + 8 * q + 4 * hh + 4]
+    assert np.array_equal(mem.reshape(rows // 8, 32, 8).transpose(1, 0, 2).reshape(32, rows), A)
+    lds = np.zeros(32 * OCTF)
+    for o in range(rows // 8):                               # DMA: block o -> slot o*OCTF, lane-linear
+        lds[o * OCTF: o * OCTF + 256] = mem[o * 256: (o + 1) * 256]
+    for st in range(16):
+        for x in range(rows // 32):
+            for hh in range(2):
+                addr = [(i >> 3) * OCTF + hh * 8 + (i & 7) + 16 * st + 4 * x * OCTF for i in range(32)]
+                assert len({a % 32 for a in addr}) == 32       # conflict-free half-wave
+                assert np.array_equal(lds[addr], A[2 * st + hh, 32 * x: 32 * x + 32])
+
+
 def test_wgrad_point_contraction():
     """wgrad.hip: dW[n][k] = sum_m X^T[n][m] Y^T[k][m]; both operands are 16-byte pieces along m taken
     at column 8*step + 4*hh, the 4 components feed 4 MFMAs."""
