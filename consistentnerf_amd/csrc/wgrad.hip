@@ -26,7 +26,9 @@ constexpr int MAX_WG_JOBS = 48;
 constexpr int NWAVES = 4;                   // waves per workgroup (1 per SIMD)
 constexpr int TM = 32;                      // points per LDS slab
 constexpr int OCTF = 264;                   // LDS pitch (floats) of one 32-point x 8-column block: 256 + 8 (banks)
-constexpr int TILE_FLOATS = 32 * OCTF;      // one operand slab: up to 32 column octets
+constexpr int LDS_BYTES = 160 * 1024;       // all of a CU's LDS: one workgroup per CU
+constexpr int DUMMY_BYTES = 1024;           // landing zone of the no-op DMA pieces (out-of-range reads write zeros)
+constexpr int LDS_FLOATS = (LDS_BYTES - DUMMY_BYTES) / 4;
 
 struct WgJob {
   int xcol, ycol;     // first column of X in G rows, of Y in stash rows
@@ -91,7 +93,7 @@ __device__ __forceinline__ void wgrad_body(const WgArgs& a, const WgJob& jb, flo
   // this split's tile rows of the two operands (tile-major storage, common.hpp), from the operand's first column octet
   const i32x4 xr = dma_rsrc(a.G + m_begin * a.g_rows + (jb.xcol >> 3) * 256, (unsigned)((m_end - m_begin) * a.g_rows * 4));
   const i32x4 yr = dma_rsrc(a.stash + m_begin * a.s_rows + (jb.ycol >> 3) * 256, (unsigned)((m_end - m_begin) * a.s_rows * 4));
-  const unsigned lds0 = (unsigned)(size_t)lds;
+  const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)lds);
   const int vo = lane * 16;
   CN_TINIT(NWAVES)
   f32x16 acc[AN][AK];
@@ -105,60 +107,83 @@ __device__ __forceinline__ void wgrad_body(const WgArgs& a, const WgJob& jb, flo
 #pragma unroll
   for (int x = 0; x < AN; ++x) bsum[x] = 0.f;
 
-  // DMA of slab `sl` (= one 32-point tile row) into buffer `buf`: one instruction moves one 32-point x 8-column block
+  // LDS = `nbuf` slab buffers of [X image | Y image], sized by this GEMM's operand widths: a full 256 x 256 GEMM
+  // double-buffers (2 x 66 KiB); the narrow ones (heads, gamma columns) are latency-bound, not MFMA-bound, and get
+  // 3-4 buffers so that 2-3 slabs are in flight.
+  const int xoct = __builtin_amdgcn_readfirstlane(4 * ntn), yoct = __builtin_amdgcn_readfirstlane(4 * ntk);
+  const int bufF = (xoct + yoct) * OCTF;
+  int nbuf = LDS_FLOATS / bufF;
+  nbuf = nbuf > 4 ? 4 : nbuf;
+  // DMA of slab `sl` (= one 32-point tile row) into its buffer: one instruction moves one 32-point x 8-column block
   // (1 KiB contiguous in HBM) to its padded slot of the LDS image; blocks round-robin over the waves, 2 x 8
   // instructions per wave: piece i (0..15) is column octet wv + 4*(i>>1) of X (i even) or Y (i odd).  Octets past the
-  // operand's width and slabs past the end read out of range (zeros).
+  // operand's width and slabs past the end read out of range; their zeros land in a 1 KiB dummy block at the end of LDS
+  // (they stay in the instruction stream so that the vmcnt bookkeeping of `publish` is a constant).
   auto piece = [&](int sl, int buf, int i) __attribute__((always_inline)) {
-    const unsigned b = lds0 + (unsigned)(buf * 2 * TILE_FLOATS * 4);
+    const unsigned b = lds0 + (unsigned)(buf * bufF * 4);
     const int o = wv + NWAVES * (i >> 1);
-    if (i & 1) dma16(yr, b + (TILE_FLOATS + o * OCTF) * 4, vo, sl < nslab && o < 4 * ntk ? sl * s_rows4 * 32 + o * 1024 : 0x7ffffc00);
-    else dma16(xr, b + o * OCTF * 4, vo, sl < nslab && o < 4 * ntn ? sl * g_rows4 * 32 + o * 1024 : 0x7ffffc00);
+    if (i & 1) {
+      const bool on = sl < nslab && o < yoct;
+      dma16(yr, on ? b + (xoct + o) * OCTF * 4 : lds0 + LDS_BYTES - DUMMY_BYTES, vo, on ? sl * s_rows4 * 32 + o * 1024 : 0x7ffffc00);
+    } else {
+      const bool on = sl < nslab && o < xoct;
+      dma16(xr, on ? b + o * OCTF * 4 : lds0 + LDS_BYTES - DUMMY_BYTES, vo, on ? sl * g_rows4 * 32 + o * 1024 : 0x7ffffc00);
+    }
   };
   auto issue = [&](int sl, int buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 2 * TM / NWAVES; ++i) piece(sl, buf, i);
   };
-
-  if (nslab > 0) {
-    issue(0, 0);
-    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's DMA pieces have landed
+  // wait until at most (nbuf - 2) slabs' worth of this wave's DMA instructions (16 each) are still in flight, i.e.
+  // the oldest outstanding slab has landed, then publish it
+  auto publish = [&]() __attribute__((always_inline)) {
+    if (nbuf == 2) __builtin_amdgcn_s_waitcnt(0x0f70);        // vmcnt(0)
+    else if (nbuf == 3) __builtin_amdgcn_s_waitcnt(0x4f70);   // vmcnt(16)
+    else __builtin_amdgcn_s_waitcnt(0x8f70);                  // vmcnt(32)
     __syncthreads();
-  }
+  };
+
+  for (int sl = 0; sl < nbuf - 1; ++sl) issue(sl, sl);   // (slabs past the end are no-ops that still count in vmcnt)
+  publish();
   CN_T(0)
   if (!active) {   // idle wave of a narrow GEMM: it still moves its share of the slabs and meets the barriers
+    int nb = nbuf - 1;   // buffer of slab sl + nbuf - 1
     for (int sl = 0; sl < nslab; ++sl) {
-      if (sl + 1 < nslab) issue(sl + 1, (sl & 1) ^ 1);
-      __builtin_amdgcn_s_waitcnt(0x0f70);
-      __syncthreads();
+      issue(sl + nbuf - 1, nb);
+      nb = nb + 1 == nbuf ? 0 : nb + 1;
+      publish();
     }
     return;
   }
+  int cur = 0, nb = nbuf - 1;
   for (int sl = 0; sl < nslab; ++sl) {
-    const int cur = sl & 1;
     // LDS image: block of column octet o at o*OCTF floats, inside it point m, column c at m*8 + c.  Lane (i, hh) of
     // step st reads column 32x + i of point 2*st + hh: one per-lane base + the immediate (4x*OCTF + 16 st) floats;
     // the 8-float pad makes the 32 lanes of a half-wave hit 32 distinct banks.
     const int lbase = (i31 >> 3) * OCTF + hh * 8 + (i31 & 7);
-    const float* Xs = lds + cur * 2 * TILE_FLOATS + 4 * tn0 * OCTF + lbase;
-    const float* Ys = lds + cur * 2 * TILE_FLOATS + TILE_FLOATS + 4 * tk0 * OCTF + lbase;
-    float av[2][AN], bv[2][AK];
+    const float* Xs = lds + cur * bufF + 4 * tn0 * OCTF + lbase;
+    const float* Ys = lds + cur * bufF + (xoct + 4 * tk0) * OCTF + lbase;
+    // operand reads run LA steps ahead of the MFMAs that consume them: one step when a step is >= 8 MFMAs (512+
+    // cycles cover the LDS latency), three for the narrow GEMMs whose steps are only 1-4 MFMAs long
+    constexpr int LA = AN * AK >= 8 ? 1 : 3, R = LA + 1;
+    float av[R][AN], bv[R][AK];
     auto rd = [&](int st, int o) __attribute__((always_inline)) {
 #pragma unroll
       for (int x = 0; x < AN; ++x) av[o][x] = Xs[16 * st + 4 * x * OCTF];
 #pragma unroll
       for (int y = 0; y < AK; ++y) bv[o][y] = Ys[16 * st + 4 * y * OCTF];
     };
-    rd(0, 0);
+#pragma unroll
+    for (int st = 0; st < LA; ++st) rd(st, st);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int st = 0; st < TM / 2; ++st) {
-      const int o = st & 1;
-      if (st + 1 < TM / 2) rd(st + 1, o ^ 1);
-      // one piece of the NEXT slab's DMA per step (other buffer: all its readers passed the previous barrier).  In a
-      // burst, the 16 KiB a wave requests exceed what the memory pipeline accepts at once and the in-order wave sits in
-      // the issue queue instead of feeding the MFMA pipe (measured: 25 % of the kernel).
-      piece(sl + 1, cur ^ 1, st);
+      const int o = st % R;
+      if (st + LA < TM / 2) rd(st + LA, (st + LA) % R);
+      // one piece of slab sl + nbuf - 1 per step, into the buffer slab sl - 1 was read from (all its readers passed the
+      // previous barrier).  In a burst, the 16 KiB a wave requests exceed what the memory pipeline accepts at once and
+      // the in-order wave sits in the issue queue instead of feeding the MFMA pipe (measured: 25 % of the kernel).
+      piece(sl + nbuf - 1, nb, st);
       __builtin_amdgcn_sched_barrier(0);
       if (BS) {
 #pragma unroll
@@ -171,9 +196,9 @@ __device__ __forceinline__ void wgrad_body(const WgArgs& a, const WgJob& jb, flo
       __builtin_amdgcn_sched_barrier(0);
     }
     CN_T(2)
-    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0) before the barrier publishes the next slab
-    CN_T(3)
-    __syncthreads();
+    cur = cur + 1 == nbuf ? 0 : cur + 1;
+    nb = nb + 1 == nbuf ? 0 : nb + 1;
+    publish();
     CN_T(1)
   }
   float* out = a.partials + (int64_t)split * a.pstride;
@@ -369,7 +394,7 @@ int cn_wgrad_launch(const NetGeom& g, const float* stash, const float* G, int64_
   a.stash = stash; a.G = G; a.partials = partials; a.Mp = Mp; a.pstride = pstride;
   a.s_rows = g.s_rows; a.g_rows = g.g_rows;
   a.chunk = cn_round_up(cn_div_up(Mp, nsplit), TM);
-  const size_t lds_bytes = (size_t)4 * TILE_FLOATS * sizeof(float);
+  const size_t lds_bytes = LDS_BYTES;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_k), hipFuncAttributeMaxDynamicSharedMemorySize,

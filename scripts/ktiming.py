@@ -96,7 +96,8 @@ def main():
     print(f"{WHICH} B={B} S={S} train={TRAIN}: kernel {ms:.3f} ms, {nw} waves sampled")
     if WHICH == "wgrad":   # slots are (job, split, wave): report the 256x256 jobs (first 9) and the rest separately
         nsp = 128
-        for name, lo, hi in (("256x256 jobs", 0, 9), ("hv 128x256", 9, 10), ("small jobs", 10, 15)):
+        for name, lo, hi in (("256x256 jobs", 0, 8), ("hv 128x256", 8, 9), ("enc 256x64", 9, 10), ("skipenc 256x64", 10, 11),
+                             ("denc 128x32", 11, 12), ("alpha 4x256", 12, 13), ("rgb 3x128", 13, 14)):
             r = t[lo * nsp * 4: hi * nsp * 4]
             r = r[r[:, 5] > 0]
             tot = r[:, 5].mean()
