@@ -104,6 +104,29 @@ def cpu_baseline(seconds_budget=25.0):
                       f"{os.cpu_count()} logical cpus"}
 
 
+def pmc_traffic(kernel, points):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
+    each in their own `--pmc` run, scripts/gpu_pmc.sh -> profiles/r01_pmc_v3/): KB units, FETCH_SIZE doubled per the
+    gfx950 correction of MI355X_MICROARCH.md (16-byte-per-lane streaming reads are tallied at half).  None when no
+    pass of that kernel at that launch size is on file (counters cannot be sampled from inside this process)."""
+    import csv
+    here = os.path.dirname(os.path.abspath(__file__))
+    name = {"mlp_wgrad": "wgrad", "mlp_dgrad": "mlp_dgrad", "mlp_fwd_train": "mlp_fwd_train", "mlp_fwd": "mlp_fwd_inf"}.get(kernel)
+    val = {}
+    for f, ctr in (("pass2_summary.csv", "FETCH_SIZE"), ("pass3_summary.csv", "WRITE_SIZE")):
+        path = os.path.join(here, "profiles", "r01_pmc_v3", f)
+        if not os.path.exists(path):
+            return None
+        rows = [r for r in csv.DictReader(open(path)) if r["kernel"] == name and r["counter"] == ctr]
+        # forward / dgrad launch 64 threads per 32 points; wgrad's grid does not encode M: take the larger (fine) launch
+        pick = [r for r in rows if int(r["grid_threads"]) == 2 * points] or (sorted(rows, key=lambda r: -int(r["grid_threads"]))[:1]
+                                                                            if name == "wgrad" and points == 786432 else [])
+        if not pick:
+            return None
+        val[ctr] = float(pick[0]["avg_per_launch"]) * 1024.0
+    return int(2 * val["FETCH_SIZE"] + val["WRITE_SIZE"])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -183,7 +206,7 @@ def main():
     dom = table[0]
     roofline = {"bound": "mfma", "kernel": f'{dom["kernel"]} (M={dom["points"]} points)', "achieved": dom["tflops"],
                 "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(dom["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4),
-                "traffic": None, "avg_launch_ms": dom["avg_ms"], "kernels": table}
+                "traffic": pmc_traffic(dom["kernel"], dom["points"]), "avg_launch_ms": dom["avg_ms"], "kernels": table}
 
     if rank == 0:
         samples_per_step = B_PER_GPU * (NC + NC + NF) * world
