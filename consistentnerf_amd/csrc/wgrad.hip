@@ -23,7 +23,10 @@
 namespace {
 
 constexpr int MAX_WG_JOBS = 48;
-constexpr int NWAVES = 4;                   // waves per workgroup (1 per SIMD)
+#ifndef CN_WG_WAVES
+#define CN_WG_WAVES 4
+#endif
+constexpr int NWAVES = CN_WG_WAVES;         // waves per workgroup (1 per SIMD)
 constexpr int TM = 32;                      // points per LDS slab
 constexpr int OCTF = 264;                   // LDS pitch (floats) of one 32-point x 8-column block: 256 + 8 (banks)
 constexpr int LDS_BYTES = 160 * 1024;       // all of a CU's LDS: one workgroup per CU
@@ -361,7 +364,7 @@ int cn_wgrad_launch(const NetGeom& g, const float* stash, const float* G, int64_
     for (int gn = 1; gn <= NWAVES; gn *= 2) {
       const int gk = NWAVES / gn;
       const int an = (ntn + gn - 1) / gn, ak = (ntk + gk - 1) / gk;
-      if (an > 4 || ak > 4) continue;                  // <= 256 accumulator registers per wave
+      if (an > 4 || ak > 4 || an * ak > 64 / NWAVES) continue;   // <= 256 accumulator registers per wave (128 at 8 waves)
       const int cost = an * ak * 16 + an + ak;
       if (cost < best_cost) { best_cost = cost; best_gk = gk; best_an = an; best_ak = ak; }
     }
