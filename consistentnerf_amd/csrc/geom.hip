@@ -200,7 +200,7 @@ extern "C" int cnerf_pack_weights(const cnerf_net* net, const cnerf_ptrs* params
   a.packed = packed;
   int nj = 0;
   const int W = g.W, Wh = g.Wh, D = g.D;
-  // contracted width padded to a multiple of 32 (4 groups: the depth of the A-operand prefetch ring)
+  // contracted width padded to a multiple of 32 (4 K-groups of 8: the GEMM pipelines peel / unroll by that)
   auto panel = [&](const float* src, int ld, int col0, int N, int K, int64_t dst, const float* bias = nullptr,
                    int zero_bias = 0) {
     a.job[nj++] = PackJob{src, ld, col0, N, K, JOB_PANEL, (int)cn_round_up(N, 32), (int)cn_round_up(K, 32) / 8, dst,

@@ -2,7 +2,7 @@
 // Three launches:
 //   1. dgrad (this file): one wave64 per 32 points walks the network backwards with the TRANSPOSED weight
 //      panels as the MFMA A operand and the previous gradient's accumulator registers as B (mlp_common.hpp: no
-//      LDS, no barriers); it writes the gradient w.r.t. every layer's pre-activation, dZ_l, into the point-major
+//      LDS, no barriers); it writes the gradient w.r.t. every layer's pre-activation, dZ_l, into the tile-major
 //      gradient workspace G[Mp][g_rows].
 //   2. wgrad (wgrad.hip): NT GEMMs contracted over points, dW_l = dZ_l^T . H_{l-1}, split over point ranges.
 //   3. a fixed-order reduction of the split partials into the parameter gradients (deterministic).

@@ -1,6 +1,6 @@
 // Weight gradients of the NeRF MLP: dW[n][k] = sum_m X[m][n] * Y[m][k]  (m = points)
-// with X = gradient w.r.t. a layer's pre-activation (columns of the point-major workspace G[Mp][g_rows]) and
-// Y = that layer's input (columns of the point-major stash[Mp][s_rows]).  GEMMs on v_mfma_f32_32x32x2_f32 whose
+// with X = gradient w.r.t. a layer's pre-activation (columns of the workspace G[Mp][g_rows]) and
+// Y = that layer's input (columns of the stash[Mp][s_rows]; both stored tile-major, common.hpp).  GEMMs on v_mfma_f32_32x32x2_f32 whose
 // contraction runs over up to ~10^6 points.
 //
 // A workgroup (4 waves, one per SIMD, <= 512 registers each) owns one GEMM's whole (<=256 x <=256) output and one of

@@ -1,6 +1,6 @@
 // Latency from issuing ONE 16-byte-per-lane buffer store (or load) to s_waitcnt vmcnt(0) returning, with the machine
 // otherwise busy (all CUs run the same loop) — coalesced (1 KiB contiguous per wave) vs row-scattered (32 rows x 32 B,
-// the point-major stash pattern).   hipcc --offload-arch=gfx950 -O3 -o scripts/storeack_probe scripts/storeack_probe.hip
+// the former point-major stash pattern).   hipcc --offload-arch=gfx950 -O3 -o scripts/storeack_probe scripts/storeack_probe.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
