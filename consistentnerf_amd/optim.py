@@ -39,6 +39,7 @@ class FusedAdam:
                 self.flat_param[o:o + n].copy_(p.data.reshape(-1))
                 p.data = self.flat_param[o:o + n].view(p.shape)
                 p.grad = self.flat_grad[o:o + n].view(p.shape)
+                p._cnerf_direct_grad = True     # _MlpFn.backward accumulates into this view directly
 
     # -- torch.optim surface -------------------------------------------------------------------
     def zero_grad(self, set_to_none: bool = False):

@@ -66,13 +66,22 @@ class _MlpFn(torch.autograd.Function):
         if train:
             # the packed buffer is reused by the next pack; keep this step's copy for the backward
             ctx.spec, ctx.B, ctx.S, ctx.stash, ctx.packed = spec, B, S, stash, packed.clone()
+            ctx.params = params
         return raw
 
     @staticmethod
     def backward(ctx, g_raw):
-        grads = ops.mlp_backward(ctx.spec, ctx.packed, g_raw.contiguous(), ctx.B, ctx.S, ctx.stash)
-        ctx.stash = ctx.packed = None
-        return (None,) * 8 + tuple(grads)
+        params = ctx.params
+        # Parameters owned by FusedAdam carry their .grad as a view into the flat gradient buffer: the wgrad reduction
+        # accumulates straight into it (what AccumulateGrad would do with ~50 add/copy launches per step) and autograd
+        # gets no per-tensor gradients back.  Anything else (plain nn.Parameters, autograd.grad) takes the tensor route.
+        direct = all(ctx.needs_input_grad[8:]) and all(
+            getattr(p, "_cnerf_direct_grad", False) and p.grad is not None and p.grad.is_contiguous() for p in params)
+        out = [p.grad for p in params] if direct else None
+        grads = ops.mlp_backward(ctx.spec, ctx.packed, g_raw.contiguous(), ctx.B, ctx.S, ctx.stash, grads=out,
+                                 accumulate=direct)
+        ctx.stash = ctx.packed = ctx.params = None
+        return (None,) * 8 + ((None,) * len(params) if direct else tuple(grads))
 
 
 class _CompositeFn(torch.autograd.Function):
