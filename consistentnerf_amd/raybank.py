@@ -1,0 +1,96 @@
+"""Training-ray supply of the reference's train() loops, on the device.
+
+  RayBank        R:677-701 + R:720-729  all rays of the training views + their colours, shuffled; N_rand-row batches;
+                                        reshuffle when an epoch ends
+  sample_image_rays   R:730-757         the `--no_batching` branch: N_rand random pixels of one image, optional centre
+                                        pre-crop for the first iterations
+
+The reference builds the bank with numpy on the host (get_rays_np per pose, concatenate, transpose, reshape, one
+np.random.shuffle) and ships 3 x 3 x 4 bytes per ray to the GPU; here the rays come out of `cnerf_gen_rays` on the
+device and only the images cross PCIe.  The random choices stay the caller's: pass the permutation / pixel indices
+the reference's RNG would have produced (tests do) or let the device draw them.
+"""
+import numpy as np
+import torch
+
+from . import ops
+
+
+def _perm_like_numpy_shuffle(n, seed):
+    """The row permutation `np.random.seed(seed); np.random.shuffle(rows)` applies (Fisher-Yates on the row index)."""
+    idx = np.arange(n)
+    np.random.seed(seed)
+    np.random.shuffle(idx)
+    return idx
+
+
+class RayBank:
+    """rays_rgb [(len(i_train) * H * W), 3, 3] = (rays_o, rays_d, rgb) per training pixel (R:683-690)."""
+
+    def __init__(self, images, poses, H, W, K, i_train, device=None, perm=None, seed=None):
+        dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.H, self.W = int(H), int(W)
+        imgs = torch.as_tensor(np.asarray(images)[..., :3] if not isinstance(images, torch.Tensor) else images[..., :3],
+                               dtype=torch.float32)
+        rows = []
+        for i in i_train:
+            c2w = torch.as_tensor(np.asarray(poses[i])[:3, :4] if not isinstance(poses, torch.Tensor)
+                                  else poses[i, :3, :4], dtype=torch.float32)
+            r = ops.gen_rays(self.H, self.W, K, c2w, 0., 1., False, False, dev)          # [H*W, 11] o, d, near, far, vd
+            rgb = imgs[i].reshape(-1, 3).to(dev)
+            rows.append(torch.stack([r[:, 0:3], r[:, 3:6], rgb], 1))                        # [H*W, 3, 3]
+        self.rays_rgb = torch.cat(rows, 0)
+        n = self.rays_rgb.shape[0]
+        if perm is None:
+            perm = _perm_like_numpy_shuffle(n, seed) if seed is not None else None          # R:692
+        if perm is not None:
+            self.rays_rgb = self.rays_rgb[torch.as_tensor(perm, device=dev, dtype=torch.long)]
+        else:
+            self.rays_rgb = self.rays_rgb[torch.randperm(n, device=dev)]
+        self.i_batch = 0
+        self.epochs = 0
+
+    def __len__(self):
+        return self.rays_rgb.shape[0]
+
+    def next_batch(self, N_rand, rand_idx=None):
+        """R:720-729 -> (batch_rays [2, B, 3], target_s [B, 3]); `rand_idx` = the epoch-end permutation to use."""
+        batch = self.rays_rgb[self.i_batch:self.i_batch + N_rand].transpose(0, 1)
+        batch_rays, target_s = batch[:2], batch[2]
+        self.i_batch += N_rand
+        if self.i_batch >= self.rays_rgb.shape[0]:
+            if rand_idx is None:
+                rand_idx = torch.randperm(self.rays_rgb.shape[0], device=self.rays_rgb.device)
+            self.rays_rgb = self.rays_rgb[torch.as_tensor(rand_idx, device=self.rays_rgb.device, dtype=torch.long)]
+            self.i_batch = 0
+            self.epochs += 1
+        return batch_rays, target_s
+
+
+def crop_coords(H, W, precrop_frac=None):
+    """Pixel grid the sampler draws from (R:741-753): centre crop of 2*dH x 2*dW or the whole image -> [n, 2] (row, col)."""
+    if precrop_frac is not None:
+        dH, dW = int(H // 2 * precrop_frac), int(W // 2 * precrop_frac)
+        rr = torch.arange(H // 2 - dH, H // 2 + dH)
+        cc = torch.arange(W // 2 - dW, W // 2 + dW)
+    else:
+        rr, cc = torch.arange(H), torch.arange(W)
+    return torch.stack(torch.meshgrid(rr, cc, indexing="ij"), -1).reshape(-1, 2)
+
+
+def sample_image_rays(target, pose, H, W, K, N_rand, precrop_frac=None, select_inds=None):
+    """R:730-757: N_rand distinct pixels of one image -> (batch_rays [2, B, 3], target_s [B, 3]).
+    `select_inds` = indices into the (cropped) pixel grid; default: a device-side draw without replacement."""
+    dev = target.device if isinstance(target, torch.Tensor) and target.is_cuda else torch.device(
+        "cuda", torch.cuda.current_device())
+    target = torch.as_tensor(target, dtype=torch.float32).to(dev)
+    c2w = torch.as_tensor(np.asarray(pose)[:3, :4] if not isinstance(pose, torch.Tensor) else pose[:3, :4],
+                          dtype=torch.float32)
+    r = ops.gen_rays(int(H), int(W), K, c2w, 0., 1., False, False, dev)
+    coords = crop_coords(int(H), int(W), precrop_frac).to(dev)
+    if select_inds is None:
+        select_inds = torch.randperm(coords.shape[0], device=dev)[:N_rand]
+    sel = coords[torch.as_tensor(select_inds, device=dev, dtype=torch.long)]
+    flat = sel[:, 0] * int(W) + sel[:, 1]
+    batch_rays = torch.stack([r[flat, 0:3], r[flat, 3:6]], 0)
+    return batch_rays, target[sel[:, 0], sel[:, 1], :3]

@@ -430,3 +430,56 @@ def lr_at(lrate: float, global_step: int, lrate_decay: int) -> float:
 def as_tensors(sd_np: Dict[str, np.ndarray], requires_grad: bool = False) -> Dict[str, Tensor]:
     return {k: torch.from_numpy(np.ascontiguousarray(v)).clone().requires_grad_(requires_grad)
             for k, v in sd_np.items()}
+
+
+# ----------------------------------------------------------------------------------------------
+# training-ray supply: ray bank + batching (R:677-701, R:720-729), --no_batching sampler (R:730-757)
+def ray_bank(images: np.ndarray, poses: np.ndarray, H: int, W: int, K, i_train, perm=None) -> np.ndarray:
+    """rays_rgb [(len(i_train)*H*W), 3, 3] = (rays_o, rays_d, rgb) per training pixel, rows permuted by `perm`
+    (the permutation np.random.shuffle applies, R:692)."""
+    rows = []
+    for i in i_train:
+        ro, rd = get_rays_np(H, W, K, np.asarray(poses[i])[:3, :4])
+        rows.append(np.stack([ro.reshape(-1, 3), rd.reshape(-1, 3), np.asarray(images[i])[..., :3].reshape(-1, 3)], 1))
+    bank = np.concatenate(rows, 0).astype(np.float32)
+    return bank if perm is None else bank[np.asarray(perm)]
+
+
+def numpy_shuffle_perm(n: int, seed: int) -> np.ndarray:
+    """Row permutation of `np.random.seed(seed); np.random.shuffle(x)` for an x with n rows."""
+    idx = np.arange(n)
+    np.random.seed(seed)
+    np.random.shuffle(idx)
+    return idx
+
+
+class BankBatches:
+    """R:720-729: consecutive N_rand-row slices; when the cursor passes the end, permute by rand_idx and restart."""
+
+    def __init__(self, bank: np.ndarray):
+        self.bank, self.i_batch = bank, 0
+
+    def next(self, N_rand: int, rand_idx=None):
+        batch = np.transpose(self.bank[self.i_batch:self.i_batch + N_rand], (1, 0, 2))
+        self.i_batch += N_rand
+        if self.i_batch >= self.bank.shape[0]:
+            self.bank = self.bank[np.asarray(rand_idx)]
+            self.i_batch = 0
+        return batch[:2], batch[2]
+
+
+def crop_coords(H: int, W: int, precrop_frac=None) -> np.ndarray:
+    """(row, col) grid the --no_batching sampler draws from (R:741-753), row-major."""
+    if precrop_frac is not None:
+        dH, dW = int(H // 2 * precrop_frac), int(W // 2 * precrop_frac)
+        rr, cc = np.arange(H // 2 - dH, H // 2 + dH), np.arange(W // 2 - dW, W // 2 + dW)
+    else:
+        rr, cc = np.arange(H), np.arange(W)
+    return np.stack(np.meshgrid(rr, cc, indexing="ij"), -1).reshape(-1, 2)
+
+
+def sample_image_rays(target: np.ndarray, pose: np.ndarray, H: int, W: int, K, select_inds, precrop_frac=None):
+    """R:730-757 with the random pixel indices given."""
+    ro, rd = get_rays_np(H, W, K, np.asarray(pose)[:3, :4])
+    sc = crop_coords(H, W, precrop_frac)[np.asarray(select_inds)]
+    return np.stack([ro[sc[:, 0], sc[:, 1]], rd[sc[:, 0], sc[:, 1]]], 0), np.asarray(target)[sc[:, 0], sc[:, 1], :3]

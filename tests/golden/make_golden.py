@@ -442,7 +442,66 @@ def fx_pairs():
     save("pairs", **{k: np.asarray(v) for k, v in d.items()})
 
 
-ALL = dict(embed=fx_embed, mlp=fx_mlp, raw2outputs=fx_raw2outputs, sample_pdf=fx_sample_pdf,
+def fx_raybank():
+    """Ray bank + batching of train() (R:677-701, R:720-729) and the --no_batching sampler (R:730-757).  Those
+    statements are inline in the reference's train(); they are replayed here verbatim around the reference's OWN
+    get_rays_np / get_rays (imported), with numpy's / torch's RNG seeded so that the draws are part of the fixture."""
+    Hmod, _, _, _ = import_reference()
+    Hh, Ww, focal = 6, 8, 7.5
+    K = I.intrinsics(Hh, Ww, focal)
+    rs = np.random.RandomState(11)
+    poses = np.stack([I.camera_pose(25.0 * k, 10.0 + 5.0 * k, 3.0 + 0.1 * k)[:3, :4] for k in range(4)], 0).astype(np.float32)
+    images = rs.uniform(size=(4, Hh, Ww, 3)).astype(np.float32)
+    i_train = np.array([0, 2, 3])
+    # R:683-692
+    rays = np.stack([Hmod.get_rays_np(Hh, Ww, K, p) for p in poses[:, :3, :4]], 0)
+    rays_rgb = np.concatenate([rays, images[:, None]], 1)
+    rays_rgb = np.transpose(rays_rgb, [0, 2, 3, 1, 4])
+    rays_rgb = np.stack([rays_rgb[i] for i in i_train], 0)
+    rays_rgb = np.reshape(rays_rgb, [-1, 3, 3]).astype(np.float32)
+    unshuffled = rays_rgb.copy()
+    np.random.seed(5)
+    np.random.shuffle(rays_rgb)
+    bank0 = rays_rgb.copy()
+    # R:720-729, N_rand = 50 -> the third batch crosses the epoch end (144 rows)
+    N_rand, i_batch = 50, 0
+    rr = torch.from_numpy(rays_rgb)
+    out = {}
+    torch.manual_seed(3)
+    for it in range(4):
+        batch = rr[i_batch:i_batch + N_rand]
+        batch = torch.transpose(batch, 0, 1)
+        out[f"rays{it}"], out[f"tgt{it}"] = T(batch[:2]), T(batch[2])
+        i_batch += N_rand
+        if i_batch >= rr.shape[0]:
+            rand_idx = torch.randperm(rr.shape[0])
+            out["rand_idx"] = rand_idx.numpy()
+            rr = rr[rand_idx]
+            i_batch = 0
+    # R:730-757 (no_batching), with and without the centre pre-crop
+    for tag, frac in (("full", None), ("crop", 0.5)):
+        target = torch.from_numpy(images[2])
+        rays_o, rays_d = Hmod.get_rays(Hh, Ww, K, torch.from_numpy(poses[2]))
+        if frac is not None:
+            dH, dW = int(Hh // 2 * frac), int(Ww // 2 * frac)
+            coords = torch.stack(torch.meshgrid(torch.linspace(Hh // 2 - dH, Hh // 2 + dH - 1, 2 * dH),
+                                                torch.linspace(Ww // 2 - dW, Ww // 2 + dW - 1, 2 * dW)), -1)
+        else:
+            coords = torch.stack(torch.meshgrid(torch.linspace(0, Hh - 1, Hh), torch.linspace(0, Ww - 1, Ww)), -1)
+        coords = torch.reshape(coords, [-1, 2])
+        np.random.seed(9)
+        n = 5 if frac is not None else 20
+        select_inds = np.random.choice(coords.shape[0], size=[n], replace=False)
+        sc = coords[select_inds].long()
+        out[f"nb_{tag}_inds"] = select_inds
+        out[f"nb_{tag}_rays"] = T(torch.stack([rays_o[sc[:, 0], sc[:, 1]], rays_d[sc[:, 0], sc[:, 1]]], 0))
+        out[f"nb_{tag}_tgt"] = T(target[sc[:, 0], sc[:, 1]])
+        out[f"nb_{tag}_coords"] = T(coords)
+    save("raybank", poses=poses, images=images, i_train=i_train, hwf=np.array([Hh, Ww, focal], np.float32),
+         unshuffled=unshuffled, bank0=bank0, **out)
+
+
+ALL = dict(raybank=fx_raybank, embed=fx_embed, mlp=fx_mlp, raw2outputs=fx_raw2outputs, sample_pdf=fx_sample_pdf,
            render_rays=fx_render_rays, render_full=fx_render_full, warp=fx_warp, hardmask=fx_hardmask,
            losses=fx_losses, train=fx_train, pairs=fx_pairs)
 

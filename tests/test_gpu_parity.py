@@ -698,3 +698,37 @@ def test_envelope_corners_vs_oracle(dev, D, W, vd, och, multires, i_embed):
     (ref * G).sum().backward()
     gref = {"g." + k: (p.grad if p.grad is not None else torch.zeros_like(p)).numpy() for k, p in sd.items()}
     check_param_grads(model, gref, "g.", "g.", rtol=5e-2, l2tol=5e-3)
+
+
+# ------------------------------------------------------------------------------------------------
+# training-ray supply
+def test_ray_bank_and_samplers_golden(dev):
+    """RayBank / sample_image_rays (device-side rays from cnerf_gen_rays) against the reference's train() statements
+    replayed on the host (fixture `raybank`): same rows, same batches across an epoch end, same --no_batching picks.
+    Colours and origins are copies (bit-exact); directions go through the ray kernel (1e-6)."""
+    from consistentnerf_amd.raybank import RayBank, sample_image_rays
+    g = golden("raybank")
+    Hh, Ww, focal = int(g["hwf"][0]), int(g["hwf"][1]), float(g["hwf"][2])
+    K = I.intrinsics(Hh, Ww, focal)
+    n = g["bank0"].shape[0]
+    bank = RayBank(g["images"], g["poses"], Hh, Ww, K, g["i_train"], device=dev, perm=O.numpy_shuffle_perm(n, 5))
+    assert len(bank) == n
+    check(bank.rays_rgb, g["bank0"], 1e-6, "shuffled bank")
+    assert torch.equal(bank.rays_rgb[:, 2].cpu(), T(g["bank0"][:, 2]))
+    also = RayBank(g["images"], g["poses"], Hh, Ww, K, g["i_train"], device=dev, seed=5)     # seed == that permutation
+    assert torch.equal(also.rays_rgb, bank.rays_rgb)
+    for it in range(4):
+        rays, tgt = bank.next_batch(50, g["rand_idx"])
+        check(rays, g[f"rays{it}"], 1e-6, f"batch {it} rays")
+        assert torch.equal(tgt.cpu(), T(g[f"tgt{it}"]))
+    assert bank.epochs == 1 and bank.i_batch == 50
+    for tag, frac in (("full", None), ("crop", 0.5)):
+        rays, tgt = sample_image_rays(T(g["images"][2], dev), g["poses"][2], Hh, Ww, K, len(g[f"nb_{tag}_inds"]), frac,
+                                      g[f"nb_{tag}_inds"])
+        check(rays, g[f"nb_{tag}_rays"], 1e-6, f"no_batching {tag} rays")
+        assert torch.equal(tgt.cpu(), T(g[f"nb_{tag}_tgt"]))
+    # device-side draws: a permutation of the same rows / distinct pixels
+    rnd = RayBank(g["images"], g["poses"], Hh, Ww, K, g["i_train"], device=dev)
+    assert torch.equal(torch.sort(rnd.rays_rgb.reshape(n, -1)[:, 8])[0], torch.sort(bank.rays_rgb.reshape(n, -1)[:, 8])[0])
+    rays, tgt = sample_image_rays(T(g["images"][2], dev), g["poses"][2], Hh, Ww, K, 20)
+    assert rays.shape == (2, 20, 3) and tgt.shape == (20, 3)

@@ -211,3 +211,23 @@ def test_train_10_steps():
         ref = g["final." + k]
         assert np.abs(p.detach().numpy() - ref).max() <= 5e-6, k
     assert float(g["test_perturb"]) == 0.0
+
+
+def test_ray_bank_and_samplers_golden():
+    """the oracle's ray bank / batching / --no_batching sampler against the statements of the
+    reference's train() replayed around its own get_rays_np / get_rays (tests/golden/make_golden.py::fx_raybank)."""
+    g = golden("raybank")
+    Hh, Ww, focal = int(g["hwf"][0]), int(g["hwf"][1]), float(g["hwf"][2])
+    K = I.intrinsics(Hh, Ww, focal)
+    bank = O.ray_bank(g["images"], g["poses"], Hh, Ww, K, g["i_train"])
+    assert np.array_equal(bank, g["unshuffled"])
+    perm = O.numpy_shuffle_perm(bank.shape[0], 5)
+    assert np.array_equal(bank[perm], g["bank0"])
+    bb = O.BankBatches(g["bank0"].copy())
+    for it in range(4):
+        rays, tgt = bb.next(50, g["rand_idx"])
+        assert np.array_equal(rays, g[f"rays{it}"]) and np.array_equal(tgt, g[f"tgt{it}"]), it
+    for tag, frac in (("full", None), ("crop", 0.5)):
+        assert np.array_equal(O.crop_coords(Hh, Ww, frac), g[f"nb_{tag}_coords"].astype(np.int64))
+        rays, tgt = O.sample_image_rays(g["images"][2], g["poses"][2], Hh, Ww, K, g[f"nb_{tag}_inds"], frac)
+        assert np.array_equal(rays, g[f"nb_{tag}_rays"]) and np.array_equal(tgt, g[f"nb_{tag}_tgt"])
