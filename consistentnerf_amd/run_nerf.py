@@ -245,6 +245,22 @@ def _save_png(path, img8):
         np.save(path + ".npy", img8)
 
 
+def save_checkpoint(basedir, expname, global_step, render_kwargs_train, optimizer):
+    """The checkpoint write of train() (R:836-845): `{basedir}/{expname}/{global_step:06d}.tar` with the reference's
+    keys, loadable by the reference and by create_nerf() here."""
+    path = os.path.join(basedir, expname, '{:06d}.tar'.format(global_step))
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    fine = render_kwargs_train.get('network_fine')
+    ckpt = {'global_step': global_step,
+            'network_fn_state_dict': render_kwargs_train['network_fn'].state_dict(),
+            'optimizer_state_dict': optimizer.state_dict()}
+    if fine is not None:
+        ckpt['network_fine_state_dict'] = fine.state_dict()
+    torch.save(ckpt, path)
+    print('Saved checkpoints at', path)
+    return path
+
+
 def create_nerf(args):
     """R:181-262 -> (render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer)."""
     return _create_nerf(args, NeRF, False)

@@ -539,6 +539,61 @@ def test_train_10_steps_golden(dev):
     assert kw_test["perturb"] is False and kw_test["raw_noise_std"] == 0.
 
 
+def test_checkpoint_round_trip(dev):
+    """save_checkpoint (R:836-845 keys) -> create_nerf reload (R:226-243): 3 steps, save, reload into fresh objects,
+    2 more steps == 5 uninterrupted steps bit for bit (weights, Adam moments, step count, lr); the optimizer state
+    has torch.optim.Adam's structure."""
+    import argparse
+    import tempfile
+    from consistentnerf_amd import run_nerf as R
+
+    def mk(tmp, no_reload):
+        return argparse.Namespace(
+            multires=10, i_embed=0, use_viewdirs=True, multires_views=4, N_importance=16, netdepth=2, netwidth=64,
+            netdepth_fine=2, netwidth_fine=64, netchunk=1024 * 64, lrate=5e-4, basedir=tmp, expname="exp",
+            ft_path=None, no_reload=no_reload, perturb=0.0, N_samples=16, white_bkgd=False, raw_noise_std=0.0,
+            dataset_type="blender", no_ndc=False, lindisp=False)
+    K = I.intrinsics(100, 100, 138.0)
+
+    def steps(kw, opt, args, lo, hi):
+        for i in range(lo, hi):
+            rays = T(I.ray_batch(64, seed=300 + i), dev)
+            target = T(np.random.RandomState(400 + i).uniform(size=(64, 3)).astype(np.float32), dev)
+            rgb, _, _, extras = R.render(100, 100, K, chunk=32768, rays=torch.stack([rays[:, 0:3], rays[:, 3:6]], 0),
+                                         retraw=True, near=2.0, far=6.0, **kw)
+            opt.zero_grad()
+            (R.img2mse(rgb, target) + R.img2mse(extras['rgb0'], target)).backward()
+            opt.step()
+            for pg in opt.param_groups:
+                pg["lr"] = args.lrate * (0.1 ** (i / 250000))
+
+    def weights(kw):
+        return torch.cat([p.detach().reshape(-1) for m in (kw['network_fn'], kw['network_fine']) for p in m.parameters()])
+    with tempfile.TemporaryDirectory() as tmp:
+        torch.manual_seed(7)
+        a = mk(tmp, True)
+        kw, _, start, _, opt = R.create_nerf(a)
+        init = {n: {k: v.clone() for k, v in kw[n].state_dict().items()} for n in ('network_fn', 'network_fine')}
+        steps(kw, opt, a, 0, 5)
+        ref_w, ref_m, ref_v = weights(kw).clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone()
+        # interrupted run from the same initial weights
+        kw1, _, _, _, opt1 = R.create_nerf(a)
+        for n in init:
+            kw1[n].load_state_dict(init[n])
+        steps(kw1, opt1, a, 0, 3)
+        path = R.save_checkpoint(tmp, "exp", 3, kw1, opt1)
+        ck = torch.load(path, map_location="cpu", weights_only=False)
+        assert set(ck) == {'global_step', 'network_fn_state_dict', 'network_fine_state_dict', 'optimizer_state_dict'}
+        osd = ck['optimizer_state_dict']
+        assert set(osd) == {'state', 'param_groups'} and set(osd['state'][0]) == {'step', 'exp_avg', 'exp_avg_sq'}
+        cpu_twin = [torch.nn.Parameter(p.detach().cpu().clone()) for p in opt1.params]
+        torch.optim.Adam(cpu_twin, lr=1e-3).load_state_dict(osd)        # the reference's optimizer accepts it
+        kw2, _, start2, _, opt2 = R.create_nerf(mk(tmp, False))
+        assert start2 == 3 and opt2._step == 3 and abs(opt2.param_groups[0]['lr'] - opt1.param_groups[0]['lr']) < 1e-12
+        steps(kw2, opt2, a, 3, 5)
+        assert torch.equal(weights(kw2), ref_w) and torch.equal(opt2.exp_avg, ref_m) and torch.equal(opt2.exp_avg_sq, ref_v)
+
+
 # ------------------------------------------------------------------------------------------------
 # full-size (BASELINE config C2: 4096 rays, 64+128 samples, D=8/W=256) property tests
 def _c2(dev, B=4096):
