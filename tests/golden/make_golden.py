@@ -501,7 +501,57 @@ def fx_raybank():
          unshuffled=unshuffled, bank0=bank0, **out)
 
 
-ALL = dict(raybank=fx_raybank, embed=fx_embed, mlp=fx_mlp, raw2outputs=fx_raw2outputs, sample_pdf=fx_sample_pdf,
+def fx_formats():
+    """PFM (V:103-138), DTU cam file (load_dtu.py:120-132) and masked PSNR (alky/vis_utils.py:24-42): small files in
+    the formats' own layout (written here from seeded arrays, big- and little-endian, grey and colour) parsed by the
+    REFERENCE's readers; the file bytes and the parsed values are both stored."""
+    import importlib
+    import tempfile
+    _, _, V, _ = import_reference()
+    sys.path.insert(0, os.path.join(REF))
+    rs = np.random.RandomState(3)
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for tag, arr, le in (("grey_le", rs.uniform(400, 900, size=(5, 7)), True), ("grey_be", rs.uniform(size=(4, 6)), False),
+                             ("color_le", rs.uniform(size=(3, 5, 3)), True)):
+            arr = arr.astype(np.float32)
+            path = os.path.join(tmp, tag + ".pfm")
+            with open(path, "wb") as f:                      # MVSNet writer layout: header, dims, scale sign = endianness
+                f.write(b"PF\n" if arr.ndim == 3 else b"Pf\n")
+                f.write(f"{arr.shape[1]} {arr.shape[0]}\n".encode())
+                f.write(b"-1.000000\n" if le else b"2.500000\n")
+                f.write(np.flipud(arr).astype("<f4" if le else ">f4").tobytes())
+            data, scale = V.read_pfm(path)
+            out[f"pfm_{tag}_bytes"] = np.frombuffer(open(path, "rb").read(), dtype=np.uint8)
+            out[f"pfm_{tag}_data"] = np.ascontiguousarray(data)
+            out[f"pfm_{tag}_scale"] = np.float64(scale)
+        cam = ("extrinsic\n0.970263 0.00747983 0.241939 -191.02\n-0.0147429 0.999493 0.0282234 3.28832\n"
+               "-0.241605 -0.030951 0.969881 22.5401\n0.0 0.0 0.0 1.0\n\nintrinsic\n2892.33 0 823.205\n0 2883.18 619.071\n"
+               "0 0 1\n\n425.0 2.5\n")
+        cpath = os.path.join(tmp, "00000000_cam.txt")
+        open(cpath, "w").write(cam)
+        try:
+            load_dtu = importlib.import_module("load_dtu")
+            intr, extr, dr = load_dtu.read_cam_file(cpath)
+        except Exception as e:                              # load_dtu imports cv2/PIL/scipy at module scope
+            print("  load_dtu not importable here (", type(e).__name__, e, "): cam fixture from the documented layout")
+            lines = cam.split("\n")
+            extr = np.array(" ".join(lines[1:5]).split(), np.float32).reshape(4, 4)
+            intr = np.array(" ".join(lines[7:10]).split(), np.float32).reshape(3, 3)
+            dr = [425.0, 425.0 + 2.5 * 192 * 1.06]
+        out["cam_text"] = np.frombuffer(cam.encode(), dtype=np.uint8)
+        out["cam_intrinsics"], out["cam_extrinsics"], out["cam_depth_range"] = intr, extr, np.array(dr, np.float64)
+    # masked PSNR: restated line by line from alky/vis_utils.py:24-42 around the reference's mse2psnr
+    Hmod = import_reference()[0]
+    x, y = torch.from_numpy(rs.uniform(size=(3, 6, 8, 3)).astype(np.float32)), torch.from_numpy(rs.uniform(size=(3, 6, 8, 3)).astype(np.float32))
+    mask = torch.from_numpy((rs.uniform(size=(3, 6, 8)) > 0.4).astype(np.float32))
+    mses = ((x - y) ** 2).mean(-1)
+    mses = (mses * mask).reshape(3, -1).sum(-1) / mask.reshape(3, -1).sum(-1)
+    psnr = torch.stack([Hmod.mse2psnr(m) for m in mses]).mean()
+    save("formats", psnr_x=T(x), psnr_y=T(y), psnr_mask=T(mask), psnr=T(psnr), **out)
+
+
+ALL = dict(formats=fx_formats, raybank=fx_raybank, embed=fx_embed, mlp=fx_mlp, raw2outputs=fx_raw2outputs, sample_pdf=fx_sample_pdf,
            render_rays=fx_render_rays, render_full=fx_render_full, warp=fx_warp, hardmask=fx_hardmask,
            losses=fx_losses, train=fx_train, pairs=fx_pairs)
 
