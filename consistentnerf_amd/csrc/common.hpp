@@ -67,9 +67,9 @@ struct NetGeom {
   // 16-byte store each, 1 KiB contiguous, and the wgrad DMA moves a tile with one instruction.
   // s_mask: ReLU sign bits of every hidden layer (1 = pre-activation > 0), packed per lane of the producing wave:
   // layer block b (trunk l = 0..D-1, then the view branch) starts at s_mask + s_mb[b]; inside it half-wave hh owns
-  // md dwords (md = tiles/2 rounded up), dword d = tiles 2d, 2d+1, element (tile t, register r) at bit
-  // 31 - (16*(t&1) + r) (15 - r when the dword holds a single tile).  The backward reads masks from here, not from
-  // the activations.
+  // md dwords (md = tiles/2 rounded up), dword d = tiles 2d, 2d+1: upper 16 bits = even registers r of tile 2d then of
+  // tile 2d+1 (first = MSB), lower 16 bits = odd registers likewise; a single-tile dword holds 8 + 8 bits left-aligned
+  // (mlp_common.hpp relu_bits).  The backward reads masks from here, not from the activations.
   int s_enc, s_h[16], s_feat, s_denc, s_hv, s_mask, s_mb[17], s_rows;
   // backward workspace (gradient wrt pre-activations), logically [Mp][g_rows], same tile-major storage
   int g_z[16], g_feat, g_hv, g_out, g_rows;

@@ -255,32 +255,59 @@ __device__ __forceinline__ void pin(f32x16 (&X)[NT]) {
 }
 
 // ---- epilogues -------------------------------------------------------------------------------------------------------
-// In-place ReLU of NT tiles; when BITS, also packs the sign bits (x > 0) into MD = ceil(NT/2) dwords per lane
-// (layout: common.hpp s_mask).  One v_max per element, plus v_cmp + v_addc (bits = 2*bits + carry) when BITS.
+// In-place ReLU of NT tiles; when BITS (training), also packs the sign bits (x > 0) into MD = ceil(NT/2) dwords per
+// lane (common.hpp s_mask).  Inference: one v_max per element.  Training: packed fp32 math on register pairs,
+// 1.5 instructions per element instead of 3 (v_cmp + v_addc + v_max):
+//     flag = clamp(x * +inf)   -> 1.0 where x > 0, else 0.0 (0 * inf = NaN clamps to 0 under DX10_CLAMP)
+//     x    = x * flag          -> ReLU (negative inputs become -0.0, which behaves as 0 everywhere downstream)
+//     acc  = acc * 2 + flag    -> the pair's two bit streams, exact in fp32 for the 16 bits a dword half holds
+// Word layout: dword d covers tiles 2d, 2d+1; its upper 16 bits are the even registers r = 0, 2, .. 14 of tile 2d then
+// of tile 2d+1 (first element = MSB), its lower 16 bits the odd registers likewise.  A last dword holding a single
+// tile keeps 8 + 8 bits, left-aligned.  mask_bits consumes the words MSB first in exactly that element order.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 template <int NT, bool BITS>
 __device__ __forceinline__ void relu_bits(f32x16 (&Q)[NT], unsigned (&bits)[(NT + 1) / 2]) {
+  if (!BITS) {
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    if (BITS && (t & 1) == 0) bits[t >> 1] = 0u;
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float x = Q[t][r];
-      if (BITS) asm("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits[t >> 1]) : "v"(x) : "vcc");
-      Q[t][r] = x > 0.f ? x : 0.f;
-    }
+      for (int r = 0; r < 16; ++r) Q[t][r] = Q[t][r] > 0.f ? Q[t][r] : 0.f;
+    return;
+  }
+  const f32x2 inf2 = {__builtin_inff(), __builtin_inff()}, two2 = {2.f, 2.f};
+#pragma unroll
+  for (int d = 0; d < (NT + 1) / 2; ++d) {
+    f32x2 acc = {0.f, 0.f};
+#pragma unroll
+    for (int t = 2 * d; t < 2 * d + 2 && t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        f32x2 x = {Q[t][r], Q[t][r + 1]}, flag;
+        asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(flag) : "v"(x), "v"(inf2));
+        asm("v_pk_mul_f32 %0, %1, %2" : "=v"(x) : "v"(x), "v"(flag));
+        asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(acc) : "v"(acc), "v"(two2), "v"(flag));
+        Q[t][r] = x[0];
+        Q[t][r + 1] = x[1];
+      }
+    const bool single = 2 * d + 1 >= NT;
+    bits[d] = ((unsigned)acc[0] << (single ? 24 : 16)) | ((unsigned)acc[1] << (single ? 16 : 0));
   }
 }
 
-// Gradient mask: Q <- Q * [bit], consuming the words produced by relu_bits in the same element order
+// Gradient mask: Q <- Q * [bit], consuming the words produced by relu_bits MSB first in the same element order
 // (v_add_co shifts the next bit into vcc, v_cndmask applies it).
 template <int NT>
 __device__ __forceinline__ void mask_bits(f32x16 (&Q)[NT], unsigned (&bits)[(NT + 1) / 2]) {
-  if (NT & 1) bits[NT >> 1] <<= 16;   // a single tile in the last word: its 16 bits sit in the low half
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+  for (int d = 0; d < (NT + 1) / 2; ++d)
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-      asm("v_add_co_u32 %0, vcc, %0, %0\n\tv_cndmask_b32 %1, 0, %1, vcc" : "+v"(bits[t >> 1]), "+v"(Q[t][r]) : : "vcc");
+    for (int par = 0; par < 2; ++par)
+#pragma unroll
+      for (int t = 2 * d; t < 2 * d + 2 && t < NT; ++t)
+#pragma unroll
+        for (int r = par; r < 16; r += 2)
+          asm("v_add_co_u32 %0, vcc, %0, %0\n\tv_cndmask_b32 %1, 0, %1, vcc" : "+v"(bits[d]), "+v"(Q[t][r]) : : "vcc");
 }
 
 // 32-feature-tile stores of C-layout registers into a tile-major row block, as a `side` functor of the GEMMs:

@@ -118,15 +118,18 @@ def stash_blocks(stash, M, D, W, vd, in_chp=64):
     words = full[:M, r:].contiguous().view(torch.int32).cpu().numpy().astype(np.int64) & 0xffffffff
 
     def decode(col0, tiles, m_d):
-        """-> [M, 32*tiles] bool in feature order n = 32t + 8(r>>2) + 4hh + (r&3)"""
+        """-> [M, 32*tiles] bool in feature order n = 32t + 8(r>>2) + 4hh + (r&3); word layout of relu_bits
+        (mlp_common.hpp): MSB first, even registers of the dword's tiles, then the odd ones."""
         bits = np.zeros((M, 32 * tiles), dtype=bool)
         for hh in range(2):
-            for t in range(tiles):
-                wd = words[:, col0 + hh * m_d + (t >> 1)]
-                single = (tiles & 1) and (t >> 1) == tiles >> 1
-                for rr in range(16):
-                    pos = (15 - rr) if single else 31 - (16 * (t & 1) + rr)
-                    bits[:, 32 * t + 8 * (rr >> 2) + 4 * hh + (rr & 3)] = (wd >> pos) & 1
+            for d in range(m_d):
+                wd = words[:, col0 + hh * m_d + d]
+                pos = 31
+                for par in range(2):
+                    for t in range(2 * d, min(2 * d + 2, tiles)):
+                        for rr in range(par, 16, 2):
+                            bits[:, 32 * t + 8 * (rr >> 2) + 4 * hh + (rr & 3)] = (wd >> pos) & 1
+                            pos -= 1
         return bits
     for l in range(D):
         assert np.array_equal(decode(l * 2 * md, nt, md), out[f"h{l}"].numpy() > 0), f"sign bits of layer {l}"

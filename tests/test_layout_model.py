@@ -149,30 +149,34 @@ def test_forward_layer_chain():
 
 
 def test_relu_sign_bit_words():
-    """relu_bits / mask_bits (mlp_common.hpp): element (tile t, register r) of a lane -> bit 31 - (16*(t&1) + r) of
-    dword t>>1 (15 - r when the last dword holds a single tile); mask_bits consumes them MSB first in the same
-    element order."""
+    """relu_bits / mask_bits (mlp_common.hpp): per dword (tiles 2d, 2d+1) two fp32 bit streams acc = 2*acc + flag — even
+    registers in the upper 16 bits, odd ones in the lower 16 (8 + 8 left-aligned when the dword holds a single tile);
+    mask_bits consumes the word MSB first in the same element order."""
     rs = np.random.RandomState(5)
     for nt in (1, 2, 4, 8):
-        x = rs.normal(size=(nt, 16))
-        words = [0] * ((nt + 1) // 2)
-        for t in range(nt):                              # v_cmp + v_addc: bits = 2*bits + (x > 0)
-            for r in range(16):
-                words[t >> 1] = ((words[t >> 1] << 1) | int(x[t, r] > 0)) & 0xffffffff
-        for t in range(nt):
-            single = (nt & 1) and (t >> 1) == nt >> 1
-            for r in range(16):
-                pos = (15 - r) if single else 31 - (16 * (t & 1) + r)
-                assert (words[t >> 1] >> pos) & 1 == int(x[t, r] > 0)
-        w = list(words)
-        if nt & 1:
-            w[nt >> 1] = (w[nt >> 1] << 16) & 0xffffffff
+        x = rs.normal(size=(nt, 16)).astype(np.float32)
+        nd = (nt + 1) // 2
+        words = []
+        for d in range(nd):
+            acc = np.zeros(2, np.float32)
+            tiles = [t for t in (2 * d, 2 * d + 1) if t < nt]
+            for t in tiles:
+                for r in range(0, 16, 2):
+                    flag = (x[t, r:r + 2] > 0).astype(np.float32)        # clamp(x * inf)
+                    acc = acc * np.float32(2) + flag                      # v_pk_fma_f32, exact below 2^24
+            single = len(tiles) == 1
+            words.append(((int(acc[0]) << (24 if single else 16)) | (int(acc[1]) << (16 if single else 0))) & 0xffffffff)
         g = np.ones((nt, 16))
-        for t in range(nt):                              # v_add_co (carry = top bit) + v_cndmask
-            for r in range(16):
-                carry = w[t >> 1] >> 31
-                w[t >> 1] = (w[t >> 1] << 1) & 0xffffffff
-                g[t, r] = g[t, r] if carry else 0.0
+        w = list(words)
+        for d in range(nd):                                               # v_add_co (carry = top bit) + v_cndmask
+            for par in range(2):
+                for t in (2 * d, 2 * d + 1):
+                    if t >= nt:
+                        continue
+                    for r in range(par, 16, 2):
+                        carry = w[d] >> 31
+                        w[d] = (w[d] << 1) & 0xffffffff
+                        g[t, r] = g[t, r] if carry else 0.0
         assert np.array_equal(g, (x > 0).astype(np.float64))
 
 
