@@ -60,20 +60,28 @@ __global__ __launch_bounds__(64) void mlp_dgrad_k(BwdArgs a) {
     if (hh == 0) buf_store(grs, valid ? m * 32 : TM_OOB, tm_col(g.g_out), f32x4{d.x, d.y, d.z, d.w});
     // rgb_linear^T on the VALU, masked by the view-branch ReLU -> dZv (C-layout registers)
     f32x16 V[NTH];
+    {
+      f32x4 wq[3][NTH][4];   // all weight quads in flight before the first use: one exposed L2 round trip, not 12*NTH
 #pragma unroll
-    for (int t = 0; t < NTH; ++t)
+      for (int c = 0; c < 3; ++c)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < NTH; ++t)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const f32x4 w = buf_load(AP.rs, hh * 16, (int)(g.v_rgb + (int64_t)c * g.Wh + 32 * t + 8 * q) * 4);
+          for (int q = 0; q < 4; ++q)
+            wq[c][t][q] = buf_load(AP.rs, hh * 16, (int)(g.v_rgb + (int64_t)c * g.Wh + 32 * t + 8 * q) * 4);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) s[j] += w[j] * dc[c];
-        }
+      for (int t = 0; t < NTH; ++t)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) V[t][4 * q + j] = s[j];
-      }
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) sacc += wq[c][t][q][j] * dc[c];
+            V[t][4 * q + j] = sacc;
+          }
+    }
     mask_bits<NTH>(V, bv);
     CN_T(0)
     // dF = views_linears^T (feature columns only; gamma(d) needs no gradient) . dZv, no mask (feature_linear is linear)
@@ -83,14 +91,20 @@ __global__ __launch_bounds__(64) void mlp_dgrad_k(BwdArgs a) {
     // dZ_{D-1} = relu'(h_{D-1}) * (feature_linear^T . dF + alpha_linear^T . dsigma)
     a_prefetch3<NT>(A, AP, (int)g.t_feat, W, W / 8 - 1);
     load_bits<MD>(srs, smo, tm_col(g.s_mask + g.s_mb[g.D - 1]), bits);
+    {
+      f32x4 wq[NT][4];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 w = buf_load(AP.rs, hh * 16, (int)(g.v_alpha + 32 * t + 8 * q) * 4);
+        for (int q = 0; q < 4; ++q) wq[t][q] = buf_load(AP.rs, hh * 16, (int)(g.v_alpha + 32 * t + 8 * q) * 4);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) Y[t][4 * q + j] = w[j] * dc[3];
-      }
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) Y[t][4 * q + j] = wq[t][q][j] * dc[3];
+    }
     CN_T(4)
     gemm_reg3<NT, NT, false, false>(Y, X, A, AP, (int)g.t_feat, W, hh, TileStores<NT, NT>{X, grs, gvo, tm_col(g.g_feat)});
     CN_T(2)

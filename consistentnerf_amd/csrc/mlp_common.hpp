@@ -268,14 +268,20 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int NT, bool BITS>
 __device__ __forceinline__ void relu_bits(f32x16 (&Q)[NT], unsigned (&bits)[(NT + 1) / 2]) {
-  if (!BITS) {
+  const f32x2 inf2 = {__builtin_inff(), __builtin_inff()}, two2 = {2.f, 2.f};
+  if (!BITS) {   // (the packed form measured faster than 16 v_max per tile: register pairs move together)
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) Q[t][r] = Q[t][r] > 0.f ? Q[t][r] : 0.f;
+      for (int r = 0; r < 16; r += 2) {
+        f32x2 x = {Q[t][r], Q[t][r + 1]}, flag;
+        asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(flag) : "v"(x), "v"(inf2));
+        asm("v_pk_mul_f32 %0, %1, %2" : "=v"(x) : "v"(x), "v"(flag));
+        Q[t][r] = x[0];
+        Q[t][r + 1] = x[1];
+      }
     return;
   }
-  const f32x2 inf2 = {__builtin_inff(), __builtin_inff()}, two2 = {2.f, 2.f};
 #pragma unroll
   for (int d = 0; d < (NT + 1) / 2; ++d) {
     f32x2 acc = {0.f, 0.f};

@@ -128,14 +128,25 @@ __global__ __launch_bounds__(64) void mlp_fwd_k(FwdArgs a) {
     relu_bits<NT, TRAIN>(In, bits);
     if (TRAIN) store_bits<MD>(srs, smo, tm_col(g.s_mask + g.s_mb[l - 1]), bits);
     if (VD && l == g.D) {
+      // weight quads in flight 16 at a time before their FMAs: consumed one by one, every load would be a separate
+      // exposed L2 round trip (all 4*NT at once spill: both accumulator sets are live here)
+      constexpr int TB = NT < 4 ? NT : 4;
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
+      for (int t0 = 0; t0 < NT; t0 += TB) {
+        f32x4 wq[TB][4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 wv = buf_load(AP.rs, hh * 16, (int)(g.v_alpha + 32 * t + 8 * q) * 4);
+        for (int t = 0; t < TB; ++t)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) sig = __builtin_fmaf(In[t][4 * q + j], wv[j], sig);
-        }
+          for (int q = 0; q < 4; ++q) wq[t][q] = buf_load(AP.rs, hh * 16, (int)(g.v_alpha + 32 * (t0 + t) + 8 * q) * 4);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < TB; ++t)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sig = __builtin_fmaf(In[t0 + t][4 * q + j], wq[t][q][j], sig);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       sig += __shfl_xor(sig, 32, 64);
       sig += a.packed[g.b_alpha];
     }
@@ -221,16 +232,25 @@ __global__ __launch_bounds__(64) void mlp_fwd_k(FwdArgs a) {
     CN_T(3)
     // rgb_linear (H:125) straight from the registers: lane holds n = 32t + 8q + 4hh + j
     float o[3] = {0.f, 0.f, 0.f};
+    {
+      f32x4 wq[3][NTH][4];                              // all weight quads in flight first (see the sigma head)
 #pragma unroll
-    for (int t = 0; t < NTH; ++t)
+      for (int c = 0; c < 3; ++c)
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+        for (int t = 0; t < NTH; ++t)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const f32x4 wv = buf_load(AP.rs, hh * 16, (int)(g.v_rgb + (int64_t)c * g.Wh + 32 * t + 8 * q) * 4);
+          for (int q = 0; q < 4; ++q)
+            wq[c][t][q] = buf_load(AP.rs, hh * 16, (int)(g.v_rgb + (int64_t)c * g.Wh + 32 * t + 8 * q) * 4);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) o[c] = __builtin_fmaf(V[t][4 * q + j], wv[j], o[c]);
-        }
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int t = 0; t < NTH; ++t)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[c] = __builtin_fmaf(V[t][4 * q + j], wq[c][t][q][j], o[c]);
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c) o[c] += __shfl_xor(o[c], 32, 64);
     if (hh == 0)
