@@ -93,4 +93,68 @@ def allreduce_scalar_sum(x: torch.Tensor) -> torch.Tensor:
 
 def barrier():
     if world() > 1:
-        dist.barrier()
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
+
+
+# ---- inference: a frame's rows sharded over ranks (precedent RegNeRF/internal/models.py:311-322) ----------
+def row_block(H: int, r: Optional[int] = None, w: Optional[int] = None):
+    """Rank r renders image rows [lo, hi); every rank renders `rows` = ceil(H/w) rows so that the gather is
+    rectangular: the `rows - (hi - lo)` extra ones repeat the block's last row (edge padding) and are dropped when
+    the frame is reassembled.  Returns (lo, hi, row_index[rows])."""
+    r = rank() if r is None else r
+    w = world() if w is None else w
+    lo, hi = shard_bounds(H, r, w)
+    rows = -(-H // w)
+    idx = torch.arange(lo, lo + rows).clamp_(max=max(hi - 1, lo)).clamp_(max=H - 1)
+    return lo, hi, idx
+
+
+def gather_rows(block: torch.Tensor, H: int) -> torch.Tensor:
+    """All-gather of the per-rank row blocks [rows, W, ...] -> the frame [H, W, ...] on every rank (padding rows
+    dropped).  The only collective of the render path, one per output per frame."""
+    w = world()
+    if w == 1:
+        return block[:H]
+    parts = [torch.empty_like(block) for _ in range(w)]
+    dist.all_gather(parts, block.contiguous())
+    keep = []
+    for r, p in enumerate(parts):
+        lo, hi = shard_bounds(H, r, w)
+        keep.append(p[:hi - lo])
+    return torch.cat(keep, 0)
+
+
+def render_image_sharded(H, W, K, chunk, c2w, render_kwargs, render_fn=None, get_rays_fn=None):
+    """One frame of `render_path` (R:156) with its rows split over the ranks: each rank renders its row block through
+    the unchanged `render(rays=...)` (so viewdirs / NDC are derived exactly as for the full frame), then the blocks
+    are all-gathered.  Returns (rgb [H,W,3], disp [H,W]) on every rank — rays are independent, so the frame equals the
+    single-GPU one bit for bit."""
+    if render_fn is None or get_rays_fn is None:
+        from . import run_nerf, run_nerf_helpers
+        render_fn = render_fn or run_nerf.render
+        get_rays_fn = get_rays_fn or run_nerf_helpers.get_rays
+    lo, hi, idx = row_block(H)
+    rays_o, rays_d = get_rays_fn(H, W, K, c2w)
+    idx = idx.to(rays_o.device)
+    rays = torch.stack([rays_o[idx], rays_d[idx]], 0)            # [2, rows, W, 3]
+    out = render_fn(H, W, K, chunk=chunk, rays=rays, **render_kwargs)
+    rgb, disp = out[0], out[1]
+    return gather_rows(rgb, H), gather_rows(disp, H)
+
+
+def render_path_sharded(render_poses, hwf, K, chunk, render_kwargs, render_factor=0, render_fn=None, get_rays_fn=None):
+    """`render_path` (R:140-178) over all ranks -> (rgbs [N,H,W,3], disps [N,H,W]) numpy on every rank."""
+    import numpy as np
+    H, W, focal = hwf
+    if render_factor != 0:
+        H, W, focal = H // render_factor, W // render_factor, focal / render_factor
+    rgbs, disps = [], []
+    for c2w in render_poses:
+        with torch.no_grad():
+            rgb, disp = render_image_sharded(H, W, K, chunk, c2w[:3, :4], render_kwargs, render_fn, get_rays_fn)
+        rgbs.append(rgb.cpu().numpy())
+        disps.append(disp.cpu().numpy())
+    return np.stack(rgbs, 0), np.stack(disps, 0)

@@ -847,3 +847,37 @@ def test_ragged_batch_sizes(dev, M):
     g_big = torch.cat([p.grad.reshape(-1) for p in model.kernel_tensors()])
     assert torch.isfinite(g_small).all()
     assert (g_small - g_big).abs().max().item() <= 2e-5 * max(1e-12, g_big.abs().max().item())
+
+
+def test_sharded_render_path_equals_render_path(dev):
+    """§8e inference: a frame rendered as row blocks through render(rays=...) (what every rank of
+    distributed.render_path_sharded does; world 1 here, plus a hand-made 3-way split with edge padding) equals
+    render_path(c2w=...) bit for bit, NDC on and off."""
+    from consistentnerf_amd import run_nerf as R, distributed as D
+    from consistentnerf_amd.run_nerf_helpers import get_rays
+    g = golden("render_full_tiny")
+    K, c2w = g["K"], T(g["c2w"], dev)
+    coarse, _ = make_model(4, 128, True, 5, 31, dev)
+    fine, _ = make_model(4, 128, True, 5, 32, dev)
+    H, W = 13, 16
+    for ndc in (False, True):
+        kw = _kwargs(coarse, fine, 16, 16, 0.0, False, 0.0, False)
+        if ndc:
+            kw.pop("lindisp")
+        near, far = (0.0, 1.0) if ndc else (2.0, 6.0)
+        kw.update(ndc=ndc, near=near, far=far, use_viewdirs=True)
+        pose4 = torch.cat([c2w[:3, :4], torch.tensor([[0., 0., 0., 1.]], device=dev)], 0)
+        rgbs, disps = R.render_path([pose4], (H, W, float(K[0][0])), K, 100, kw)
+        rgbs_s, disps_s = D.render_path_sharded([pose4], (H, W, float(K[0][0])), K, 100, kw)
+        assert np.array_equal(rgbs, rgbs_s) and np.array_equal(disps, disps_s, equal_nan=True)
+        # the per-rank work of a 3-rank job, done serially: blocks 5+4+4 rows, each padded to 5
+        ro, rd = get_rays(H, W, K, c2w[:3, :4])
+        parts = []
+        for r in range(3):
+            lo, hi, idx = D.row_block(H, r, 3)
+            assert len(idx) == 5
+            idx = idx.to(dev)
+            with torch.no_grad():
+                out = R.render(H, W, K, chunk=100, rays=torch.stack([ro[idx], rd[idx]], 0), **kw)
+            parts.append(out[0][:hi - lo])
+        assert np.array_equal(torch.cat(parts, 0).cpu().numpy(), rgbs[0])
