@@ -56,6 +56,7 @@ SIGNATURES = {
                                   _vp, _vp]),
     "cnerf_loss_ws_floats": (_i64, []),
     "cnerf_masked_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
+    "cnerf_patch_depth_loss": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp, _vp]),
     "cnerf_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _f, _f, _f, _f, _f, _f, _vp]),
 }
 

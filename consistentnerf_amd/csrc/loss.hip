@@ -68,6 +68,102 @@ __global__ __launch_bounds__(T) void masked_loss_k(const float* __restrict__ rgb
   }
 }
 
+
+// ---- f-5: monocular-depth patch term (V:1678-1720) -------------------------------------------------------------------
+// Per patch of n rays: inverse rendered depth pr = nan_to_num(1 / where(d <= 0, 1e-4, d)) and the monocular prior
+// gt = nan_to_num(mono) are each min-max normalised over the prior's valid set m = (gt > 0), aligned by the mean
+// difference, and the mean squared residual / P / 2 is summed over the P patches.  One wave64 per patch (n = 256 ->
+// 4 elements per lane), everything re-read from L1/L2 between the reduction passes; butterfly reductions in a fixed
+// order, the P partial losses summed by thread 0.  The backward follows autograd's rules for the same expression:
+// full-reduction min()/max() split their gradient evenly over ties, nan_to_num passes it where 1/x is finite,
+// d(1/x) = -g (1/x)^2, and nothing flows where d <= 0 (the constant branch of the where()).
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float nan_to_num(float v) {
+  if (v != v) return 0.f;
+  if (v == INFINITY) return 3.402823466e+38f;
+  if (v == -INFINITY) return -3.402823466e+38f;
+  return v;
+}
+
+__global__ void patch_depth_loss_k(const float* __restrict__ depth, const float* __restrict__ mono, int P, int n,
+                                   float g_scale, float* __restrict__ loss, float* __restrict__ d_depth) {
+  __shared__ float part[16];
+  const int p = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const float* d = depth + (int64_t)p * n;
+  const float* g = mono + (int64_t)p * n;
+  auto inv = [&](int i) { const float x = d[i] <= 0.f ? 1e-4f : d[i]; return 1.f / x; };
+  // pass 1: ranges
+  float gmin = 1e5f, gmax = -INFINITY, pmin = 1e5f, pmax = -INFINITY;
+  for (int i = lane; i < n; i += 64) {
+    const float gt = nan_to_num(g[i]), pr = nan_to_num(inv(i));
+    const float m = gt > 0.f ? 1.f : 0.f;
+    gmin = fminf(gmin, gt > 0.f ? gt : 1e5f);
+    gmax = fmaxf(gmax, gt);
+    pmin = fminf(pmin, m * pr > 0.f ? pr : 1e5f);
+    pmax = fmaxf(pmax, m * pr);
+  }
+  gmin = wave_min(gmin); gmax = wave_max(gmax); pmin = wave_min(pmin); pmax = wave_max(pmax);
+  const float rg = gmax - gmin + 1e-4f, r = pmax - pmin + 1e-4f;
+  auto gtn = [&](int i) { const float gt = nan_to_num(g[i]); return (gt > 0.f ? 1.f : 0.f) * (gt - gmin) / rg; };
+  auto prq = [&](int i) { const float gt = nan_to_num(g[i]); return (gt > 0.f ? 1.f : 0.f) * (nan_to_num(inv(i)) - pmin); };
+  // pass 2: shift
+  double sd = 0.0;
+  for (int i = lane; i < n; i += 64) sd += (double)(prq(i) / r - gtn(i));
+  const float alpha = (float)(wave_sum(sd) / n);
+  // pass 3: residuals
+  double se2 = 0.0, se = 0.0;
+  for (int i = lane; i < n; i += 64) {
+    const float e = gtn(i) - prq(i) / r + alpha;
+    se2 += (double)(e * e); se += (double)e;
+  }
+  se2 = wave_sum(se2); se = wave_sum(se);
+  if (lane == 0) part[p] = (float)(se2 / n) / P / 2;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float l = 0.f;
+    for (int k = 0; k < P; ++k) l += part[k];
+    loss[0] = l;
+  }
+  if (!d_depth) return;
+  // pass 4: gradient sums.  dL/dprn_i = (mean(e) - e_i) / (n P)
+  const float ebar = (float)(se / n), w = g_scale / ((float)n * (float)P);
+  double s_mg = 0.0, s_gq = 0.0;
+  int cmin = 0, cmax = 0;
+  for (int i = lane; i < n; i += 64) {
+    const float gt = nan_to_num(g[i]), pr = nan_to_num(inv(i));
+    const float m = gt > 0.f ? 1.f : 0.f, q = m * (pr - pmin);
+    const float gi = w * (ebar - (gtn(i) - q / r + alpha));
+    s_mg += (double)(m * gi); s_gq += (double)(gi * q);
+    cmin += ((m * pr > 0.f ? pr : 1e5f) == pmin);
+    cmax += (m * pr == pmax);
+  }
+  s_mg = wave_sum(s_mg); s_gq = wave_sum(s_gq);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { cmin += __shfl_xor(cmin, o, 64); cmax += __shfl_xor(cmax, o, 64); }
+  const float d_r = (float)(-s_gq / ((double)r * (double)r));          // dL/dr
+  const float d_pmin = (float)(-s_mg / (double)r) - d_r, d_pmax = d_r;    // r = pmax - pmin + 1e-4
+  for (int i = lane; i < n; i += 64) {
+    const float gt = nan_to_num(g[i]), c = inv(i), pr = nan_to_num(c);
+    const float m = gt > 0.f ? 1.f : 0.f, q = m * (pr - pmin);
+    const float gi = w * (ebar - (gtn(i) - q / r + alpha));
+    float dpr = m * gi / r;
+    if (m * pr > 0.f && pr == pmin) dpr += d_pmin / (float)cmin;
+    if (m * pr == pmax) dpr += m * d_pmax / (float)cmax;
+    const float dc = (c == c && fabsf(c) != INFINITY) ? dpr : 0.f;     // nan_to_num backward
+    const float dx = -dc * c * c;                                      // reciprocal backward
+    d_depth[(int64_t)p * n + i] = d[i] <= 0.f ? 0.f : dx;
+  }
+}
+
 }  // namespace
 
 extern "C" int64_t cnerf_loss_ws_floats(void) { return 0; }
@@ -80,6 +176,15 @@ extern "C" int cnerf_masked_loss(const float* rgb, const float* target, const fl
   if (!rgb || !target || !loss || B <= 0 || (depth && !prior) || !(far > 0.f)) return CNERF_E_ARG;
   hipLaunchKernelGGL(masked_loss_k, dim3(1), dim3(T), 0, cn_stream(stream), rgb, target, depth, prior, mask, B, far,
                      coef, counts, g_scale, loss, d_rgb, d_depth);
+  CN_CHECK_LAUNCH();
+  return CNERF_OK;
+}
+
+extern "C" int cnerf_patch_depth_loss(const float* depth_pred, const float* mono, int P, int n, float g_scale,
+                                      float* loss, float* d_depth, void* stream) {
+  if (!depth_pred || !mono || !loss || P <= 0 || P > 16 || n <= 0) return CNERF_E_ARG;
+  hipLaunchKernelGGL(patch_depth_loss_k, dim3(1), dim3(64 * P), 0, cn_stream(stream), depth_pred, mono, P, n, g_scale,
+                     loss, d_depth);
   CN_CHECK_LAUNCH();
   return CNERF_OK;
 }

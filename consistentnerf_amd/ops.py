@@ -319,6 +319,18 @@ def masked_loss(rgb, target, depth, prior, mask, far: float, coef: float, counts
     return loss, d_rgb, d_depth
 
 
+def patch_depth_loss(depth_pred: Tensor, mono: Tensor, P: int, n: int, g_scale: float = 1.0, want_grad: bool = True):
+    """f-5 (V:1678-1720): (loss[1], d_depth[P*n] | None) over the first P*n rays."""
+    depth_pred, mono = _chk(depth_pred, "depth_pred"), _chk(mono, "mono")
+    if depth_pred.numel() < P * n or mono.numel() < P * n:
+        raise CnerfError(f"patch_depth_loss: need {P}x{n} values, got {depth_pred.numel()} / {mono.numel()}")
+    loss = torch.empty(1, device=depth_pred.device)
+    d = torch.empty(P * n, device=depth_pred.device) if want_grad else None
+    _lib.check(_lib.load().cnerf_patch_depth_loss(_p(depth_pred), _p(mono), int(P), int(n), float(g_scale), _p(loss),
+                                                  _p(d), _stream()), "cnerf_patch_depth_loss")
+    return loss, d
+
+
 def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float, beta1=0.9, beta2=0.999, eps=1e-8,
               clip: float = 0.0, grad_scale: float = 1.0):
     for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):

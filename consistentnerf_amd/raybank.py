@@ -94,3 +94,51 @@ def sample_image_rays(target, pose, H, W, K, N_rand, precrop_frac=None, select_i
     flat = sel[:, 0] * int(W) + sel[:, 1]
     batch_rays = torch.stack([r[flat, 0:3], r[flat, 3:6]], 0)
     return batch_rays, target[sel[:, 0], sel[:, 1], :3]
+
+
+# ---- patch sampler of run_nerf_view.train() (V:1471-1517) ------------------------------------------------------------
+def draw_patch_starts(H, W, n_patches=4, patch_size=16, precrop=None):
+    """Top-left corners of the `n_patches` patches, drawn from numpy's global RNG exactly as V:1477-1488 does (two
+    randint per patch; the white-background test at V:1497 can never reject a 256-pixel patch).  `precrop` = (dH, dW)
+    while i < precrop_iters; the column start is bounded below by H//2 - dH there, as in the reference."""
+    H, W = int(H), int(W)
+    starts = np.empty((n_patches, 2), dtype=np.int64)
+    for k in range(n_patches):
+        if precrop is not None:
+            dH, dW = precrop
+            starts[k, 0] = np.random.randint(H // 2 - dH, H // 2 + dH - patch_size, size=(1, 1, 1)).item()
+            starts[k, 1] = np.random.randint(H // 2 - dH, W // 2 + dW - patch_size, size=(1, 1, 1)).item()
+        else:
+            starts[k, 0] = np.random.randint(0, H - patch_size + 1, size=(1, 1, 1)).item()
+            starts[k, 1] = np.random.randint(0, W - patch_size + 1, size=(1, 1, 1)).item()
+    return starts
+
+
+def patch_coords(starts, patch_size=16, device=None):
+    """[P, 2] corners -> [P * ps * ps, 2] (row, col); within a patch the ROW index runs fastest (V:1490-1494)."""
+    s = torch.as_tensor(np.asarray(starts), dtype=torch.long, device=device).reshape(-1, 1, 2)
+    k = torch.arange(patch_size * patch_size, device=device)
+    off = torch.stack([k % patch_size, k // patch_size], -1)[None]
+    return (s + off).reshape(-1, 2)
+
+
+def sample_patch_rays(target, pose, H, W, K, N_rand, patch_starts, select_inds=None, precrop_frac=None, patch_size=16,
+                      extras=()):
+    """V:1452-1517: the P patches' pixels first, then N_rand distinct random pixels of the (cropped) grid ->
+    (batch_rays [2, P*ps*ps + N_rand, 3], target_s, select_coords [.., 2], [e[select_coords] for e in extras])
+    — `extras` are per-pixel maps sampled at the same pixels (depth priors, hard mask, monocular depth)."""
+    dev = target.device if isinstance(target, torch.Tensor) and target.is_cuda else torch.device(
+        "cuda", torch.cuda.current_device())
+    target = torch.as_tensor(target, dtype=torch.float32).to(dev)
+    c2w = torch.as_tensor(np.asarray(pose)[:3, :4] if not isinstance(pose, torch.Tensor) else pose[:3, :4],
+                          dtype=torch.float32)
+    r = ops.gen_rays(int(H), int(W), K, c2w, 0., 1., False, False, dev)
+    coords = crop_coords(int(H), int(W), precrop_frac).to(dev)
+    if select_inds is None:
+        select_inds = torch.randperm(coords.shape[0], device=dev)[:N_rand]
+    sel = torch.cat([patch_coords(patch_starts, patch_size, dev),
+                     coords[torch.as_tensor(select_inds, device=dev, dtype=torch.long)]], 0)
+    flat = sel[:, 0] * int(W) + sel[:, 1]
+    batch_rays = torch.stack([r[flat, 0:3], r[flat, 3:6]], 0)
+    ex = [torch.as_tensor(e).to(dev)[sel[:, 0], sel[:, 1]] for e in extras]
+    return batch_rays, target[sel[:, 0], sel[:, 1], :3], sel, ex

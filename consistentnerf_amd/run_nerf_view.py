@@ -159,3 +159,25 @@ def hardmask_losses(rgb, target, mask, hardmask_coef=0.2, depth=None, depth_prio
     batch is sharded over ranks (distributed.global_mask_counts) so the means stay global."""
     m = None if mask is None else mask.reshape(-1).to(torch.float32)
     return _MaskedLossFn.apply(rgb, depth, target, depth_prior, m, float(far), float(hardmask_coef), counts)
+
+
+class _PatchDepthLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, depth_pred, mono, patch_num, n):
+        loss, d = ops.patch_depth_loss(depth_pred, mono, patch_num, n, 1.0, ctx.needs_input_grad[0])
+        ctx.save_for_backward(d)
+        ctx.shape = depth_pred.shape
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        d, = ctx.saved_tensors
+        out = torch.zeros(ctx.shape, device=d.device).reshape(-1)
+        out[:d.numel()] = d * g
+        return out.reshape(ctx.shape), None, None, None
+
+
+def midas_patch_loss(depth_pred, mono_dpt_s, patch_num=4, patch_size=16):
+    """`mono_depth_mses` of V:1678-1720 (the monocular-depth patch term; its SSIM / LPIPS neighbours are out of scope):
+    the first patch_num * patch_size^2 rays of the batch are the sampled patches (raybank.sample_patch_rays)."""
+    return _PatchDepthLossFn.apply(depth_pred, mono_dpt_s, int(patch_num), int(patch_size) * int(patch_size))

@@ -171,6 +171,14 @@ int cnerf_masked_loss(const float* rgb, const float* target, const float* depth,
                       float g_scale, float* loss, float* d_rgb, float* d_depth, float* workspace,
                       void* stream);
 
+/* ---- f-5: monocular-depth patch term (V:1678-1720) --------------------------------------------- */
+/* depth_pred[P*n] = rendered depth of the P patches' rays (n = 16*16 in the reference, P = 4 <= 16), mono[P*n] = the
+ * monocular (MiDaS) inverse-depth prior at the same pixels.  loss[0] = sum_p mean_i((gtn_i - prn_i + alpha_p)^2) / P / 2
+ * with gtn / prn the min-max normalised prior / clipped inverse depth over the prior's valid set (mono > 0) and
+ * alpha_p = mean(prn - gtn).  d_depth[P*n] (optional) = g_scale * dloss/d depth_pred, autograd's tie rules. */
+int cnerf_patch_depth_loss(const float* depth_pred, const float* mono, int P, int n, float g_scale,
+                           float* loss, float* d_depth, void* stream);
+
 /* ---- f-1: optimiser tail  (clip_grad_value_ V:1983, Adam R:210/780, lr decay R:784-788) --------- */
 /* In-place Adam over n contiguous floats; clip<=0 disables the value clip; step is 1-based. */
 int cnerf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr,

@@ -483,3 +483,50 @@ def sample_image_rays(target: np.ndarray, pose: np.ndarray, H: int, W: int, K, s
     ro, rd = get_rays_np(H, W, K, np.asarray(pose)[:3, :4])
     sc = crop_coords(H, W, precrop_frac)[np.asarray(select_inds)]
     return np.stack([ro[sc[:, 0], sc[:, 1]], rd[sc[:, 0], sc[:, 1]]], 0), np.asarray(target)[sc[:, 0], sc[:, 1], :3]
+
+
+# ---- f-2 / f-5: patch sampler and the monocular-depth patch term of run_nerf_view.train() -----------------------------
+def patch_coords(starts, patch_size: int = 16) -> np.ndarray:
+    """V:1471-1503: pixel (row, col) lists of the sampled patches, in the reference's order — the FIRST index runs
+    fastest within a patch (its meshgrid is 'xy' and the pair is used as (row, col)) -> [P * ps * ps, 2]."""
+    out = []
+    for x0, y0 in np.asarray(starts).reshape(-1, 2):
+        k = np.arange(patch_size * patch_size)
+        out.append(np.stack([x0 + k % patch_size, y0 + k // patch_size], -1))
+    return np.concatenate(out, 0)
+
+
+def draw_patch_starts(H: int, W: int, n_patches: int = 4, patch_size: int = 16, precrop=None) -> np.ndarray:
+    """The np.random draws of V:1477-1488 (global numpy RNG, two randint per patch; the 'fewer than 257 white pixels'
+    test at V:1497 always passes for a 256-pixel patch, so no draw is ever rejected).  `precrop` = (dH, dW) during the
+    pre-crop iterations — the reference bounds the column start by H//2 - dH there (sic)."""
+    s = []
+    for _ in range(n_patches):
+        if precrop is not None:
+            dH, dW = precrop
+            x0 = np.random.randint(H // 2 - dH, H // 2 + dH - patch_size, size=(1, 1, 1))
+            y0 = np.random.randint(H // 2 - dH, W // 2 + dW - patch_size, size=(1, 1, 1))
+        else:
+            x0 = np.random.randint(0, H - patch_size + 1, size=(1, 1, 1))
+            y0 = np.random.randint(0, W - patch_size + 1, size=(1, 1, 1))
+        s.append((int(x0.item()), int(y0.item())))
+    return np.asarray(s, dtype=np.int64)
+
+
+def patch_depth_loss(depth_pred: Tensor, mono: Tensor, patch_num: int = 4, n: int = 256) -> Tensor:
+    """V:1678-1720 without the SSIM / LPIPS lines: sum over patches of the shift-aligned, min-max normalised
+    squared difference between clipped inverse rendered depth and the monocular prior, / patch_num / 2."""
+    one = torch.ones(1)
+    clip = 1 / torch.where(depth_pred <= 0, 0.0001 * one, depth_pred)
+    total = 0.0
+    for p in range(patch_num):
+        pr = torch.nan_to_num(clip[p * n:(p + 1) * n])
+        gt = torch.nan_to_num(mono[p * n:(p + 1) * n])
+        m = torch.where(gt > 0, one, torch.zeros(1))
+        lo = torch.where(gt > 0, gt, one * 10 ** 5).min()
+        gt = m * (gt - lo) / (gt.max() - lo + 0.0001)
+        lo = torch.where(m * pr > 0, pr, one * 10 ** 5).min()
+        pr = m * (pr - lo) / ((m * pr).max() - lo + 0.0001)
+        alpha = (pr - gt).mean()
+        total = total + ((gt - pr + alpha) ** 2).mean() / patch_num / 2
+    return total

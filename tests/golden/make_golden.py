@@ -551,7 +551,75 @@ def fx_formats():
     save("formats", psnr_x=T(x), psnr_y=T(y), psnr_mask=T(mask), psnr=T(psnr), **out)
 
 
-ALL = dict(formats=fx_formats, raybank=fx_raybank, embed=fx_embed, mlp=fx_mlp, raw2outputs=fx_raw2outputs, sample_pdf=fx_sample_pdf,
+
+def _ref_lines(path, first, last, must_contain):
+    """Lines [first, last] (1-based) of a reference source file, dedented — read at generation time and exec'd so that
+    statements which are inline in the reference's train() can be driven like a function.  Nothing of them is stored."""
+    import textwrap
+    lines = open(path).read().split("\n")[first - 1:last]
+    text = textwrap.dedent("\n".join(lines))
+    assert must_contain in lines[0], (lines[0], must_contain)
+    return text
+
+
+def fx_patch():
+    """Patch sampler (V:1472-1509) and the monocular-depth patch term (V:1681-1719) of run_nerf_view.train(): the
+    reference's own statements are read from its source and executed on seeded inputs (ssim / lpips_fn — unavailable
+    third-party nets, out of scope — stubbed to zero; they do not touch depth_mse)."""
+    src = os.path.join(REF, "run_nerf_view.py")
+    sampler = _ref_lines(src, 1472, 1509, "patch_size = 16")
+    term = _ref_lines(src, 1681, 1719, "depth_predict_clip = 1 /")
+    out = {}
+    # ---- sampler: 40 x 48 image, full grid and centre pre-crop (dH = 18, dW = 21 -> 36 x 42 window)
+    Hh, Ww = 40, 48
+    rs = np.random.RandomState(4)
+    img = rs.uniform(size=(Hh, Ww, 3)).astype(np.float32)
+    img[:10] = 1.0                                              # a white band (the sampler's background test reads it)
+    for tag, pre in (("full", False), ("crop", True)):
+        ns = dict(np=np, torch=torch, H=Hh, W=Ww, N_rand=37, target=torch.from_numpy(img),
+                  i=0, args=types.SimpleNamespace(precrop_iters=5 if pre else 0))
+        if pre:
+            dH, dW = int(Hh // 2 * 0.9), int(Ww // 2 * 0.9)
+            ns.update(dH=dH, dW=dW)
+            coords = torch.stack(torch.meshgrid(torch.linspace(Hh // 2 - dH, Hh // 2 + dH - 1, 2 * dH),
+                                                torch.linspace(Ww // 2 - dW, Ww // 2 + dW - 1, 2 * dW)), -1)
+            out["crop_dhw"] = np.array([dH, dW])
+        else:
+            coords = torch.stack(torch.meshgrid(torch.linspace(0, Hh - 1, Hh), torch.linspace(0, Ww - 1, Ww)), -1)
+        ns["coords"] = torch.reshape(coords, [-1, 2])
+        np.random.seed(21)
+        exec(sampler, ns)
+        out[f"{tag}_patch_idxs"] = ns["patch_idxs"].numpy()
+        out[f"{tag}_select_inds"] = np.asarray(ns["select_inds"])
+        out[f"{tag}_select_coords"] = ns["select_coords"].numpy()
+    # ---- patch term: 4 patches x 256 rays; depths with non-positive / NaN entries, priors with invalid (<= 0) pixels,
+    #      one patch with tied extrema (quantised values), one fully invalid patch in the second case
+    for tag in ("a", "b"):
+        rs = np.random.RandomState(8 if tag == "a" else 9)
+        dp = rs.uniform(1.5, 6.0, size=(1024 + 64,)).astype(np.float32)
+        if tag == "b":                                          # 1 / 1e-4 outliers then dominate the prediction's range
+            dp[rs.randint(0, 1024, 12)] = 0.0
+            dp[rs.randint(0, 1024, 6)] = -0.3
+        mono = rs.uniform(0.05, 1.0, size=(1024 + 64,)).astype(np.float32)
+        mono[rs.randint(0, 1024, 90)] = 0.0
+        dp[256:512] = np.round(dp[256:512] * 2) / 2             # ties in min / max of patch 1
+        mono[256:512] = np.round(mono[256:512] * 8) / 8
+        if tag == "b":
+            mono[768:1024] = 0.0                                # no valid prior pixel in patch 3
+            dp[5] = np.nan
+        dpt = torch.from_numpy(dp).requires_grad_(True)
+        ns = dict(torch=torch, patch_num=4, depth_pred=dpt, mono_dpts=np.zeros((1, 2, 2), np.float32), mono_dpt_s=torch.from_numpy(mono),
+                  rgb=torch.zeros(1088, 3), target_s=torch.zeros(1088, 3),
+                  ssim=lambda *a, **k: torch.zeros(1), lpips_fn=lambda *a, **k: torch.zeros(1))
+        exec(term, ns)
+        loss = ns["mono_depth_mses"]
+        g, = torch.autograd.grad(loss, dpt)
+        out[f"term_{tag}_depth"], out[f"term_{tag}_mono"] = dp, mono
+        out[f"term_{tag}_loss"], out[f"term_{tag}_grad"] = loss.detach().numpy(), g.numpy()
+    save("patch", image=img, hw=np.array([Hh, Ww]), **out)
+
+
+ALL = dict(patch=fx_patch, formats=fx_formats, raybank=fx_raybank, embed=fx_embed, mlp=fx_mlp, raw2outputs=fx_raw2outputs, sample_pdf=fx_sample_pdf,
            render_rays=fx_render_rays, render_full=fx_render_full, warp=fx_warp, hardmask=fx_hardmask,
            losses=fx_losses, train=fx_train, pairs=fx_pairs)
 

@@ -881,3 +881,59 @@ def test_sharded_render_path_equals_render_path(dev):
                 out = R.render(H, W, K, chunk=100, rays=torch.stack([ro[idx], rd[idx]], 0), **kw)
             parts.append(out[0][:hi - lo])
         assert np.array_equal(torch.cat(parts, 0).cpu().numpy(), rgbs[0])
+
+
+def test_patch_sampler_golden(dev):
+    """f-2 (V:1472-1517): patch pixels first (row index fastest), then the random pixels; rays / colours / per-pixel
+    maps gathered at those coordinates — against the reference's own statements (fixture `patch`)."""
+    from consistentnerf_amd import raybank as RB
+    g = golden("patch")
+    Hh, Ww = (int(v) for v in g["hw"])
+    K = I.intrinsics(Hh, Ww, 30.0)
+    pose = I.camera_pose(20.0, -15.0, 3.0)
+    ro, rd = O.get_rays_np(Hh, Ww, K, pose[:3, :4])
+    for tag in ("full", "crop"):
+        pre = tuple(int(v) for v in g["crop_dhw"]) if tag == "crop" else None
+        np.random.seed(21)
+        starts = RB.draw_patch_starts(Hh, Ww, 4, 16, pre)
+        assert np.array_equal(RB.patch_coords(starts, 16).numpy(), g[f"{tag}_patch_idxs"])
+        depth_map = np.arange(Hh * Ww, dtype=np.float32).reshape(Hh, Ww)
+        rays, tgt, sel, (dsel,) = RB.sample_patch_rays(T(g["image"], dev), pose, Hh, Ww, K, 37, starts,
+                                                       select_inds=g[f"{tag}_select_inds"],
+                                                       precrop_frac=0.9 if pre else None, extras=(depth_map,))
+        sc = g[f"{tag}_select_coords"]
+        assert np.array_equal(sel.cpu().numpy(), sc) and rays.shape == (2, 1024 + 37, 3)
+        assert np.array_equal(tgt.cpu().numpy(), g["image"][sc[:, 0], sc[:, 1]])
+        assert np.array_equal(dsel.cpu().numpy(), depth_map[sc[:, 0], sc[:, 1]])
+        check(rays[0], ro[sc[:, 0], sc[:, 1]], 0.0, "rays_o"); check(rays[1], rd[sc[:, 0], sc[:, 1]], 1e-6, "rays_d")
+
+
+def test_patch_depth_term_golden(dev):
+    """f-5 (V:1681-1719): value and gradient of the monocular-depth patch term vs the reference's own statements run
+    under autograd — ties in the patch extrema, non-positive / NaN depths, a patch without any valid prior pixel.
+    Tolerance: 1e-5 relative on the loss, 1e-4 of the patch's largest |gradient| per element (fp32 normalisation
+    by a range the 1/1e-4 outliers of case b inflate to 1e4)."""
+    from consistentnerf_amd import ops, run_nerf_view as V
+    g = golden("patch")
+    for tag in ("a", "b"):
+        dp, mono = T(g[f"term_{tag}_depth"], dev), T(g[f"term_{tag}_mono"], dev)
+        loss, d = ops.patch_depth_loss(dp, mono, 4, 256)
+        assert abs(loss.item() - float(g[f"term_{tag}_loss"])) <= 1e-5 * float(g[f"term_{tag}_loss"])
+        ref = g[f"term_{tag}_grad"]
+        got = d.cpu().numpy()
+        assert np.array_equal(np.isnan(got), np.isnan(ref[:1024]))
+        for p in range(4):
+            sl = slice(256 * p, 256 * (p + 1))
+            scale = np.nanmax(np.abs(ref[sl]))
+            err = np.nanmax(np.abs(got[sl] - ref[sl]))
+            assert err <= 1e-4 * scale + 1e-30, (tag, p, err, scale)
+        # the autograd surface: gradient reaches all 1088 rays' depth (zeros past the patches), scaled by the upstream
+        dpr = dp.clone().requires_grad_(True)
+        (3.0 * V.midas_patch_loss(dpr, mono, 4, 16)).backward()
+        gg = dpr.grad.cpu().numpy()
+        assert gg.shape == (1088,) and not gg[1024:].any()
+        m = ~np.isnan(ref[:1024])
+        assert np.allclose(gg[:1024][m], 3.0 * got[m], rtol=1e-6, atol=0)
+    # a second launch gives the same bits (fixed reduction order)
+    l2, d2 = ops.patch_depth_loss(dp, mono, 4, 256)
+    assert torch.equal(l2, loss) and np.array_equal(d2.cpu().numpy(), got, equal_nan=True)

@@ -231,3 +231,26 @@ def test_ray_bank_and_samplers_golden():
         assert np.array_equal(O.crop_coords(Hh, Ww, frac), g[f"nb_{tag}_coords"].astype(np.int64))
         rays, tgt = O.sample_image_rays(g["images"][2], g["poses"][2], Hh, Ww, K, g[f"nb_{tag}_inds"], frac)
         assert np.array_equal(rays, g[f"nb_{tag}_rays"]) and np.array_equal(tgt, g[f"nb_{tag}_tgt"])
+
+
+def test_patch_sampler_and_depth_term_golden():
+    """f-2 / f-5: the oracle's patch sampler and monocular-depth patch term against the reference's own statements
+    (V:1472-1509, V:1681-1719) executed on seeded inputs."""
+    g = golden("patch")
+    Hh, Ww = (int(v) for v in g["hw"])
+    for tag in ("full", "crop"):
+        pre = tuple(int(v) for v in g["crop_dhw"]) if tag == "crop" else None
+        np.random.seed(21)
+        starts = O.draw_patch_starts(Hh, Ww, 4, 16, pre)
+        pc = O.patch_coords(starts, 16)
+        assert np.array_equal(pc, g[f"{tag}_patch_idxs"])
+        coords = O.crop_coords(Hh, Ww, 0.9 if pre else None)
+        inds = np.random.choice(coords.shape[0], size=[37], replace=False)      # the draw that follows at V:1507
+        assert np.array_equal(inds, g[f"{tag}_select_inds"])
+        assert np.array_equal(np.concatenate([pc, coords[inds]], 0), g[f"{tag}_select_coords"])
+    for tag in ("a", "b"):
+        dp = torch.from_numpy(g[f"term_{tag}_depth"]).requires_grad_(True)
+        loss = O.patch_depth_loss(dp, torch.from_numpy(g[f"term_{tag}_mono"]), 4, 256)
+        gr, = torch.autograd.grad(loss, dp)
+        assert torch.equal(loss.detach(), torch.from_numpy(g[f"term_{tag}_loss"]))
+        assert np.array_equal(gr.numpy(), g[f"term_{tag}_grad"], equal_nan=True)
