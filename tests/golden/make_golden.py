@@ -619,7 +619,44 @@ def fx_patch():
     save("patch", image=img, hw=np.array([Hh, Ww]), **out)
 
 
-ALL = dict(patch=fx_patch, formats=fx_formats, raybank=fx_raybank, embed=fx_embed, mlp=fx_mlp, raw2outputs=fx_raw2outputs, sample_pdf=fx_sample_pdf,
+
+def fx_poses():
+    """LLFF pose pipeline and Blender camera ring: the reference's load_llff.load_llff_data with its disk reader
+    `_load_data` replaced by in-memory arrays (a seeded forward-facing rig in the raw poses_bounds layout; images are not
+    involved in the pose maths), and load_blender.pose_spherical."""
+    sys.path.insert(0, REF)
+    import load_llff as LL
+    import load_blender as LB
+    rs = np.random.RandomState(17)
+    N, Hh, Ww, factor = 7, 378, 504, 8
+    arr = np.zeros((N, 17))
+    for k in range(N):
+        a, b = rs.uniform(-0.15, 0.15, 2)
+        Rm = np.array([[1, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]]) @ \
+            np.array([[np.cos(b), 0, np.sin(b)], [0, 1, 0], [-np.sin(b), 0, np.cos(b)]])
+        t = rs.uniform(-1.5, 1.5, 3) * [1, 0.6, 0.2]
+        m = np.concatenate([Rm[:, [1, 0, 2]] * [1, -1, 1], t[:, None], np.array([[3024.], [4032.], [3260.]])], 1)   # [down? right back | t | hwf]
+        arr[k, :15] = m.reshape(-1)
+        arr[k, 15:] = [rs.uniform(8, 12), rs.uniform(60, 110)]
+    raw = arr.copy()
+
+    def fake_load_data(basedir, factor=None, **kw):      # what _load_data returns after reading poses_bounds.npy + images
+        poses = raw[:, :-2].reshape([-1, 3, 5]).transpose([1, 2, 0]).copy()
+        bds = raw[:, -2:].transpose([1, 0]).copy()
+        poses[:2, 4, :] = np.array([Hh, Ww]).reshape([2, 1])
+        poses[2, 4, :] = poses[2, 4, :] * 1. / factor
+        return poses, bds, np.zeros((Hh, Ww, 3, N), np.float32), np.zeros((N, Hh, Ww))
+    LL._load_data = fake_load_data
+    out = {}
+    for tag, kw in (("default", {}), ("norecenter", dict(recenter=False)), ("nobd", dict(bd_factor=None))):
+        images, poses, bds, render_poses, i_test, _ = LL.load_llff_data("unused", factor=factor, **kw)
+        out[f"{tag}_poses"], out[f"{tag}_bds"], out[f"{tag}_render"], out[f"{tag}_itest"] = poses, bds, render_poses, np.array(i_test)
+    ang = [(0.0, -30.0, 4.0), (120.0, -30.0, 4.0), (240.0, -30.0, 4.0), (-185.0, -30.0, 4.0), (37.5, 12.0, 2.5)]
+    sph = np.stack([LB.pose_spherical(*a).numpy() for a in ang], 0)
+    save("poses", poses_bounds=raw, hw=np.array([Hh, Ww]), factor=np.array(factor), sph_args=np.array(ang), sph=sph, **out)
+
+
+ALL = dict(poses=fx_poses, patch=fx_patch, formats=fx_formats, raybank=fx_raybank, embed=fx_embed, mlp=fx_mlp, raw2outputs=fx_raw2outputs, sample_pdf=fx_sample_pdf,
            render_rays=fx_render_rays, render_full=fx_render_full, warp=fx_warp, hardmask=fx_hardmask,
            losses=fx_losses, train=fx_train, pairs=fx_pairs)
 

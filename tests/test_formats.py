@@ -59,3 +59,25 @@ def test_pairs_split_lists():
         for k in d:
             assert np.array_equal(d[k], g[k])
     assert any(k.endswith("_train") for k in g.keys())
+
+
+def test_llff_pose_pipeline_and_blender_ring():
+    """llff_poses vs the reference's load_llff_data driven on the same raw poses_bounds array (axis reorder, bound
+    rescale, recentring, hold-out view, 60-pose spiral); pose_spherical vs load_blender's."""
+    g = golden("poses")
+    hw, factor = tuple(int(v) for v in g["hw"]), int(g["factor"])
+    for tag, kw in (("default", {}), ("norecenter", dict(recenter=False)), ("nobd", dict(bd_factor=None))):
+        poses, bds, render_poses, i_test = F.llff_poses(g["poses_bounds"].copy(), hw, factor, **kw)
+        assert poses.dtype == np.float32 and render_poses.shape == (60, 3, 4) and render_poses.dtype == np.float32
+        np.testing.assert_allclose(poses, g[f"{tag}_poses"], rtol=0, atol=1e-6 * np.abs(g[f"{tag}_poses"]).max())
+        np.testing.assert_allclose(bds, g[f"{tag}_bds"], rtol=1e-7)
+        np.testing.assert_allclose(render_poses, g[f"{tag}_render"], rtol=0, atol=2e-6)
+        assert i_test == int(g[f"{tag}_itest"])
+    for a, ref in zip(g["sph_args"], g["sph"]):
+        np.testing.assert_allclose(F.pose_spherical(*a), ref, rtol=0, atol=1e-6)
+    meta = {"camera_angle_x": 0.6911112070083618,
+            "frames": [{"file_path": f"./train/r_{k}", "transform_matrix": F.pose_spherical(30.0 * k, -30.0, 4.0).tolist()}
+                       for k in range(3)]}
+    poses, focal, files = F.read_transforms(meta, 800)
+    assert poses.shape == (3, 4, 4) and files[2] == "./train/r_2" and abs(focal - 1111.111) < 1e-2
+    np.testing.assert_array_equal(poses[1], F.pose_spherical(30.0, -30.0, 4.0))
