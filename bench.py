@@ -135,10 +135,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON: everything else that writes to fd 1 — the reference-style prints of
+    # create_nerf(), and RCCL's version banner, which the C library flushes at exit, i.e. AFTER the JSON — goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch.distributed as dist
     from consistentnerf_amd import distributed as D, ops
     from consistentnerf_amd import run_nerf as R
-    rank, world, local = D.init_from_env("nccl" if a.gpus > 1 else None)
+    rank, world, local = D.init_from_env("nccl" if (a.gpus > 1 or os.environ.get("CNERF_FORCE_DIST") == "1") else None)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -225,8 +231,10 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
-    if world > 1:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    os.close(json_fd)
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

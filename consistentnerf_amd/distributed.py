@@ -20,7 +20,9 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # CNERF_FORCE_DIST=1 builds the group even for a single rank, so that the RCCL init / all-reduce / barrier calls can be
+    # exercised on a 1-GPU box (collectives over one rank are identities)
+    if (world > 1 or os.environ.get("CNERF_FORCE_DIST") == "1") and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
@@ -62,15 +64,16 @@ def shard_batch(*tensors, dim: int = 0):
 def allreduce_mean_(flat_grad: torch.Tensor) -> torch.Tensor:
     """Sum the flat gradient over ranks, scale by 1/world.  One collective per step.  Use when every rank's
     loss is already a GLOBAL mean contribution scaled by world (plain per-rank means of equal shards)."""
-    if world() > 1:
+    if dist.is_initialized():
         dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
-        flat_grad.mul_(1.0 / world())
+        if world() > 1:
+            flat_grad.mul_(1.0 / world())
     return flat_grad
 
 
 def allreduce_sum_(flat_grad: torch.Tensor) -> torch.Tensor:
     """Sum only: for losses whose per-ray weights were already normalised by global counts."""
-    if world() > 1:
+    if dist.is_initialized():
         dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
     return flat_grad
 
@@ -92,7 +95,7 @@ def allreduce_scalar_sum(x: torch.Tensor) -> torch.Tensor:
 
 
 def barrier():
-    if world() > 1:
+    if dist.is_initialized():
         if dist.get_backend() == "nccl":
             dist.barrier(device_ids=[torch.cuda.current_device()])
         else:
