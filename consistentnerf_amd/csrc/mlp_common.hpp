@@ -329,16 +329,8 @@ struct TileStores {
   int voff, soff;
   __device__ __forceinline__ void operator()(int kg, int j, int t) const {
     if (j != 1 || t != 0) return;
-#if defined(CN_EXP) && (CN_EXP & 32)     // ablation 32: no tile stores
-    if (kg >= 0) return;
-#endif
-    const int i = kg;
-    const int tt = i >> 2, q = i & 3;
-#if defined(CN_EXP) && (CN_EXP & 128)   // ablation 128: 1 KiB-contiguous (tile-major) store addresses; layout is then wrong
-    buf_store(rs, (int)(threadIdx.x & 63) * 16, soff + (4 * tt + q) * 1024, f32x4{X[tt][4 * q], X[tt][4 * q + 1], X[tt][4 * q + 2], X[tt][4 * q + 3]});
-#else
+    const int tt = kg >> 2, q = kg & 3;
     buf_store(rs, voff, soff + (4 * tt + q) * 1024, f32x4{X[tt][4 * q], X[tt][4 * q + 1], X[tt][4 * q + 2], X[tt][4 * q + 3]});
-#endif
   }
 };
 

@@ -89,7 +89,7 @@ __device__ __forceinline__ void wgrad_body(const WgArgs& a, const WgJob& jb, flo
   const int64_t m_end = m_begin + a.chunk < a.Mp ? m_begin + a.chunk : a.Mp;
   const int nslab = __builtin_amdgcn_readfirstlane(m_end > m_begin ? (int)((m_end - m_begin) / TM) : 0);
   const int ntn = (jb.N + 31) >> 5, ntk = (jb.K + 31) >> 5;
-  const int tn0 = wn * AN, tk0 = wk * AK;          // first n / k tile of this wave
+  const int tn0 = __builtin_amdgcn_readfirstlane(wn * AN), tk0 = __builtin_amdgcn_readfirstlane(wk * AK);   // first n / k tile of this wave
   const bool active = tn0 < ntn && tk0 < ntk;      // wave-uniform
   // this split's rows of the two operands behind buffer resources; a lane past the operand's width reads out of
   // range (zeros land in the unused columns of the LDS row)
@@ -106,9 +106,12 @@ __device__ __forceinline__ void wgrad_body(const WgArgs& a, const WgJob& jb, flo
     for (int y = 0; y < AK; ++y)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
-  float bsum[AN];
+  // bias column sums, two tiles per v_pk_add_f32 (every VALU instruction costs MFMA issue time: ~7 cycles each)
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  constexpr int AN2 = (AN + 1) / 2;
+  f32x2 bsum2[AN2];
 #pragma unroll
-  for (int x = 0; x < AN; ++x) bsum[x] = 0.f;
+  for (int x = 0; x < AN2; ++x) bsum2[x] = f32x2{0.f, 0.f};
 
   // LDS = `nbuf` slab buffers of [X image | Y image], sized by this GEMM's operand widths: a full 256 x 256 GEMM
   // double-buffers (2 x 66 KiB); the narrow ones (heads, gamma columns) are latency-bound, not MFMA-bound, and get
@@ -190,7 +193,7 @@ __device__ __forceinline__ void wgrad_body(const WgArgs& a, const WgJob& jb, flo
       __builtin_amdgcn_sched_barrier(0);
       if (BS) {
 #pragma unroll
-        for (int x = 0; x < AN; ++x) bsum[x] += av[o][x];
+        for (int x = 0; x < AN2; ++x) bsum2[x] += f32x2{av[o][2 * x], av[o][2 * x + 1 < AN ? 2 * x + 1 : 2 * x]};
       }
 #pragma unroll
       for (int x = 0; x < AN; ++x)
@@ -204,28 +207,62 @@ __device__ __forceinline__ void wgrad_body(const WgArgs& a, const WgJob& jb, flo
     publish();
     CN_T(1)
   }
-  float* out = a.partials + (int64_t)split * a.pstride;
-  float* Wout = out + a.toff[jb.tensor];
+  // Epilogue: the wave's AN x AK accumulator tiles -> this split's slice of the partial buffer, 256 dword stores per
+  // lane.  Buffer stores against a resource that covers exactly the job's (N - n_lo) x ld rows: addresses are one
+  // per-lane VGPR (column, half-wave row) + a scalar row offset; lanes past K carry an out-of-range offset and are
+  // dropped by the hardware; nothing waits on anything.  (__float_as_uint, not __builtin_bit_cast: the latter applied to a
+  // vector ELEMENT reads element 0.)  (As plain pointer stores these were `flat_store` + a scratch reload of the
+  // job bounds + s_waitcnt vmcnt(0) EACH — the argument struct lives in scratch, a flat store may alias it — i.e. 256
+  // serialised round trips, 2.8 % of a 256x256 job.)
+  const int N = __builtin_amdgcn_readfirstlane(jb.N), K = __builtin_amdgcn_readfirstlane(jb.K);
+  const int n_lo = __builtin_amdgcn_readfirstlane(jb.n_lo), ld4 = __builtin_amdgcn_readfirstlane(jb.ld * 4);
+  const int col0 = __builtin_amdgcn_readfirstlane(jb.col0);
+  // (values read from the scratch-resident argument struct count as divergent: make the pointers provably uniform,
+  // or every store becomes a waterfall loop over the "different" resources)
+  auto uniform = [](const float* q) __attribute__((always_inline)) {
+    const unsigned long long v = (unsigned long long)q;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(v & 0xffffffffu));
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32));
+    return (const float*)(((unsigned long long)hi << 32) | lo);
+  };
+  const float* out = a.partials + (int64_t)split * a.pstride;
+  const rsrc_t wr = make_rsrc(uniform(out + a.toff[jb.tensor]), (unsigned)((N - n_lo) * ld4));
+  int kvo[AK];   // byte offset of (row 4*hh, column k) or an always-out-of-range one for k >= K
+#pragma unroll
+  for (int y = 0; y < AK; ++y) {
+    const int k = 32 * (tk0 + y) + i31;
+    kvo[y] = k < K ? (col0 + k) * 4 + hh * 4 * ld4 : TM_OOB;
+  }
 #pragma unroll
   for (int x = 0; x < AN; ++x)
 #pragma unroll
-    for (int y = 0; y < AK; ++y) {
-      const int k = 32 * (tk0 + y) + i31;
+    for (int r = 0; r < 16; ++r) {
+      const int n0 = 32 * (tn0 + x) + (r & 3) + 8 * (r >> 2);   // row of the hh = 0 half-wave (scalar); hh = 1: n0 + 4
+      if (n0 >= N) continue;
+      if (n0 >= n_lo && n0 + 4 < N) {   // both half-waves' rows valid (wave-uniform test)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int n = 32 * (tn0 + x) + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if (n >= jb.n_lo && n < jb.N && k < jb.K) Wout[(int64_t)(n - jb.n_lo) * jb.ld + jb.col0 + k] = acc[x][y][r];
+        for (int y = 0; y < AK; ++y)
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[x][y][r]), wr, kvo[y], (n0 - n_lo) * ld4, 0);
+      } else {   // ragged heads (N = 3, 4, 5; the sigma head starts at n_lo = 3): per-lane row test
+        const int n = n0 + 4 * hh;
+#pragma unroll
+        for (int y = 0; y < AK; ++y) {
+          const int k = 32 * (tk0 + y) + i31;
+          const int vo = (n >= n_lo && n < N && k < K) ? ((n - n_lo) * (ld4 >> 2) + col0 + k) * 4 : TM_OOB;
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[x][y][r]), wr, vo, 0, 0);
+        }
       }
     }
-  CN_T(0)
+  CN_T(3)
   CN_TEND
   if (BS) {
-    float* Bout = out + a.toff[jb.bias_tensor];
+    const rsrc_t br = make_rsrc(uniform(out + a.toff[jb.bias_tensor]), (unsigned)((N - n_lo) * 4));
 #pragma unroll
     for (int x = 0; x < AN; ++x) {
-      const float s = bsum[x] + __shfl_xor(bsum[x], 32, 64);
+      const float bx = bsum2[x >> 1][x & 1];
+      const float s = bx + __shfl_xor(bx, 32, 64);
       const int n = 32 * (tn0 + x) + i31;
-      if (hh == 0 && n >= jb.n_lo && n < jb.N) Bout[n - jb.n_lo] = s;
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(s), br, (hh == 0 && n >= n_lo && n < N) ? (n - n_lo) * 4 : TM_OOB, 0, 0);
     }
   }
 }
