@@ -184,21 +184,43 @@ __device__ __forceinline__ void wgrad_body(const WgArgs& a, const WgJob& jb, flo
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int st = 0; st < TM / 2; ++st) {
-      const int o = st % R;
-      if (st + LA < TM / 2) rd(st + LA, (st + LA) % R);
-      // one piece of slab sl + nbuf - 1 per step, into the buffer slab sl - 1 was read from (all its readers passed the
-      // previous barrier).  In a burst, the 16 KiB a wave requests exceed what the memory pipeline accepts at once and
-      // the in-order wave sits in the issue queue instead of feeding the MFMA pipe (measured: 25 % of the kernel).
-      piece(sl + nbuf - 1, nb, st);
-      __builtin_amdgcn_sched_barrier(0);
-      if (BS) {
+      const int o = st % R, nx = (st + LA) % R;
+      // Per step: AN+AK LDS reads (operands of step st+LA), one DMA piece of slab sl+nbuf-1 (into the buffer slab sl-1
+      // was read from: all its readers passed the previous barrier; one piece per step because a burst of 16 KiB per
+      // wave exceeds what the memory pipeline accepts at once and the in-order wave then sits in the issue queue —
+      // measured 25 % of the kernel), its scalar address arithmetic, and the bias adds.  A wave issues about one
+      // instruction per 4 cycles, so ~25 of them between two MFMAs (64 cycles apart) leave the matrix pipe idle for
+      // ~45 cycles per step (measured, 4.5 %): when a step has >= 8 MFMAs the side work is dealt out one item per MFMA.
+      // The 16 pieces go out two per step in the first half of the slab: the wave waits for its own pieces before the
+      // barrier that publishes the slab, and a piece issued in the last steps has not landed by then (HBM latency
+      // ~2000 cycles = 2 steps; measured 900 cycles of exposed wait per slab with one piece per step).
+      constexpr bool SPREAD = AN * AK >= AN + AK + 2;
+      if (!SPREAD) {
+        if (st + LA < TM / 2) rd(st + LA, nx);
+        piece(sl + nbuf - 1, nb, st);
+        __builtin_amdgcn_sched_barrier(0);
+        if (BS) {
 #pragma unroll
-        for (int x = 0; x < AN2; ++x) bsum2[x] += f32x2{av[o][2 * x], av[o][2 * x + 1 < AN ? 2 * x + 1 : 2 * x]};
+          for (int x = 0; x < AN2; ++x) bsum2[x] += f32x2{av[o][2 * x], av[o][2 * x + 1 < AN ? 2 * x + 1 : 2 * x]};
+        }
       }
 #pragma unroll
       for (int x = 0; x < AN; ++x)
 #pragma unroll
-        for (int y = 0; y < AK; ++y) acc[x][y] = mfma(av[o][x], bv[o][y], acc[x][y]);
+        for (int y = 0; y < AK; ++y) {
+          acc[x][y] = mfma(av[o][x], bv[o][y], acc[x][y]);
+          if (SPREAD) {
+            const int j = x * AK + y;
+            if (st + LA < TM / 2) {
+              if (j < AN) av[nx][j] = Xs[16 * (st + LA) + 4 * j * OCTF];
+              else if (j < AN + AK) bv[nx][j - AN] = Ys[16 * (st + LA) + 4 * (j - AN) * OCTF];
+            }
+            if (BS && j < AN2) bsum2[j] += f32x2{av[o][2 * j], av[o][2 * j + 1 < AN ? 2 * j + 1 : 2 * j]};
+            if (st < TM / 4 && j == AN + AK) piece(sl + nbuf - 1, nb, 2 * st);
+            if (st < TM / 4 && j == AN + AK + 1) piece(sl + nbuf - 1, nb, 2 * st + 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
       __builtin_amdgcn_sched_barrier(0);
     }
     CN_T(2)
