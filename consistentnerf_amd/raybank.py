@@ -78,6 +78,18 @@ def crop_coords(H, W, precrop_frac=None):
     return torch.stack(torch.meshgrid(rr, cc, indexing="ij"), -1).reshape(-1, 2)
 
 
+_COORDS = {}
+
+
+def _coords_on(dev, H, W, precrop_frac):
+    """The (cropped) pixel grid on the device, built once per (size, crop): the reference rebuilds it every step on the
+    host (R:741-753), which here would be a 3 MB host-to-device copy per step at LLFF size."""
+    key = (str(dev), int(H), int(W), precrop_frac)
+    if key not in _COORDS:
+        _COORDS[key] = crop_coords(int(H), int(W), precrop_frac).to(dev)
+    return _COORDS[key]
+
+
 def sample_image_rays(target, pose, H, W, K, N_rand, precrop_frac=None, select_inds=None):
     """R:730-757: N_rand distinct pixels of one image -> (batch_rays [2, B, 3], target_s [B, 3]).
     `select_inds` = indices into the (cropped) pixel grid; default: a device-side draw without replacement."""
@@ -87,7 +99,7 @@ def sample_image_rays(target, pose, H, W, K, N_rand, precrop_frac=None, select_i
     c2w = torch.as_tensor(np.asarray(pose)[:3, :4] if not isinstance(pose, torch.Tensor) else pose[:3, :4],
                           dtype=torch.float32)
     r = ops.gen_rays(int(H), int(W), K, c2w, 0., 1., False, False, dev)
-    coords = crop_coords(int(H), int(W), precrop_frac).to(dev)
+    coords = _coords_on(dev, H, W, precrop_frac)
     if select_inds is None:
         select_inds = torch.randperm(coords.shape[0], device=dev)[:N_rand]
     sel = coords[torch.as_tensor(select_inds, device=dev, dtype=torch.long)]
@@ -133,7 +145,7 @@ def sample_patch_rays(target, pose, H, W, K, N_rand, patch_starts, select_inds=N
     c2w = torch.as_tensor(np.asarray(pose)[:3, :4] if not isinstance(pose, torch.Tensor) else pose[:3, :4],
                           dtype=torch.float32)
     r = ops.gen_rays(int(H), int(W), K, c2w, 0., 1., False, False, dev)
-    coords = crop_coords(int(H), int(W), precrop_frac).to(dev)
+    coords = _coords_on(dev, H, W, precrop_frac)
     if select_inds is None:
         select_inds = torch.randperm(coords.shape[0], device=dev)[:N_rand]
     sel = torch.cat([patch_coords(patch_starts, patch_size, dev),
