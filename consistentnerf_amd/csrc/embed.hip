@@ -14,9 +14,10 @@ __global__ void embed_k(const float* __restrict__ x, int64_t M, int L, float* __
   for (int l = 0; l < L; ++l) {
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-      const float a = v[d] * f;
-      o[3 + 6 * l + d] = sinf(a);
-      o[3 + 6 * l + 3 + d] = cosf(a);
+      float sn, cs;
+      sincosf(v[d] * f, &sn, &cs);
+      o[3 + 6 * l + d] = sn;
+      o[3 + 6 * l + 3 + d] = cs;
     }
     f *= 2.f;
   }

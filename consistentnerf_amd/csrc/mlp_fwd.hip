@@ -51,9 +51,10 @@ __device__ __forceinline__ void encode(float* T, const float (&v)[3], int L, int
   for (int l = hh; l < L; l += 2) {
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-      const float arg = v[d] * f;
-      put(3 + 6 * l + d, sinf(arg));
-      put(3 + 6 * l + 3 + d, cosf(arg));
+      float sn, cs;
+      sincosf(v[d] * f, &sn, &cs);   // one range reduction for the pair (same values as sinf / cosf)
+      put(3 + 6 * l + d, sn);
+      put(3 + 6 * l + 3 + d, cs);
     }
     f *= 4.f;
   }
