@@ -181,3 +181,53 @@ def midas_patch_loss(depth_pred, mono_dpt_s, patch_num=4, patch_size=16):
     """`mono_depth_mses` of V:1678-1720 (the monocular-depth patch term; its SSIM / LPIPS neighbours are out of scope):
     the first patch_num * patch_size^2 rays of the batch are the sampled patches (raybank.sample_patch_rays)."""
     return _PatchDepthLossFn.apply(depth_pred, mono_dpt_s, int(patch_num), int(patch_size) * int(patch_size))
+
+
+# ----------------------------------------------------------------------------- in-loop consistency (a15)
+def ss_consistency(rays_o, rays_d, depth_cas_s, pose_ref, K, image_ref, depth_ref, H, W, render_kwargs, chunk=1024 * 32,
+                   occlusion_threshold=0.1, with_depth_loss=False):
+    """The `args.ss_loss` block of run_nerf_view_test.train() (VT:905-938): the batch's depth-prior points
+    `rays_o + depth_cas_s * rays_d` are warped into the reference view (`get_ref_rays`, VT variant), the in-bounds ones
+    define rays of the reference camera through the snapped pixels; those rays are rendered (a second full render pass)
+    and compared with the reference view's colours (and depth prior).  The occlusion mask |z_ref_cam - D_ref| < thr uses
+    the reference's doubling rule (thr = occlusion_threshold * 2^k, smallest k that lets some point pass) evaluated on
+    the device — the reference's `while mask.sum() == 0` loop costs a host sync per iteration.
+
+    rays_o, rays_d [N, 3], depth_cas_s [N], pose_ref [3, 4] (c2w), image_ref [H, W, 3], depth_ref [H, W].
+    Returns a dict: loss (the four VT:930-938 terms), mask_bound [1, N], mask [M, 1], threshold (0-d tensor, the one that
+    produced `mask`), batch_rays_ref [2, M, 3], rgb_target_ref [1, 3, M], rays_depth_ref [1, 1, M], and the second
+    render's rgb_ref, depth_pred_ref, extras_ref."""
+    dev = rays_o.device
+    point_samples_w = rays_o + depth_cas_s[:, None] * rays_d
+    c2w_ref = torch.eye(4)
+    c2w_ref[:3, :4] = torch.as_tensor(np.asarray(pose_ref.cpu() if isinstance(pose_ref, torch.Tensor) else pose_ref),
+                                      dtype=torch.float32)[:3, :4]
+    w2c_ref = torch.inverse(c2w_ref)                       # 4x4 on the host, as VT:910
+    Kt = torch.as_tensor(np.asarray(K.cpu() if isinstance(K, torch.Tensor) else K), dtype=torch.float32).to(dev)
+    img = torch.as_tensor(image_ref, dtype=torch.float32).to(dev)[None].permute(0, 3, 1, 2)
+    dep = torch.as_tensor(depth_ref, dtype=torch.float32).to(dev)[None]
+    rgb_target_ref, rays_depth_ref, pts_c_ref, rays_o_ref, rays_d_ref, mask_bound = get_ref_rays(
+        w2c_ref.to(dev)[None], c2w_ref.to(dev)[None], Kt[None], point_samples_w[None, :, None, :], img, dep, variant="VT")
+    if rays_o_ref.shape[0] == 0:
+        raise ops.CnerfError("ss_consistency: no point of the batch projects into the reference view "
+                             "(the reference loops forever here)")
+    adiff = (pts_c_ref[..., -1].reshape(-1, 1) - rays_depth_ref.reshape(-1)[:, None]).abs()
+    mn = adiff.min()
+    thr = torch.full((), float(occlusion_threshold), device=dev)
+    for _ in range(64):                                    # thr * 2^k, first k with some |diff| below it; no host sync
+        thr = torch.where(mn < thr, thr, thr * 2)
+    mask = adiff < thr
+    batch_rays_ref = torch.stack([rays_o_ref, rays_d_ref], 0)
+    rgb_ref, disp_ref, acc_ref, depth_pred_ref, extras_ref = render(H, W, K, chunk=chunk, rays=batch_rays_ref, retraw=True,
+                                                                    **render_kwargs)
+    tgt = rgb_target_ref.squeeze(0).permute(1, 0)
+    loss = img2mse(rgb_ref, tgt)
+    if with_depth_loss:
+        loss = loss + img2mse(depth_pred_ref, rays_depth_ref)
+    if 'rgb0' in extras_ref:
+        loss = loss + img2mse(extras_ref['rgb0'], tgt)
+        if with_depth_loss:
+            loss = loss + img2mse(extras_ref['depth0'], rays_depth_ref)
+    return dict(loss=loss, mask_bound=mask_bound, mask=mask, threshold=thr, batch_rays_ref=batch_rays_ref,
+                rgb_target_ref=rgb_target_ref, rays_depth_ref=rays_depth_ref, rgb_ref=rgb_ref,
+                depth_pred_ref=depth_pred_ref, extras_ref=extras_ref)

@@ -656,7 +656,48 @@ def fx_poses():
     save("poses", poses_bounds=raw, hw=np.array([Hh, Ww]), factor=np.array(factor), sph_args=np.array(ang), sph=sph, **out)
 
 
-ALL = dict(poses=fx_poses, patch=fx_patch, formats=fx_formats, raybank=fx_raybank, embed=fx_embed, mlp=fx_mlp, raw2outputs=fx_raw2outputs, sample_pdf=fx_sample_pdf,
+
+def fx_ssloss():
+    """In-loop cross-view consistency of run_nerf_view_test.train() (VT:905-938, the `args.ss_loss` block): the batch's
+    depth-prior points are warped into a random training view, the occlusion threshold is doubled until some point
+    passes, the warped rays are rendered and compared with the reference view's colours / depths.  The reference's own
+    statements are read from its source and executed around its own get_ref_rays / render / img2mse (module VT) with
+    small seeded networks (D=4/W=128, 16+16 samples, perturb 0)."""
+    src = os.path.join(REF, "run_nerf_view_test.py")
+    block = _ref_lines(src, 905, 938, "point_samples_w = rays_o + depth_cas_s")
+    Hh, Ww = 32, 40
+    poses = np.stack([I.camera_pose(0.0, -15.0, 4.0), I.camera_pose(18.0, -10.0, 4.2), I.camera_pose(-14.0, -12.0, 3.9)])
+    K, depths, images = _two_view_scene(Hh, Ww, 45.0, list(poses))
+    coarse, fine = make_model(H, 4, 128, True, 5, 31), make_model(H, 4, 128, True, 5, 32)
+    kw = _render_kwargs(VT, coarse, fine, 16, 16, 0.0, False, 0.0)
+    kw.update(near=2.0, far=7.0, ndc=False, use_viewdirs=True)
+    out = dict(K=K, poses=poses, depths=depths, images=images)
+    for tag, thr in (("a", 0.1), ("b", 1e-4)):            # b: the threshold has to double several times
+        rs = np.random.RandomState(5)
+        sel = rs.choice(Hh * Ww, 96, replace=False)
+        ro, rd = H.get_rays(Hh, Ww, K, T(poses[0]))
+        rays_o, rays_d = ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]
+        depth_cas_s = T(depths[0]).reshape(-1)[sel]
+        ns = dict(np=np, torch=torch, rays_o=rays_o, rays_d=rays_d, depth_cas_s=depth_cas_s, i_train=np.array([1, 2]),
+                  poses=T(poses), K=K, images=images, depths_cas=depths, H=Hh, W=Ww, i=100, loss=0,
+                  args=types.SimpleNamespace(occlusion_threshold=thr, chunk=4096, with_depth_loss=True, ss_loss=True),
+                  render_kwargs_train=kw, get_ref_rays=VT.get_ref_rays, render=VT.render, img2mse=VT.img2mse)
+        np.random.seed(3)
+        for m in (coarse, fine):
+            m.zero_grad()
+        exec(block, ns)
+        ns["loss"].backward()
+        out.update({f"{tag}.sel": sel, f"{tag}.ref_index": np.array(ns["ref_index"]), f"{tag}.mask_bound": ns["mask_bound"],
+                    f"{tag}.mask": ns["mask"], f"{tag}.thr_next": np.array(ns["occlusion_threshold"], np.float64),
+                    f"{tag}.rays_ref": ns["batch_rays_ref"], f"{tag}.rgb_target_ref": ns["rgb_target_ref"],
+                    f"{tag}.rays_depth_ref": ns["rays_depth_ref"], f"{tag}.rgb_ref": ns["rgb_ref"].detach(),
+                    f"{tag}.depth_pred_ref": ns["depth_pred_ref"].detach(), f"{tag}.loss": ns["loss"].detach()})
+        out.update(grad_summary(fine, f"{tag}.gf."))
+        out.update(grad_summary(coarse, f"{tag}.gc."))
+    save("ssloss", **out)
+
+
+ALL = dict(ssloss=fx_ssloss, poses=fx_poses, patch=fx_patch, formats=fx_formats, raybank=fx_raybank, embed=fx_embed, mlp=fx_mlp, raw2outputs=fx_raw2outputs, sample_pdf=fx_sample_pdf,
            render_rays=fx_render_rays, render_full=fx_render_full, warp=fx_warp, hardmask=fx_hardmask,
            losses=fx_losses, train=fx_train, pairs=fx_pairs)
 

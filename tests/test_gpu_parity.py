@@ -937,3 +937,37 @@ def test_patch_depth_term_golden(dev):
     # a second launch gives the same bits (fixed reduction order)
     l2, d2 = ops.patch_depth_loss(dp, mono, 4, 256)
     assert torch.equal(l2, loss) and np.array_equal(d2.cpu().numpy(), got, equal_nan=True)
+
+
+def test_in_loop_consistency_golden(dev):
+    """a15 (VT:905-938): warp of the batch's depth-prior points into a reference view, occlusion threshold doubling,
+    second render on the warped rays, the four loss terms and their weight gradients — against the reference's own
+    statements executed on the same seeded scene and networks (fixture `ssloss`).  Masks exact; rays 1e-5; rendered
+    colours / depths and the loss at the end-to-end render tolerance (5e-3, 5e-3 * far); gradients by summary."""
+    from consistentnerf_amd import run_nerf_view as V
+    g = golden("ssloss")
+    Hh, Ww, far = 32, 40, 7.0
+    K, poses = g["K"], g["poses"]
+    ro, rd = O.get_rays_np(Hh, Ww, K, poses[0][:3, :4])
+    for tag, thr in (("a", 0.1), ("b", 1e-4)):
+        coarse, _ = make_model(4, 128, True, 5, 31, dev)
+        fine, _ = make_model(4, 128, True, 5, 32, dev)
+        kw = _kwargs(coarse, fine, 16, 16, 0.0, False, 0.0, False)
+        kw.update(near=2.0, far=far, ndc=False, use_viewdirs=True)
+        sel, r = g[tag + ".sel"], int(g[tag + ".ref_index"])
+        out = V.ss_consistency(T(ro.reshape(-1, 3)[sel], dev), T(rd.reshape(-1, 3)[sel], dev),
+                               T(g["depths"][0].reshape(-1)[sel], dev), poses[r], K, g["images"][r], g["depths"][r],
+                               Hh, Ww, kw, chunk=4096, occlusion_threshold=thr, with_depth_loss=True)
+        assert np.array_equal(out["mask_bound"].cpu().numpy(), g[tag + ".mask_bound"])
+        assert np.array_equal(out["mask"].cpu().numpy(), g[tag + ".mask"])
+        assert abs(2.0 * out["threshold"].item() - float(g[tag + ".thr_next"])) < 1e-6 * float(g[tag + ".thr_next"])
+        check(out["batch_rays_ref"], g[tag + ".rays_ref"], 1e-5, "rays_ref")
+        check(out["rgb_target_ref"], g[tag + ".rgb_target_ref"], 0.0, "rgb_target_ref")
+        check(out["rays_depth_ref"], g[tag + ".rays_depth_ref"], 0.0, "rays_depth_ref")
+        check(out["rgb_ref"], g[tag + ".rgb_ref"], 5e-3, "rgb_ref")
+        check(out["depth_pred_ref"], g[tag + ".depth_pred_ref"], 5e-3 * far, "depth_pred_ref")
+        ref_loss = float(g[tag + ".loss"])
+        assert abs(out["loss"].item() - ref_loss) < 5e-3 * ref_loss
+        out["loss"].backward()
+        check_param_grads(fine, g, tag + ".gf.__full__", tag + ".gf.", rtol=2e-1, l2tol=1e-1)
+        check_param_grads(coarse, g, tag + ".gc.__full__", tag + ".gc.", rtol=2e-1, l2tol=1e-1)
