@@ -98,7 +98,26 @@ def cpu_baseline(seconds_budget=25.0):
         step(n + 1)
         n += 1
     dt = (time.perf_counter() - t0) / n
+    # single-thread figure (SURVEY §8d asks for both): one warm + one timed step of 64 rays
+    torch.set_num_threads(1)
+    Bc1 = 64
+    rays1, target1 = rays[:Bc1], target[:Bc1]
+
+    def step1(i):
+        out = O.render_rays(rays1, sd[0], sd[1], net, cfg, torch.rand(Bc1, NC), torch.rand(Bc1, NF))
+        loss = O.mse(out["rgb_map"], target1) + O.mse(out["rgb0"], target1)
+        grads = torch.autograd.grad(loss, params, allow_unused=True)
+        with torch.no_grad():
+            for p, g, mm, vv in zip(params, grads, m, v):
+                if g is not None:
+                    O.adam_step(p, g, mm, vv, n + 2 + i, 5e-4)
+    step1(0)
+    t1 = time.perf_counter()
+    step1(1)
+    dt1 = time.perf_counter() - t1
+    torch.set_num_threads(ncores)
     return {"value": Bc * (NC + NC + NF) / dt, "unit": "ray-samples/s", "cores": ncores, "kind": "port",
+            "single_thread_value": Bc1 * (NC + NC + NF) / dt1,
             "sample": f"{n} training steps of {Bc} rays (same C2 shapes: 64+192 samples, D=8/W=256, fwd+bwd+Adam), "
                       f"{dt:.2f} s/step, torch {torch.__version__} CPU fp32, {ncores} threads of {avail} usable / "
                       f"{os.cpu_count()} logical cpus"}
