@@ -442,61 +442,78 @@ def fx_pairs():
     save("pairs", **{k: np.asarray(v) for k, v in d.items()})
 
 
+def _ref_lines(path, first, last, must_contain):
+    """Lines [first, last] (1-based) of a reference source file, dedented — read at generation time and exec'd so that
+    statements which are inline in the reference's train() can be driven like a function.  Nothing of them is stored."""
+    import textwrap
+    lines = open(path).read().split("\n")[first - 1:last]
+    text = textwrap.dedent("\n".join(lines))
+    assert must_contain in lines[0], (lines[0], must_contain)
+    return text
+
+
 def fx_raybank():
-    """Ray bank + batching of train() (R:677-701, R:720-729) and the --no_batching sampler (R:730-757).  Those
-    statements are inline in the reference's train(); they are replayed here verbatim around the reference's OWN
-    get_rays_np / get_rays (imported), with numpy's / torch's RNG seeded so that the draws are part of the fixture."""
-    Hmod, _, _, _ = import_reference()
+    """Ray bank + batching of train() (R:683-691, R:720-729) and the --no_batching sampler (R:733-760).  Those statements
+    are inline in the reference's train(): they are read from its source at generation time and executed (`_ref_lines`)
+    around the reference's OWN get_rays_np / get_rays, with numpy's / torch's RNG seeded so that the draws are part of
+    the fixture."""
+    src = os.path.join(REF, "run_nerf.py")
+    build = _ref_lines(src, 683, 691, "rays = np.stack([get_rays_np(H, W, K, p)")
+    batching = _ref_lines(src, 720, 729, "batch = rays_rgb[i_batch:i_batch+N_rand]")
+    nobatch = _ref_lines(src, 733, 760, "img_i = np.random.choice(i_train)")
     Hh, Ww, focal = 6, 8, 7.5
     K = I.intrinsics(Hh, Ww, focal)
     rs = np.random.RandomState(11)
     poses = np.stack([I.camera_pose(25.0 * k, 10.0 + 5.0 * k, 3.0 + 0.1 * k)[:3, :4] for k in range(4)], 0).astype(np.float32)
     images = rs.uniform(size=(4, Hh, Ww, 3)).astype(np.float32)
     i_train = np.array([0, 2, 3])
-    # R:683-692
-    rays = np.stack([Hmod.get_rays_np(Hh, Ww, K, p) for p in poses[:, :3, :4]], 0)
-    rays_rgb = np.concatenate([rays, images[:, None]], 1)
-    rays_rgb = np.transpose(rays_rgb, [0, 2, 3, 1, 4])
-    rays_rgb = np.stack([rays_rgb[i] for i in i_train], 0)
-    rays_rgb = np.reshape(rays_rgb, [-1, 3, 3]).astype(np.float32)
-    unshuffled = rays_rgb.copy()
+    quiet = lambda *a, **k: None   # noqa: E731
+    ns = dict(np=np, torch=torch, get_rays_np=H.get_rays_np, H=Hh, W=Ww, K=K, poses=poses, images=images, i_train=i_train,
+              print=quiet)
+    # the bank is identical whatever the shuffle: build once unshuffled (shuffle patched out), once for real
+    real_shuffle = np.random.shuffle
+    np.random.shuffle = lambda a: None
+    try:
+        exec(build, ns)
+    finally:
+        np.random.shuffle = real_shuffle
+    unshuffled = ns["rays_rgb"].copy()
     np.random.seed(5)
-    np.random.shuffle(rays_rgb)
-    bank0 = rays_rgb.copy()
-    # R:720-729, N_rand = 50 -> the third batch crosses the epoch end (144 rows)
-    N_rand, i_batch = 50, 0
-    rr = torch.from_numpy(rays_rgb)
+    exec(build, ns)
+    bank0 = ns["rays_rgb"].copy()
+    # N_rand = 50 -> the third batch crosses the epoch end (144 rows)
     out = {}
+    ns.update(N_rand=50, i_batch=0, rays_rgb=torch.from_numpy(ns["rays_rgb"]))
     torch.manual_seed(3)
     for it in range(4):
-        batch = rr[i_batch:i_batch + N_rand]
-        batch = torch.transpose(batch, 0, 1)
-        out[f"rays{it}"], out[f"tgt{it}"] = T(batch[:2]), T(batch[2])
-        i_batch += N_rand
-        if i_batch >= rr.shape[0]:
-            rand_idx = torch.randperm(rr.shape[0])
-            out["rand_idx"] = rand_idx.numpy()
-            rr = rr[rand_idx]
-            i_batch = 0
-    # R:730-757 (no_batching), with and without the centre pre-crop
+        exec(batching, ns)
+        out[f"rays{it}"], out[f"tgt{it}"] = T(ns["batch_rays"]), T(ns["target_s"])
+        if "rand_idx" in ns and "rand_idx" not in out:
+            out["rand_idx"] = ns["rand_idx"].numpy()
+    # --no_batching, with and without the centre pre-crop; the image index is pinned (i_train = [2]) and its draw consumed
     for tag, frac in (("full", None), ("crop", 0.5)):
-        target = torch.from_numpy(images[2])
-        rays_o, rays_d = Hmod.get_rays(Hh, Ww, K, torch.from_numpy(poses[2]))
-        if frac is not None:
-            dH, dW = int(Hh // 2 * frac), int(Ww // 2 * frac)
-            coords = torch.stack(torch.meshgrid(torch.linspace(Hh // 2 - dH, Hh // 2 + dH - 1, 2 * dH),
-                                                torch.linspace(Ww // 2 - dW, Ww // 2 + dW - 1, 2 * dW)), -1)
-        else:
-            coords = torch.stack(torch.meshgrid(torch.linspace(0, Hh - 1, Hh), torch.linspace(0, Ww - 1, Ww)), -1)
-        coords = torch.reshape(coords, [-1, 2])
-        np.random.seed(9)
         n = 5 if frac is not None else 20
-        select_inds = np.random.choice(coords.shape[0], size=[n], replace=False)
-        sc = coords[select_inds].long()
-        out[f"nb_{tag}_inds"] = select_inds
-        out[f"nb_{tag}_rays"] = T(torch.stack([rays_o[sc[:, 0], sc[:, 1]], rays_d[sc[:, 0], sc[:, 1]]], 0))
-        out[f"nb_{tag}_tgt"] = T(target[sc[:, 0], sc[:, 1]])
-        out[f"nb_{tag}_coords"] = T(coords)
+        ns2 = dict(np=np, torch=torch, get_rays=H.get_rays, H=Hh, W=Ww, K=K, poses=torch.from_numpy(poses),
+                   images=images, i_train=np.array([2]), device="cpu", N_rand=n, i=0, start=0, print=quiet,
+                   args=types.SimpleNamespace(precrop_iters=1 if frac is not None else 0, precrop_frac=frac))
+        np.random.seed(9)                        # select_inds is the first draw after this seed (the image pick is pinned)
+        real_choice = np.random.choice
+        calls = []
+
+        def choice(a, *args, **kw):              # the image pick must not consume the seeded stream the fixture pins
+            if not calls:
+                calls.append(1)
+                return 2
+            return real_choice(a, *args, **kw)
+        np.random.choice = choice
+        try:
+            exec(nobatch, ns2)
+        finally:
+            np.random.choice = real_choice
+        out[f"nb_{tag}_inds"] = np.asarray(ns2["select_inds"])
+        out[f"nb_{tag}_rays"] = T(ns2["batch_rays"])
+        out[f"nb_{tag}_tgt"] = T(ns2["target_s"])
+        out[f"nb_{tag}_coords"] = T(ns2["coords"])
     save("raybank", poses=poses, images=images, i_train=i_train, hwf=np.array([Hh, Ww, focal], np.float32),
          unshuffled=unshuffled, bank0=bank0, **out)
 
@@ -550,16 +567,6 @@ def fx_formats():
     psnr = torch.stack([Hmod.mse2psnr(m) for m in mses]).mean()
     save("formats", psnr_x=T(x), psnr_y=T(y), psnr_mask=T(mask), psnr=T(psnr), **out)
 
-
-
-def _ref_lines(path, first, last, must_contain):
-    """Lines [first, last] (1-based) of a reference source file, dedented — read at generation time and exec'd so that
-    statements which are inline in the reference's train() can be driven like a function.  Nothing of them is stored."""
-    import textwrap
-    lines = open(path).read().split("\n")[first - 1:last]
-    text = textwrap.dedent("\n".join(lines))
-    assert must_contain in lines[0], (lines[0], must_contain)
-    return text
 
 
 def fx_patch():
