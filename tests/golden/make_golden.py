@@ -295,6 +295,16 @@ def fx_warp():
     save("warp", **out)
 
 
+def _ref_lines(path, first, last, must_contain):
+    """Lines [first, last] (1-based) of a reference source file, dedented — read at generation time and exec'd so that
+    statements which are inline in the reference's train() can be driven like a function.  Nothing of them is stored."""
+    import textwrap
+    lines = open(path).read().split("\n")[first - 1:last]
+    text = textwrap.dedent("\n".join(lines))
+    assert must_contain in lines[0], (lines[0], must_contain)
+    return text
+
+
 def reference_hard_masks(Hh, Ww, K, poses, depths, images, i_train, thr0, chunk=5120):
     """Drives the reference's own get_ref_rays (run_nerf_view.py:576-627) with the control flow of the
     mask precompute at run_nerf_view.py:994-1046 (per-5120-pixel chunk, threshold doubled until some
@@ -352,6 +362,15 @@ def fx_hardmask():
     i_train = [0, 1, 2]   # view 3 is a held-out view -> all-zero mask (V:1043)
     masks, thr = reference_hard_masks(Hh, Ww, K, poses, depths, images, i_train, 0.1)
     assert (thr[:, 3] > 0.1).any(), "fixture must exercise the doubling loop"
+    # the masks themselves are pinned on the reference's OWN block (V:999-1046, read from its source and executed; its
+    # per-view JPEG dump goes to a no-op); reference_hard_masks above only adds the per-chunk thresholds it does not keep
+    block = _ref_lines(os.path.join(REF, "run_nerf_view.py"), 999, 1046, "for tgt_index in range(images.shape[0]):")
+    ns = dict(np=np, torch=torch, os=os, images=images, i_train=i_train, poses=np.stack(poses), H=Hh, W=Ww, K=K,
+              depths_cas=depths, get_rays=V.get_rays, get_ref_rays=V.get_ref_rays, mask_all=[],
+              args=types.SimpleNamespace(occlusion_threshold=0.1, train_view_num=3), basedir="", expname="", scene="",
+              imageio=types.SimpleNamespace(imwrite=lambda *a, **k: None))
+    exec(block, ns)
+    assert np.array_equal(np.stack(ns["mask_all"]), masks), "restated control flow disagrees with the reference block"
     save("hardmask_tiny", K=K, poses=np.stack(poses), depths=depths, images=images,
          i_train=np.array(i_train), masks=masks, thr=thr)
 
@@ -440,16 +459,6 @@ def fx_pairs():
     import io
     d = U(io.BytesIO(raw)).load()
     save("pairs", **{k: np.asarray(v) for k, v in d.items()})
-
-
-def _ref_lines(path, first, last, must_contain):
-    """Lines [first, last] (1-based) of a reference source file, dedented — read at generation time and exec'd so that
-    statements which are inline in the reference's train() can be driven like a function.  Nothing of them is stored."""
-    import textwrap
-    lines = open(path).read().split("\n")[first - 1:last]
-    text = textwrap.dedent("\n".join(lines))
-    assert must_contain in lines[0], (lines[0], must_contain)
-    return text
 
 
 def fx_raybank():
