@@ -10,12 +10,17 @@
 // stash / gradient workspace are stored as 32-point x 8-column blocks (common.hpp), one instruction moves one block
 // (1 KiB contiguous) into a padded slot of the LDS image; the MFMA A operand of step s is one `ds_read_b32` per tile
 // (column 32x + lane&31 of point 2s+hh; B likewise from Ys) at an IMMEDIATE offset from one per-lane base,
-// conflict-free.  The inner loop is VALU-free apart from the bias column sums: fp32 MFMA and the VALU share the
+// conflict-free.  The inner loop is VALU-free apart from the packed bias column sums: fp32 MFMA and the VALU share the
 // SIMD's datapath (mlp_common.hpp), every VALU instruction is MFMA time lost.  Reads run one step ahead of the
-// MFMAs that consume them (sched_barriers pin the order).  Two LDS buffers: the DMA of slab s+1 runs under the
-// 16 steps x (an x ak) MFMAs of slab s; one barrier per slab.
-// GEMMs are launched largest-first over many small point ranges so the tail of the grid is short; split
-// partials are reduced in a fixed order by a second kernel (bit-reproducible run to run).
+// MFMAs that consume them, and every side instruction of a step (reads, DMA pieces and their scalar address
+// arithmetic, bias adds) is dealt out one per MFMA: a wave issues ~1 instruction per 4 cycles, a bunch of 25 between
+// two MFMAs would idle the matrix pipe (sched_barriers pin the order).  2 LDS buffers for a 256 x 256 GEMM, 3-4 for
+// the narrow ones: the DMA of slab s+1 is issued in the first half of slab s (so that it has landed at the barrier)
+// and runs under its 16 steps x (an x ak) MFMAs; one barrier per slab.  The epilogue writes the accumulators with
+// scalar-addressed buffer stores.
+// GEMMs are launched largest-first over many small point ranges so the tail of the grid is short (measured makespan =
+// the packing bound at M = 786 432); split partials are reduced in a fixed order by a second kernel (bit-reproducible
+// run to run).
 #include <stdlib.h>
 
 #include "mlp_common.hpp"
