@@ -194,3 +194,21 @@ def test_two_rank_gloo_sharded_render_path(tmp_path):
                         "--master-addr", "127.0.0.1", "--master-port", "29541", str(script), ROOT],
                        capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "RENDER_OK 2" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_bench_roofline_constants_match_the_architecture():
+    """bench.py's FLOP-per-ray-sample constants recomputed from the D=8/W=256/viewdirs layer list, and the
+    committed PMC summaries it reads for `roofline.traffic` parse to plausible byte counts."""
+    sys.path.insert(0, ROOT)
+    import bench
+    W, Wh, xe, de = 256, 128, 63, 27
+    layers = [(W, xe)] + [(W, W)] * 4 + [(W, W + xe)] + [(W, W)] * 2 + [(Wh, W + de), (W, W), (1, W), (3, Wh)]
+    fwd = sum(o * i for o, i in layers)
+    assert fwd == bench.MAC_FWD == bench.MAC_WGRAD == 593408
+    # dgrad skips inputs that need no gradient: gamma(x) into layer 0 and into the skip layer, gamma(d) into the view layer
+    assert fwd - (W * xe + W * xe + Wh * de) == bench.MAC_DGRAD == 557696
+    assert 2 * (bench.MAC_FWD + bench.MAC_DGRAD + bench.MAC_WGRAD) == 3489024
+    t = bench.pmc_traffic("mlp_wgrad", 786432)
+    assert t is not None and 15e9 < t < 25e9            # ~16.2 GB algorithmic reads + 1.5 GB of partials
+    assert bench.pmc_traffic("mlp_fwd_train", 786432) > 8e9   # the 8.2 GB stash
+    assert bench.pmc_traffic("nonexistent", 1) is None
