@@ -24,6 +24,24 @@ class Ptrs(C.Structure):
     _fields_ = [("p", C.c_void_p * MAX_TENSORS)]
 
 
+class RenderCfg(C.Structure):
+    """struct cnerf_render_cfg"""
+    _fields_ = [("Nc", C.c_int32), ("Nf", C.c_int32), ("lindisp", C.c_int32), ("white_bkgd", C.c_int32),
+                ("ray_stride", C.c_int32), ("train", C.c_int32)]
+
+
+class RenderOut(C.Structure):
+    """struct cnerf_render_out"""
+    _fields_ = [(n, C.c_void_p) for n in ("rgb_map", "disp_map", "acc_map", "depth_map", "rgb0", "disp0", "acc0",
+                                          "depth0", "z_std", "raw", "z_vals", "weights")]
+
+
+class RenderGrads(C.Structure):
+    """struct cnerf_render_grads"""
+    _fields_ = [(n, C.c_void_p) for n in ("g_rgb_map", "g_disp_map", "g_acc_map", "g_depth_map", "g_rgb0", "g_disp0",
+                                          "g_acc0", "g_depth0")]
+
+
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _NetP, _PtrsP = C.POINTER(Net), C.POINTER(Ptrs)
 
@@ -49,6 +67,11 @@ SIGNATURES = {
     "cnerf_composite_bwd": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cnerf_sample_pdf": (_i, [_vp, _vp, _vp, _i64, _i64, _i, _i, _vp, _vp, _vp]),
     "cnerf_resample": (_i, [_vp, _vp, _vp, _i64, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "cnerf_render_ws_floats": (_i64, [_NetP, _NetP, C.POINTER(RenderCfg), _i64]),
+    "cnerf_render_fwd": (_i, [_NetP, _vp, _NetP, _vp, _vp, _i64, C.POINTER(RenderCfg), _vp, _vp, _vp, _i64, _vp, _vp,
+                              C.POINTER(RenderOut), _vp, _vp]),
+    "cnerf_render_bwd": (_i, [_NetP, _vp, _NetP, _vp, _vp, _i64, C.POINTER(RenderCfg), _vp, _vp, C.POINTER(RenderGrads),
+                              _vp, _PtrsP, _PtrsP, _i, _vp]),
     "cnerf_gen_rays": (_i, [_i, _i, _f, _f, _f, _f, C.POINTER(_f), _f, _f, _i, _i, _f, _f, _vp, _vp]),
     "cnerf_pack_rays": (_i, [_vp, _vp, _i64, _f, _f, _i, _i, _f, _f, _vp, _vp]),
     "cnerf_warp_points": (_i, [_vp, _i64, C.POINTER(_f), _f, _f, _f, _f, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),

@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import CnerfError, Net, Ptrs
+from ._lib import CnerfError, Net, Ptrs, RenderCfg, RenderGrads, RenderOut
 
 Tensor = torch.Tensor
 
@@ -220,6 +220,66 @@ def mlp_backward(spec: NetSpec, packed: Tensor, d_raw: Tensor, B: int, S: int, s
         _lib.check(lib.cnerf_mlp_wgrad(C.byref(net), B, S, _p(stash), _p(ws), C.byref(ptrs), int(accumulate),
                                        _stream()), "cnerf_mlp_wgrad")
     return grads
+
+
+# ------------------------------------------------------------------------------------------ render_rays as one call
+class RenderState:
+    """What cnerf_render_bwd needs from the forward call it follows: the workspace (z, raw, weights, stashes) and the
+    call's arguments."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def render_forward(spec_c: NetSpec, packed_c: Tensor, spec_f: Optional[NetSpec], packed_f: Optional[Tensor], rays: Tensor,
+                   Nc: int, Nf: int, t_rand: Optional[Tensor] = None, u: Optional[Tensor] = None,
+                   noise0: Optional[Tensor] = None, noise1: Optional[Tensor] = None, lindisp: bool = False,
+                   white_bkgd: bool = False, train: bool = False, retraw: bool = False):
+    """cnerf_render_fwd: render_rays (R:311-421 / V:441-551) of one ray batch in one C call.  Returns (dict with the
+    reference's keys + depth maps, RenderState for render_backward)."""
+    lib = _lib.load()
+    rays, t_rand, u = _chk(rays, "rays"), _chk(t_rand, "t_rand"), _chk(u, "u")
+    noise0, noise1 = _chk(noise0, "noise0"), _chk(noise1, "noise1")
+    B, dev = rays.shape[0], rays.device
+    cfg = RenderCfg(int(Nc), int(Nf), int(lindisp), int(white_bkgd), int(rays.shape[1]), int(train))
+    nc, nf = spec_c.c(), (spec_f.c() if spec_f is not None else None)
+    nfp = C.byref(nf) if nf is not None else None
+    n = lib.cnerf_render_ws_floats(C.byref(nc), nfp, C.byref(cfg), B)
+    if n < 0:
+        raise CnerfError("cnerf_render_ws_floats: inconsistent arguments")
+    ws = torch.empty(n, device=dev, dtype=torch.float32)
+    S = Nc + Nf
+    ch = (spec_f if (spec_f is not None and Nf > 0) else spec_c).raw_ch
+    o = {k: torch.empty(B, 3, device=dev) if k.startswith("rgb") else torch.empty(B, device=dev)
+         for k in ("rgb_map", "disp_map", "acc_map", "depth_map")}
+    if Nf > 0:
+        o.update({k: torch.empty(B, 3, device=dev) if k.startswith("rgb") else torch.empty(B, device=dev)
+                  for k in ("rgb0", "disp0", "acc0", "depth0", "z_std")})
+    if retraw:
+        o["raw"] = torch.empty(B, S, ch, device=dev)
+    out = RenderOut(**{k: v.data_ptr() for k, v in o.items()})
+    stride = 0 if (u is None or u.dim() == 1 or u.shape[0] == 1) else Nf
+    _lib.check(lib.cnerf_render_fwd(C.byref(nc), _p(packed_c), nfp, _p(packed_f), _p(rays), B, C.byref(cfg),
+                                    _p(_t_vals(Nc, dev)), _p(t_rand), _p(u), stride, _p(noise0), _p(noise1), C.byref(out),
+                                    _p(ws), _stream()), "cnerf_render_fwd")
+    st = RenderState(spec_c=spec_c, packed_c=packed_c, spec_f=spec_f, packed_f=packed_f, rays=rays, B=B, cfg=cfg,
+                     noise0=noise0, noise1=noise1, ws=ws)
+    return o, st
+
+
+def render_backward(st: RenderState, grads_in: dict, grads_c: List[Tensor], grads_f: Optional[List[Tensor]],
+                    accumulate: bool = False):
+    """cnerf_render_bwd: upstream gradients of the maps (dict with any of rgb_map, disp_map, acc_map, depth_map, rgb0,
+    disp0, acc0, depth0) -> parameter gradients of the coarse / fine network, written into the given tensors."""
+    lib = _lib.load()
+    keep = {k: _chk(v, k) for k, v in grads_in.items() if v is not None}
+    g = RenderGrads(**{"g_" + k: v.data_ptr() for k, v in keep.items()})
+    nc, nf = st.spec_c.c(), (st.spec_f.c() if st.spec_f is not None else None)
+    pc, pf = _ptrs(grads_c), (_ptrs(grads_f) if grads_f is not None else None)
+    _lib.check(lib.cnerf_render_bwd(C.byref(nc), _p(st.packed_c), C.byref(nf) if nf is not None else None,
+                                    _p(st.packed_f), _p(st.rays), st.B, C.byref(st.cfg), _p(st.noise0), _p(st.noise1),
+                                    C.byref(g), _p(st.ws), C.byref(pc), C.byref(pf) if pf is not None else None,
+                                    int(accumulate), _stream()), "cnerf_render_bwd")
 
 
 # ------------------------------------------------------------------------------------------ compositing

@@ -129,6 +129,43 @@ int cnerf_resample(const float* z, const float* weights, const float* u, int64_t
                    int Nc, int Nf, float* z_fine, float* z_std, float* samples, int64_t* inds,
                    void* stream);
 
+/* ---- a3 as one call: render_rays (R:311-421 / V:441-551) and its autograd ---------------------------------------- */
+/* The launch sequence of one ray batch — coarse_z -> [encoding + MLP](coarse) -> composite -> (Nf > 0:) resample ->
+ * [encoding + MLP](fine) -> composite — and its backward (composite_bwd -> dgrad -> wgrad per level; no gradient
+ * through the resampling, R:397), composed from the entry points above inside ONE caller-provided workspace of
+ * cnerf_render_ws_floats() floats that also carries everything the backward needs (the "saved-for-backward blob").
+ * Randomness stays the caller's: t_rand[B,Nc] (NULL: no jitter), u[B,Nf] (row stride 0 broadcasts one row),
+ * noise0[B,Nc] / noise1[B,Nc+Nf] already scaled by raw_noise_std (NULL: none); t_vals[Nc] = linspace(0,1,Nc).
+ * fine == NULL with Nf > 0 evaluates the second level with the coarse network (R:402) and its gradients add up. */
+typedef struct cnerf_render_cfg {
+  int32_t Nc, Nf;        /* N_samples, N_importance                                      */
+  int32_t lindisp;       /* sample linearly in inverse depth (R:362-364)                  */
+  int32_t white_bkgd;    /* R:305-306                                                     */
+  int32_t ray_stride;    /* 8 or 11 floats per ray: o, d, near, far, (viewdirs)           */
+  int32_t train;         /* keep the stashes: cnerf_render_bwd may follow                 */
+} cnerf_render_cfg;
+typedef struct cnerf_render_out {            /* device pointers; every one may be NULL                      */
+  float *rgb_map, *disp_map, *acc_map, *depth_map;   /* [B,3] [B] [B] [B] of the last level                 */
+  float *rgb0, *disp0, *acc0, *depth0;               /* coarse level (Nf > 0 only)                           */
+  float *z_std;                                      /* [B] (Nf > 0 only, R:415)                             */
+  float *raw, *z_vals, *weights;                     /* last level: [B,S,C] [B,S] [B,S], S = Nc + Nf         */
+} cnerf_render_out;
+typedef struct cnerf_render_grads {          /* upstream gradients of the maps above (NULL = zero)          */
+  const float *g_rgb_map, *g_disp_map, *g_acc_map, *g_depth_map, *g_rgb0, *g_disp0, *g_acc0, *g_depth0;
+} cnerf_render_grads;
+int64_t cnerf_render_ws_floats(const cnerf_net* coarse, const cnerf_net* fine, const cnerf_render_cfg* cfg, int64_t B);
+int cnerf_render_fwd(const cnerf_net* coarse, const float* packed_coarse, const cnerf_net* fine,
+                     const float* packed_fine, const float* rays, int64_t B, const cnerf_render_cfg* cfg,
+                     const float* t_vals, const float* t_rand, const float* u, int64_t u_row_stride,
+                     const float* noise0, const float* noise1, const cnerf_render_out* out, float* workspace,
+                     void* stream);
+/* Same nets / rays / cfg / noise / workspace as the forward call it follows (cfg->train != 0).  Parameter gradients
+ * go to grads_coarse / grads_fine (layout of cnerf_ptrs as for cnerf_mlp_bwd); accumulate != 0 adds into them. */
+int cnerf_render_bwd(const cnerf_net* coarse, const float* packed_coarse, const cnerf_net* fine,
+                     const float* packed_fine, const float* rays, int64_t B, const cnerf_render_cfg* cfg,
+                     const float* noise0, const float* noise1, const cnerf_render_grads* g, float* workspace,
+                     const cnerf_ptrs* grads_coarse, const cnerf_ptrs* grads_fine, int accumulate, void* stream);
+
 /* ---- a1: ray generation  (get_rays H:164-173, ndc_rays H:186-202, render R:100-125) ------------- */
 /* Builds rays[H*W, 8|11] = o, d, near, far, (viewdirs) for a full image from c2w[3,4] (12 floats,
  * HOST pointer) and K = fx, fy, cx, cy; viewdirs are normalised pre-NDC directions (R:103-110);
