@@ -59,6 +59,21 @@ def main():
     torch.cuda.synchronize()
     out["hard_masks_3views_512x640_s"] = time.perf_counter() - t0
     out["hard_mask_fraction"] = float(masks.mean())
+    # CPU oracle beside it (forward-only at C5 shapes, bounded sample): 2048 rays of the same frame
+    from oracle import nerf_oracle as O
+    ncores = max(1, min(len(os.sched_getaffinity(0)), 32))
+    torch.set_num_threads(ncores)
+    sd = [O.as_tensors(I.nerf_state_dict(8, 256, 10, 4, 5, True, seed=s_)) for s_ in (21, 22)]
+    net, cfg = O.NetCfg(8, 256, output_ch=5), O.RenderCfg(64, 128, 0.0)
+    rb = torch.from_numpy(I.ray_batch(2048, seed=5, near=0.0, far=1.0))
+    with torch.no_grad():
+        O.render_rays(rb[:256], sd[0], sd[1], net, cfg)
+        t0 = time.perf_counter()
+        O.render_rays(rb, sd[0], sd[1], net, cfg)
+        dtc = time.perf_counter() - t0
+    out["cpu_oracle_inference_ray_samples_per_s"] = 2048 * 256 / dtc
+    out["cpu_oracle_threads"] = ncores
+    out["cpu_oracle_frame_s_extrapolated"] = rays * 256 / out["cpu_oracle_inference_ray_samples_per_s"]
     print(json.dumps(out))
 
 
