@@ -14,6 +14,8 @@ Stated tolerances (fp32 path, v_mfma_f32_32x32x2_f32 + OCML sin/cos/exp vs ATen/
                            2^9-frequency encoding, see test_render_rays_golden); 2e-5 when the oracle is evaluated at
                            the kernel's own sample depths
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -1010,3 +1012,60 @@ def test_render_fwd_bwd_single_call_equals_python_surface(dev, Nf, vd, perturb):
     same(gc, coarse)
     if Nf:
         same(gf, fine)
+
+
+def test_plain_c_program_uses_the_abi(dev, tmp_path):
+    """The boundary without PyTorch: tests/c_abi/render_smoke.c (C99, gcc, links libcnerf_hip.so + the HIP runtime) packs
+    two networks, renders a ray batch and runs the backward through include/cnerf.h; its maps and all parameter
+    gradients equal the same calls made from Python through ctypes, bit for bit."""
+    import subprocess
+    from consistentnerf_amd import _lib, ops, run_nerf as R
+    from consistentnerf_amd.run_nerf_helpers import pytest_uniform
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    exe = str(tmp_path / "render_smoke")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    cc = ["gcc", "-std=c99", "-O1", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(root, "include"),
+          os.path.join(here, "c_abi", "render_smoke.c"), "-o", exe, "-L/opt/rocm/lib", "-lamdhip64", "-L" + libdir,
+          "-l:" + os.path.basename(_lib.LIB_PATH), "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath," + libdir]
+    r = subprocess.run(cc, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    D, W, B, Nc, Nf = 8, 256, 80, 64, 128
+    coarse, _ = make_model(D, W, True, 5, 61, dev)
+    fine, _ = make_model(D, W, True, 5, 62, dev)
+    rays = T(I.ray_batch(B, seed=12), dev)
+    t_rand, u = pytest_uniform((B, Nc), dev), pytest_uniform((B, Nf), dev)
+    keys = ["rgb_map", "disp_map", "acc_map", "depth_map", "rgb0", "disp0", "acc0", "depth0"]
+    rs = np.random.RandomState(6)
+    gin = {k: T(rs.normal(size=(B, 3) if k.startswith("rgb") else (B,)).astype(np.float32), dev) for k in keys}
+    # reference: the same entry points through ctypes
+    out, st = ops.render_forward(coarse.spec(), R._packed(coarse), fine.spec(), R._packed(fine), rays, Nc, Nf,
+                                 t_rand=t_rand, u=u, white_bkgd=True, train=True, retraw=True)
+    gc = [torch.empty_like(p) for p in coarse.kernel_tensors()]
+    gf = [torch.empty_like(p) for p in fine.kernel_tensors()]
+    ops.render_backward(st, gin, gc, gf)
+    torch.cuda.synchronize()
+    # the blob the C program reads
+    blob = [np.array([D, W, 10, 4, 1, 5, 4, B, Nc, Nf, 1, 11], np.int32).tobytes()]
+    for m in (coarse, fine):
+        blob += [p.detach().cpu().numpy().astype(np.float32).tobytes() for p in m.kernel_tensors()]
+    blob += [rays.cpu().numpy().tobytes(), ops._t_vals(Nc, dev).cpu().numpy().tobytes(), t_rand.cpu().numpy().tobytes(),
+             u.cpu().numpy().tobytes()] + [gin[k].cpu().numpy().tobytes() for k in keys]
+    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+    fin.write_bytes(b"".join(blob))
+    r = subprocess.run([exe, str(fin), str(fout)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "render_smoke ok" in r.stdout, r.stdout + r.stderr
+    got = np.frombuffer(fout.read_bytes(), np.float32)
+    want = [out[k] for k in keys] + [out["z_std"], out["raw"]]
+    off = 0
+    for k, t in zip(keys + ["z_std", "raw"], want):
+        n = t.numel()
+        assert np.array_equal(got[off:off + n], t.cpu().numpy().reshape(-1), equal_nan=True), k
+        off += n
+    off += 2 * B * (Nc + Nf)            # z_vals and weights of the last level (not returned by ops.render_forward)
+    for gs in (gc, gf):
+        for i, t in enumerate(gs):
+            n = t.numel()
+            assert np.array_equal(got[off:off + n], t.cpu().numpy().reshape(-1)), f"grad tensor {i}"
+            off += n
+    assert off == got.size

@@ -212,3 +212,22 @@ def test_bench_roofline_constants_match_the_architecture():
     assert t is not None and 15e9 < t < 25e9            # ~16.2 GB algorithmic reads + 1.5 GB of partials
     assert bench.pmc_traffic("mlp_fwd_train", 786432) > 8e9   # the 8.2 GB stash
     assert bench.pmc_traffic("nonexistent", 1) is None
+
+
+def test_header_is_plain_c_and_the_c_example_links(tmp_path):
+    """include/cnerf.h compiles as C99 with gcc (no C++, no torch types in any signature) and the plain-C user of the
+    ABI (tests/c_abi/render_smoke.c; the GPU suite runs it) links against libcnerf_hip.so."""
+    from consistentnerf_amd import _lib
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    src = os.path.join(ROOT, "tests", "c_abi", "render_smoke.c")
+    cc = ["gcc", "-std=c99", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+          "-I" + os.path.join(ROOT, "include"), src, "-o", str(tmp_path / "render_smoke"), "-L/opt/rocm/lib", "-lamdhip64",
+          "-L" + libdir, "-l:" + os.path.basename(_lib.LIB_PATH), "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath," + libdir]
+    r = subprocess.run(cc, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    hdr_only = tmp_path / "h.c"
+    hdr_only.write_text('#include "cnerf.h"\nint main(void) { return sizeof(cnerf_render_cfg) == 24 ? 0 : 1; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                        str(hdr_only), "-o", str(tmp_path / "h")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert subprocess.run([str(tmp_path / "h")]).returncode == 0
