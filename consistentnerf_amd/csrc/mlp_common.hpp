@@ -107,8 +107,10 @@ __device__ __forceinline__ void a_load(f32x4 (&a)[NTO], const APanel& P, int pof
 
 // Both A register sets of a panel: a0 <- group 0, a1 <- group 1.  Two sets are refilled IN PLACE by the GEMMs below:
 // set a0 holds the even K-groups, a1 the odd ones; tile t of a set is reloaded with group kg+2 right behind its last
-// MFMA of group kg (row j = 3), i.e. 5*NTO-1 MFMAs (~2600 cycles at NTO = 8) before its next use.  Groups past the
-// panel's last one are clamped (re-read): branch-free, so the compiler's vmcnt bookkeeping stays exact.
+// MFMA of group kg (row j = 3), i.e. 5*NTO-1 MFMAs (~2600 cycles at NTO = 8) before its next use.  The register-operand
+// GEMMs are fully unrolled, so the refills past the panel's last group are simply not emitted (9 % of the weight
+// stream from L2 otherwise); the LDS-operand GEMM's loop clamps them instead (re-read): branch-free, so the compiler's
+// vmcnt bookkeeping stays exact.
 template <int NTO>
 __device__ __forceinline__ void a_prefetch(f32x4 (&a0)[NTO], f32x4 (&a1)[NTO], const APanel& P, int poff, int NP,
                                            int last) {
@@ -154,7 +156,7 @@ __device__ __forceinline__ void gemm_reg(f32x16 (&Q)[NTO], const f32x16 (&X)[NTI
         if (INIT && kg == 0 && j == 0) Q[t] = mfma_z(a[t][j], b);
         else Q[t] = mfma(a[t][j], b, Q[t]);
         side(kg, j, t);
-        if (j == 3) a[t] = buf_load(P.rs, P.lane, sn + t * 1024);
+        if (j == 3 && kg + 2 <= last) a[t] = buf_load(P.rs, P.lane, sn + t * 1024);   // (kg is a compile-time constant here)
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -183,7 +185,7 @@ __device__ __forceinline__ void gemm_reg3(f32x16 (&Q)[NTO], const f32x16 (&X)[NT
         if (INIT && kg == 0 && j == 0) Q[t] = mfma_z(a[t][j], b);
         else Q[t] = mfma(a[t][j], b, Q[t]);
         side(kg, j, t);
-        if (j == 3) a[t] = buf_load(P.rs, P.lane, sn + t * 1024);
+        if (j == 3 && kg + 3 <= last) a[t] = buf_load(P.rs, P.lane, sn + t * 1024);   // no refill past the last group
         __builtin_amdgcn_sched_barrier(0);
       }
     }
