@@ -30,7 +30,7 @@ extern "C" {
 
 /* Architecture of one NeRF MLP (H:67-130; created by create_nerf R:181-204).
  * Compiled envelope: W in {64,128,256}; 1 <= D <= 16 and D != skip+1; 3+6*multires <= 64;
- * 3+6*multires_views <= 32; use_viewdirs in {0,1}; output_ch in 1..8 (used only without viewdirs). */
+ * 3+6*multires_views <= 32; use_viewdirs in {0,1}; output_ch in 4..8 (used only without viewdirs: rgb, sigma, spare channels). */
 typedef struct cnerf_net {
   int32_t D;               /* trunk depth  (netdepth)                                        */
   int32_t W;               /* trunk width  (netwidth)                                        */

@@ -248,7 +248,12 @@ def test_mlp_golden(dev, tag, D, W, vd, och):
     check_param_grads(model, g, "grad.", "gs.", rtol=2e-1, l2tol=1e-1)
 
 
-@pytest.mark.parametrize("tag,D,W,vd,och", MLP_CASES)
+# (the envelope's far corners too: their capture-style gradient check is loose by construction, this one is not)
+EXACT_CASES = MLP_CASES + [("D16W128_novd_och8", 16, 128, False, 8), ("D1W256_vd", 1, 256, True, 4),
+                           ("D9W256_novd_och4", 9, 256, False, 4), ("D2W64_vd", 2, 64, True, 4)]
+
+
+@pytest.mark.parametrize("tag,D,W,vd,och", EXACT_CASES)
 @pytest.mark.parametrize("M_rays,S", [(24, 16), (37, 13)])
 def test_mlp_backward_exact_from_stash(dev, tag, D, W, vd, och, M_rays, S):
     """Tight check of dgrad + wgrad + split reduction + stash layout: the backward is replayed in fp64 from the
@@ -723,7 +728,9 @@ def test_nerf_module_forward_on_embedded_inputs(dev, D, W, vd, och):
 
 
 @pytest.mark.parametrize("D,W,vd,och,multires,i_embed", [(2, 64, True, 4, 10, 0), (6, 64, False, 4, 10, 0),
-                                                          (8, 256, True, 5, 0, -1), (3, 128, True, 4, 4, 0)])
+                                                          (8, 256, True, 5, 0, -1), (3, 128, True, 4, 4, 0),
+                                                          (1, 256, True, 4, 10, 0), (16, 128, False, 8, 10, 0),
+                                                          (9, 256, False, 4, 7, 0), (4, 64, True, 4, 1, 0)])
 def test_envelope_corners_vs_oracle(dev, D, W, vd, och, multires, i_embed):
     """W=64 (one view-branch tile: wave 1 idles there), D=2, D=6 (skip right before the last layer), identity
     embedding (i_embed=-1: 3 input channels padded to 32) — forward + gradients against the CPU oracle."""
@@ -757,7 +764,11 @@ def test_envelope_corners_vs_oracle(dev, D, W, vd, och, multires, i_embed):
     (raw * G.to(dev)).sum().backward()
     (ref * G).sum().backward()
     gref = {"g." + k: (p.grad if p.grad is not None else torch.zeros_like(p)).numpy() for k, p in sd.items()}
-    check_param_grads(model, gref, "g.", "g.", rtol=5e-2, l2tol=5e-3)
+    # one ReLU mask that differs from the CPU's (pre-activation within round-off of 0) moves every upstream gradient by
+    # ~1/M of its scale, M = 209 points here: a 16-layer net collects a few of them (the tight check of these corners is
+    # test_mlp_backward_exact_from_stash, which replays the backward from the kernel's own masks)
+    deep = D >= 12
+    check_param_grads(model, gref, "g.", "g.", rtol=1e-1 if deep else 5e-2, l2tol=3e-2 if deep else 5e-3)
 
 
 # ------------------------------------------------------------------------------------------------
