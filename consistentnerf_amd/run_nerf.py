@@ -338,6 +338,20 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
     """R:311-421 (V:441-551 when _with_depth).  Returns the same dict (+ the sample depths when _debug)."""
     rays = ray_batch if ray_batch.is_contiguous() else ray_batch.contiguous()
     N_rays, dev = rays.shape[0], rays.device
+    if N_rays == 0:   # nothing to launch (the reference's batchify_rays raises on an empty batch; here: empty maps)
+        S = N_samples + N_importance
+        last = network_fn if (network_fine is None or N_importance <= 0) else network_fine
+        e = lambda *sh: torch.empty(*sh, device=dev)  # noqa: E731
+        ret = {'rgb_map': e(0, 3), 'disp_map': e(0), 'acc_map': e(0)}
+        if _with_depth:
+            ret['depth_map'] = e(0)
+        if retraw:
+            ret['raw'] = e(0, S, last.spec().raw_ch)
+        if N_importance > 0:
+            ret.update({'rgb0': e(0, 3), 'disp0': e(0), 'acc0': e(0), 'z_std': e(0)})
+            if _with_depth:
+                ret['depth0'] = e(0)
+        return ret
     viewdirs = rays[:, -3:] if rays.shape[-1] > 8 else None
     t_rand = None
     if perturb > 0.:

@@ -1080,3 +1080,22 @@ def test_plain_c_program_uses_the_abi(dev, tmp_path):
             assert np.array_equal(got[off:off + n], t.cpu().numpy().reshape(-1)), f"grad tensor {i}"
             off += n
     assert off == got.size
+
+
+def test_rays_are_independent_and_tiny_batches_work(dev):
+    """Size-independent property: a ray's outputs do not depend on what else is in the batch, bit for bit (each output is
+    one fmaf chain in a fixed order wherever the point lands in a tile) — B = 1, 2, 33 against rows of B = 70; an empty
+    batch returns empty maps."""
+    from consistentnerf_amd import run_nerf as R
+    coarse, _ = make_model(8, 256, True, 5, 71, dev)
+    fine, _ = make_model(8, 256, True, 5, 72, dev)
+    kw = _kwargs(coarse, fine, 64, 128, 0.0, False, 0.0, False)
+    rays = T(I.ray_batch(70, seed=31), dev)
+    with torch.no_grad():
+        full = R.render_rays(rays, retraw=True, _with_depth=True, **kw)
+        for lo, n in ((0, 1), (5, 2), (17, 33), (69, 1)):
+            part = R.render_rays(rays[lo:lo + n].contiguous(), retraw=True, _with_depth=True, **kw)
+            for k in ("rgb_map", "depth_map", "acc_map", "rgb0", "depth0", "z_std", "raw"):
+                assert torch.equal(part[k], full[k][lo:lo + n]), (k, lo, n)
+        empty = R.render_rays(rays[:0].contiguous(), retraw=True, _with_depth=True, **kw)
+        assert empty["rgb_map"].shape == (0, 3) and empty["raw"].shape == (0, 192, 4) and empty["z_std"].shape == (0,)
