@@ -167,6 +167,10 @@ def main():
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if dist.is_initialized():   # build the RCCL communicator now (seconds), not inside the first step
+        t = torch.zeros(1, device=dev)
+        dist.all_reduce(t)
+        torch.cuda.synchronize()
     ok, name, cus, _ = ops.device_info(local)
 
     import tempfile
