@@ -392,9 +392,10 @@ int cn_wgrad_nsplit(int64_t Mp) {
   int64_t s = Mp / 4096;
   if (s < 1) s = 1;
   if (s > 128) s = 128;
+  if (s * 65536 < Mp) s = (Mp + 65535) / 65536;   // <= 65536 points per range: a range's rows stay within 32-bit byte offsets
   if (const char* e = getenv("CNERF_WGRAD_NSPLIT")) {   // tuning knob (scripts/kbench.py); both callers see the same value
     const int v = atoi(e);
-    if (v >= 1 && v <= 256) s = v;
+    if (v >= 1 && v <= 256 && (int64_t)v * 65536 >= Mp) s = v;
   }
   return (int)s;
 }
@@ -461,6 +462,8 @@ int cn_wgrad_launch(const NetGeom& g, const float* stash, const float* G, int64_
   a.stash = stash; a.G = G; a.partials = partials; a.Mp = Mp; a.pstride = pstride;
   a.s_rows = g.s_rows; a.g_rows = g.g_rows;
   a.chunk = cn_round_up(cn_div_up(Mp, nsplit), TM);
+  // a split's operand rows sit behind one buffer resource each: 32-bit byte offsets
+  if (a.chunk * (int64_t)(g.s_rows > g.g_rows ? g.s_rows : g.g_rows) * 4 >= (int64_t)0x7fffffff) return CNERF_E_UNSUPPORTED;
   const size_t lds_bytes = LDS_BYTES;
   static bool attr_set = false;
   if (!attr_set) {

@@ -1099,3 +1099,33 @@ def test_rays_are_independent_and_tiny_batches_work(dev):
                 assert torch.equal(part[k], full[k][lo:lo + n]), (k, lo, n)
         empty = R.render_rays(rays[:0].contiguous(), retraw=True, _with_depth=True, **kw)
         assert empty["rgb_map"].shape == (0, 3) and empty["raw"].shape == (0, 192, 4) and empty["z_std"].shape == (0,)
+
+
+def test_wgrad_beyond_128_point_ranges(dev):
+    """9.2 M points in ONE backward call (more than 128 x 65 536: the point ranges per GEMM grow past 128 so that a range's
+    rows stay within 32-bit byte offsets): its weight gradients equal the sum of the gradients of the two half batches
+    (each on the usual 128-range path) to fp32 summation accuracy."""
+    from consistentnerf_amd import ops
+    from consistentnerf_amd.run_nerf import _packed
+    model, _ = make_model(4, 128, True, 4, 81, dev)
+    spec, packed = model.spec(), _packed(model)
+    B, S = 36000, 256
+    g = torch.Generator(device=dev).manual_seed(5)
+    pts = (torch.rand(B * S, 3, device=dev, generator=g) * 4 - 2)
+    dirs = torch.nn.functional.normalize(torch.randn(B, 3, device=dev, generator=g), dim=-1)
+    G = torch.randn(B * S, 4, device=dev, generator=g) * 1e-3
+
+    def grads(lo, hi):
+        raw, stash = ops.mlp_forward(spec, packed, hi - lo, S, pts=pts[lo * S:hi * S], dirs=dirs[lo:hi], want_stash=True)
+        out = ops.mlp_backward(spec, packed, G[lo * S:hi * S].contiguous(), hi - lo, S, stash)
+        del stash
+        return out
+    whole = grads(0, B)
+    a, b = grads(0, B // 2), grads(B // 2, B)
+    for i, (w, x, y) in enumerate(zip(whole, a, b)):
+        ref = x.double() + y.double()
+        scale = float(ref.abs().max())
+        if scale == 0.0:
+            assert not w.any()
+            continue
+        assert float((w.double() - ref).abs().max()) <= 2e-5 * scale, f"tensor {i}"
