@@ -132,6 +132,10 @@ def run_network(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk=1024 * 64
     B, S = inputs.shape[0], inputs.shape[1]
     dirs = viewdirs.contiguous() if (viewdirs is not None and spec.use_viewdirs) else None
     params = fn.kernel_tensors()
+    if not torch.is_grad_enabled():
+        # under torch.no_grad() a Function still sees needs_input_grad = True for the parameters: detach them, or the
+        # inference pass would run the training kernel and write a 10 KB-per-point stash nobody reads
+        params = [p.detach() for p in params]
     if isinstance(inputs, RayPoints):
         return _MlpFn.apply(fn, B, S, None, inputs.rays, inputs.z_vals, dirs, None, *params)
     pts = inputs.reshape(-1, 3).contiguous()

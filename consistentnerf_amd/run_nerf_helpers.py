@@ -121,7 +121,10 @@ class NeRF(nn.Module):
         lead = x.shape[:-1]
         width = self.input_ch + (self.input_ch_views if self.use_viewdirs else 0)
         x2 = x.reshape(-1, x.shape[-1])[:, :width].contiguous()
-        out = _MlpFn.apply(self, x2.shape[0], 1, None, None, None, None, x2, *self.kernel_tensors())
+        params = self.kernel_tensors()
+        if not torch.is_grad_enabled():     # (see run_network: no stash for inference)
+            params = [p.detach() for p in params]
+        out = _MlpFn.apply(self, x2.shape[0], 1, None, None, None, None, x2, *params)
         return out.reshape(*lead, out.shape[-1])
 
     def load_weights_from_keras(self, weights):

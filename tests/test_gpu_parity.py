@@ -1129,3 +1129,27 @@ def test_wgrad_beyond_128_point_ranges(dev):
             assert not w.any()
             continue
         assert float((w.double() - ref).abs().max()) <= 2e-5 * scale, f"tensor {i}"
+
+
+def test_inference_runs_the_inference_kernel(dev):
+    """Under torch.no_grad() (render_path, evaluation) the forward must be the stash-free kernel: a Function sees
+    needs_input_grad = True for parameters even when grad mode is off, which once made every inference pass write a
+    10 KB-per-point training stash.  With grad mode on (training) the stash variant runs."""
+    from consistentnerf_amd import ops, run_nerf as R
+    coarse, _ = make_model(4, 128, True, 5, 91, dev)
+    fine, _ = make_model(4, 128, True, 5, 92, dev)
+    kw = _kwargs(coarse, fine, 16, 16, 0.0, False, 0.0, False)
+    rays = T(I.ray_batch(40, seed=2), dev)
+    try:
+        ops.PROFILE = []
+        with torch.no_grad():
+            a = R.render_rays(rays, **kw)
+            xe = torch.cat([O.embed(T(I.ray_batch(8, seed=1)[:, :3]), 10), O.embed(T(I.ray_batch(8, seed=1)[:, 3:6]), 4)], -1)
+            coarse(xe.to(dev))
+        assert {n for n, *_ in ops.PROFILE} == {"mlp_fwd"}
+        ops.PROFILE = []
+        b = R.render_rays(rays, **kw)
+        assert {n for n, *_ in ops.PROFILE} == {"mlp_fwd_train"}
+    finally:
+        ops.PROFILE = None
+    assert torch.equal(a["rgb_map"], b["rgb_map"].detach())
