@@ -465,11 +465,16 @@ int cn_wgrad_launch(const NetGeom& g, const float* stash, const float* G, int64_
   // a split's operand rows sit behind one buffer resource each: 32-bit byte offsets
   if (a.chunk * (int64_t)(g.s_rows > g.g_rows ? g.s_rows : g.g_rows) * 4 >= (int64_t)0x7fffffff) return CNERF_E_UNSUPPORTED;
   const size_t lds_bytes = LDS_BYTES;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)lds_bytes);
-    attr_set = true;
+  // the 160 KiB dynamic-LDS opt-in is a per-device function attribute: set it once per device this process launches on
+  // (idempotent, so a race between two host threads only repeats the call)
+  static bool attr_set[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return CNERF_E_NODEVICE;
+  if (!attr_set[dev]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds_bytes) != hipSuccess)
+      return (int)hipGetLastError();
+    attr_set[dev] = true;
   }
   hipLaunchKernelGGL(wgrad_k, dim3(nsplit, nj), dim3(64 * NWAVES), lds_bytes, st, a);
   CN_CHECK_LAUNCH();
