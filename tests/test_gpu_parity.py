@@ -1203,3 +1203,30 @@ def test_autograd_usage_patterns(dev):
     torch.cuda.current_stream().wait_stream(s)
     with torch.no_grad():
         assert torch.equal(side, R.render_rays(r2, **kw)["rgb_map"])
+
+
+def test_static_camera_and_render_factor(dev):
+    """render(c2w=..., c2w_staticcam=...) (R:104-108): geometry from the static camera, view directions from the moving one;
+    render_path(render_factor=f) (R:145-149) renders H//f x W//f with focal/f and the caller's K (as the reference does)."""
+    from consistentnerf_amd import run_nerf as R
+    from consistentnerf_amd.run_nerf_helpers import get_rays
+    g = golden("render_full_tiny")
+    K = g["K"]
+    c2w, cam = T(g["c2w"], dev), T(I.camera_pose(30.0, -10.0, 4.0)[:3, :4], dev)
+    batch, sh = R._ray_batch(16, 16, K, None, c2w, False, 2.0, 6.0, True, cam, dev)
+    ro, rd = get_rays(16, 16, K, cam)
+    _, rd_mov = get_rays(16, 16, K, c2w)
+    assert sh == (16, 16)
+    check(batch[:, 0:3], ro.reshape(-1, 3).cpu().numpy(), 0.0, "static origin")
+    check(batch[:, 3:6], rd.reshape(-1, 3).cpu().numpy(), 1e-6, "static direction")
+    vd = rd_mov.reshape(-1, 3) / rd_mov.reshape(-1, 3).norm(dim=-1, keepdim=True)
+    check(batch[:, 8:11], vd.cpu().numpy(), 1e-6, "moving view direction")
+    coarse, _ = make_model(4, 128, True, 5, 31, dev)
+    kw = _kwargs(coarse, None, 16, 0, 0.0, False, 0.0, False)
+    kw.update(near=2.0, far=6.0, ndc=False, use_viewdirs=True)
+    pose4 = torch.cat([c2w[:3, :4], torch.tensor([[0., 0., 0., 1.]], device=dev)], 0)
+    rgbs, disps = R.render_path([pose4], (32, 32, float(K[0][0]) * 2), K, 4096, kw, render_factor=2)
+    assert rgbs.shape == (1, 16, 16, 3) and disps.shape == (1, 16, 16)
+    with torch.no_grad():
+        direct = R.render(16, 16, K, chunk=4096, c2w=c2w[:3, :4], **kw)[0]
+    assert np.array_equal(rgbs[0], direct.cpu().numpy())
