@@ -125,7 +125,7 @@ def cpu_baseline(seconds_budget=25.0):
 
 def pmc_traffic(kernel, points):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
-    each in their own `--pmc` run, scripts/gpu_pmc.sh -> profiles/r01_pmc_v6/): KB units, FETCH_SIZE doubled per the
+    each in their own `--pmc` run, scripts/gpu_pmc.sh -> profiles/r01_pmc_final/): KB units, FETCH_SIZE doubled per the
     gfx950 correction of MI355X_MICROARCH.md (16-byte-per-lane streaming reads are tallied at half).  None when no
     pass of that kernel at that launch size is on file (counters cannot be sampled from inside this process)."""
     import csv
@@ -133,7 +133,7 @@ def pmc_traffic(kernel, points):
     name = {"mlp_wgrad": "wgrad", "mlp_dgrad": "mlp_dgrad", "mlp_fwd_train": "mlp_fwd_train", "mlp_fwd": "mlp_fwd_inf"}.get(kernel)
     val = {}
     for f, ctr in (("pass2_summary.csv", "FETCH_SIZE"), ("pass3_summary.csv", "WRITE_SIZE")):
-        path = os.path.join(here, "profiles", "r01_pmc_v6", f)
+        path = os.path.join(here, "profiles", "r01_pmc_final", f)
         if not os.path.exists(path):
             return None
         rows = [r for r in csv.DictReader(open(path)) if r["kernel"] == name and r["counter"] == ctr]
