@@ -58,6 +58,11 @@ class _MlpFn(torch.autograd.Function):
     def forward(ctx, model, B, S, pts, rays, z, dirs, emb, *params):
         spec = model.spec()
         packed = _packed(model)
+        if any(ctx.needs_input_grad[3:8]):
+            # fail loudly rather than return silently-missing gradients: the reference never differentiates through the
+            # sample positions (z is detached at R:397, rays come from the data), and the dgrad kernel stops at layer 0
+            raise ops.CnerfError("gradients w.r.t. sample positions / rays / view directions / pre-embedded inputs are "
+                                 "not implemented (only w.r.t. the network parameters)")
         train = any(ctx.needs_input_grad[8:])
         if emb is not None:      # NeRF.forward(x) on pre-embedded inputs
             raw, stash = ops.mlp_forward_embedded(spec, packed, emb, want_stash=train)

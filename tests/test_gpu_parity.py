@@ -1230,3 +1230,14 @@ def test_static_camera_and_render_factor(dev):
     with torch.no_grad():
         direct = R.render(16, 16, K, chunk=4096, c2w=c2w[:3, :4], **kw)[0]
     assert np.array_equal(rgbs[0], direct.cpu().numpy())
+
+
+def test_input_gradients_fail_loudly(dev):
+    """Only parameter gradients exist (as in the reference's training loops): asking for a gradient w.r.t. the inputs must
+    raise, not return None silently."""
+    from consistentnerf_amd import ops
+    model, _ = make_model(4, 128, True, 5, 95, dev)
+    x = torch.rand(16, 90, device=dev, requires_grad=True)
+    with pytest.raises(ops.CnerfError):
+        model(x)
+    assert model(x.detach()).shape == (16, 4)
