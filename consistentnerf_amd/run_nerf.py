@@ -94,6 +94,8 @@ class _CompositeFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, raw, z_vals, rays, noise, white_bkgd):
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:   # (z is detached in the reference, R:397; rays are data)
+            raise ops.CnerfError("raw2outputs: gradients w.r.t. z_vals / rays are not implemented (only w.r.t. raw)")
         rgb, disp, acc, weights, depth = ops.composite_forward(raw, z_vals, rays, noise, white_bkgd)
         ctx.save_for_backward(raw, z_vals, rays)
         ctx.noise, ctx.white = noise, white_bkgd
