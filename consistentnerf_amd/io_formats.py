@@ -169,7 +169,7 @@ def llff_poses(poses_arr, image_hw, factor=8, recenter=True, bd_factor=.75, n_re
     [N, 17] and the size of the (down-scaled) images: -> (poses [N, 3, 5] float32 with hwf in the last column,
     bds [N, 2], render_poses [n_render, 3, 4] float32 — the spiral `render_path` is fed (C5) —, i_test = the view
     closest to the average camera)."""
-    poses_arr = np.asarray(poses_arr)
+    poses_arr = np.array(poses_arr, copy=True)      # the in-place hwf edits below must not reach the caller's array
     poses = poses_arr[:, :-2].reshape([-1, 3, 5]).transpose([1, 2, 0])
     bds = poses_arr[:, -2:].transpose([1, 0])
     poses[:2, 4, :] = np.array(image_hw[:2]).reshape([2, 1])

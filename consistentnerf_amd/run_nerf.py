@@ -51,6 +51,18 @@ def _packed(model):
     return cache[1]
 
 
+def _engine_accumulates(p):
+    """True when the running backward pass will ACCUMULATE into p.grad (loss.backward(), also with inputs=[...]); False
+    under torch.autograd.grad(), where the engine captures the gradient of a leaf instead (it refuses the query for a
+    leaf's AccumulateGrad node in that mode — that refusal is the signal)."""
+    with torch.enable_grad():
+        acc = p.view_as(p).grad_fn.next_functions[0][0]
+    try:
+        return bool(torch._C._will_engine_execute_node(acc))
+    except RuntimeError:
+        return False
+
+
 class _MlpFn(torch.autograd.Function):
     """Fused gamma(x), gamma(d) + MLP (replaces R:37-52 + H:44-45 + H:107-130 and their autograd)."""
 
@@ -77,11 +89,14 @@ class _MlpFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_raw):
         params = ctx.params
-        # Parameters owned by FusedAdam carry their .grad as a view into the flat gradient buffer: the wgrad reduction
-        # accumulates straight into it (what AccumulateGrad would do with ~50 add/copy launches per step) and autograd
-        # gets no per-tensor gradients back.  Anything else (plain nn.Parameters, autograd.grad) takes the tensor route.
+        # Parameters owned by FusedAdam carry their .grad as a view into the flat gradient buffer: under loss.backward()
+        # the wgrad reduction accumulates straight into it (what AccumulateGrad would do with ~50 add/copy launches per
+        # step) and autograd gets no per-tensor gradients back.  Anything else — plain nn.Parameters, and
+        # torch.autograd.grad() on FusedAdam-owned ones, where the engine captures gradients instead of accumulating them
+        # — takes the tensor route and leaves the flat buffer untouched.
         direct = all(ctx.needs_input_grad[8:]) and all(
-            getattr(p, "_cnerf_direct_grad", False) and p.grad is not None and p.grad.is_contiguous() for p in params)
+            getattr(p, "_cnerf_direct_grad", False) and p.grad is not None and p.grad.is_contiguous() for p in params) \
+            and _engine_accumulates(params[0])
         out = [p.grad for p in params] if direct else None
         grads = ops.mlp_backward(ctx.spec, ctx.packed, g_raw.contiguous(), ctx.B, ctx.S, ctx.stash, grads=out,
                                  accumulate=direct)
@@ -178,10 +193,9 @@ def batchify_rays(rays_flat, chunk=1024 * 32, **kwargs):
 def _ray_batch(H, W, K, rays, c2w, ndc, near, far, use_viewdirs, c2w_staticcam, device):
     """R:97-125 -> (rays [B, 8|11], output leading shape)."""
     coef = ndc_coefficients(H, W, K[0][0]) if ndc else (0., 0.)
-    if torch.is_tensor(near) or torch.is_tensor(far):
-        near_s, far_s = 0., 1.
-    else:
-        near_s, far_s = near, far
+    # per-ray tensor bounds are written after the pack (R:111 `near * ones` takes any mix of scalars and tensors)
+    near_s = 0. if torch.is_tensor(near) else near
+    far_s = 1. if torch.is_tensor(far) else far
     if c2w is not None:
         sh = (H, W)
         if c2w_staticcam is not None and use_viewdirs:

@@ -113,6 +113,13 @@ class NeRF(nn.Module):
             ts += [self.output_linear.weight, self.output_linear.bias]
         return ts
 
+    def invalidate_packed(self):
+        """Forget the kernel-layout copy of the weights.  The cache key (run_nerf._packed) sees optimizer steps,
+        load_state_dict() and every autograd-visible in-place edit, but NOT writes through `p.data` (manual EMA /
+        re-initialisation code: `p.data.mul_()`, `p.data.copy_()`), which bump no version counter — call this after such
+        an edit."""
+        self.__dict__.pop("_cnerf_packed", None)
+
     def forward(self, x):
         """H:107-130 on an already-embedded batch x[..., input_ch + input_ch_views] -> [..., 4 | output_ch]
         (differentiable w.r.t. the parameters).  The render path does not come through here: run_network feeds

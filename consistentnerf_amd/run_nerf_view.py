@@ -3,7 +3,9 @@
   render V:183-249 (4 maps + extras) | render_path V:252-294 (rgbs, disps, accs) | create_nerf V:297-389 |
   render_rays V:441-551 | raw2outputs V:392-438 | get_rays_ref V:553 | get_ref_rays V:576 |
   get_test_label V:630 | the hard-mask precompute of train() V:994-1046 (`compute_hard_masks`) |
-  the masked RGB / depth losses V:1645-1648, V:1737, V:1786-1788, V:1865 (`hardmask_losses`)
+  the masked RGB / depth losses V:1645-1648, V:1737, V:1786-1788, V:1865 (`hardmask_losses`) |
+  the in-loop consistency block of run_nerf_view_test.py: VT:905-938 (`ss_consistency`) and its consumers VT:941-969
+  (`ss_primary_losses`)
 
 The older in-loop variant of the warp (run_nerf_view_test.py VT:451-501: no axis flip, masked points) is
 available through `get_ref_rays(..., variant="VT")`.
@@ -231,3 +233,45 @@ def ss_consistency(rays_o, rays_d, depth_cas_s, pose_ref, K, image_ref, depth_re
     return dict(loss=loss, mask_bound=mask_bound, mask=mask, threshold=thr, batch_rays_ref=batch_rays_ref,
                 rgb_target_ref=rgb_target_ref, rays_depth_ref=rays_depth_ref, rgb_ref=rgb_ref,
                 depth_pred_ref=depth_pred_ref, extras_ref=extras_ref)
+
+
+
+def ss_primary_losses(rgb, depth_pred, extras, target_s, depth_cas_s, mask_bound, mask, with_depth_loss=False, coins=None):
+    """The primary render's loss terms under `args.ss_loss` (VT:941-969), consumers of `ss_consistency`'s masks: each term
+    is restricted to the rays `[mask_bound.squeeze()][mask.squeeze()]` (projected into the reference view AND passing the
+    occlusion test) when its `random.randint(0, 1)` coin is 1, and is the plain mean (rgb) / absent (depth) otherwise.
+    `coins` = the draws in the reference's call order — (rgb, depth, rgb0, depth0) with the depth loss, (rgb, rgb0) without
+    — or None to draw them here with `random.randint` like the reference.  The reference's fallback of the COARSE rgb
+    term to the FINE rgb when its coin is 0 (VT:959) is kept.  Depth terms are un-normalised MSEs (no /far), as in VT.
+    Returns (loss, img_loss, img_loss0); img_loss0 is None when the render has no coarse outputs.
+
+    The double boolean selection becomes one 0/1 ray weight (no host sync, no gathers) fed to the masked-loss kernel."""
+    import random
+    draw = (lambda: random.randint(0, 1)) if coins is None else iter(list(coins)).__next__
+    mb, mk = mask_bound.reshape(-1).bool(), mask.reshape(-1).bool()
+    if mk.numel() == 0:
+        sel = torch.zeros(mb.shape, device=rgb.device, dtype=torch.float32)
+    else:   # sel[i] = mask_bound[i] and mask[rank of i among the in-bounds rays]
+        pos = (torch.cumsum(mb.long(), 0) - 1).clamp_(min=0, max=mk.numel() - 1)
+        sel = (mb & mk[pos]).to(torch.float32)
+
+    def masked(c, d):      # (masked rgb mse, masked depth mse) of one level in one launch
+        return hardmask_losses(c, target_s, sel, 0.0, d, depth_cas_s if d is not None else None, 1.0)
+
+    c_rgb = draw()
+    c_dep = draw() if with_depth_loss else 0
+    lm = masked(rgb, depth_pred if c_dep else None) if (c_rgb or c_dep) else None
+    img_loss = lm[0] if c_rgb else img2mse(rgb, target_s)
+    loss = img_loss
+    if c_dep:
+        loss = loss + lm[1]
+    img_loss0 = None
+    if 'rgb0' in extras:
+        c_rgb0 = draw()
+        c_dep0 = draw() if with_depth_loss else 0
+        lm0 = masked(extras['rgb0'], extras['depth0'] if c_dep0 else None) if (c_rgb0 or c_dep0) else None
+        img_loss0 = lm0[0] if c_rgb0 else img2mse(rgb, target_s)
+        loss = loss + img_loss0
+        if c_dep0:
+            loss = loss + lm0[1]
+    return loss, img_loss, img_loss0

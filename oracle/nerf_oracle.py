@@ -406,6 +406,28 @@ def masked_depth_loss(depth: Tensor, prior: Tensor, m: Tensor, far: float) -> Te
     return mse(depth[m == 1] / far, prior[m == 1] / far)
 
 
+def ss_primary_losses(rgb: Tensor, depth_pred: Tensor, rgb0: Optional[Tensor], depth0: Optional[Tensor], target_s: Tensor,
+                      depth_cas_s: Tensor, mask_bound: Tensor, mask: Tensor, with_depth_loss: bool, coins):
+    """VT:941-969 (the `args.ss_loss` consumers of a15's masks): each primary-render term is restricted to
+    `[mask_bound][mask]` when its coin is 1.  coins = the `random.randint(0, 1)` draws in call order: (rgb, depth, rgb0,
+    depth0) with the depth loss, (rgb, rgb0) without.  The coarse rgb term falls back to the FINE rgb when its coin is 0
+    (VT:959, kept).  Returns (loss, img_loss, img_loss0)."""
+    coins = list(coins)
+    mb, mk = mask_bound.reshape(-1), mask.reshape(-1)
+    pick = lambda x: x[mb][mk]  # noqa: E731
+    img_loss = mse(pick(rgb), pick(target_s)) if coins.pop(0) == 1 else mse(rgb, target_s)
+    loss = img_loss
+    if with_depth_loss:
+        loss = loss + (mse(pick(depth_pred), pick(depth_cas_s)) if coins.pop(0) == 1 else 0)
+    img_loss0 = None
+    if rgb0 is not None:
+        img_loss0 = mse(pick(rgb0), pick(target_s)) if coins.pop(0) == 1 else mse(rgb, target_s)
+        loss = loss + img_loss0
+        if with_depth_loss:
+            loss = loss + (mse(pick(depth0), pick(depth_cas_s)) if coins.pop(0) == 1 else 0)
+    return loss, img_loss, img_loss0
+
+
 # ----------------------------------------------------------------------------------------------
 # optimiser tail ("next" f-1)                                   R:210, R:780-788, V:1983
 # ----------------------------------------------------------------------------------------------

@@ -1,10 +1,25 @@
 #!/usr/bin/env python3
-"""PSNR-parity run (BASELINE metric, second half): train the HIP path and the CPU oracle from the SAME initial
-weights on the SAME ray batches of a synthetic DTU-like 3-view scene (analytic sphere-over-floor colours), with the
-reference's deterministic RNG hook (pytest=True: identical jitter / resampling streams on both sides), then render
-a held-out view with both and compare PSNR (definition H:10 / V:2047: -10 log10 of the mean MSE) and loss curves.
-Reduced size so the CPU side finishes in minutes: 64x80 images, 512-ray batches, coarse 64 + fine 64+128,
-D=8/W=256, viewdirs.   usage: python scripts/psnr_parity.py [steps]"""
+"""PSNR-parity measurement (BASELINE metric, second half: "at PSNR parity with the reference").
+
+For each of S seeds (initial weights, ray-bank shuffle): train the HIP path and the CPU oracle from the SAME initial
+weights on the SAME ray batches of a synthetic DTU-like 3-view scene (analytic sphere-over-floor colours) with the
+reference's deterministic RNG hook (pytest=True: identical jitter / resampling streams on both sides), render a held-out
+view with both, and compare PSNR (definition H:10 / V:2047-2048: -10 log10 of the mean MSE over the held-out image).
+
+Two fp32 Adam trajectories of a chaotic system decorrelate at the rate round-off is amplified, so "the gap" needs a noise
+estimate: the CONTROL is the oracle against ITSELF with every initial weight moved by one ulp (random direction).  Whatever
+held-out-PSNR spread that produces is the spread any bit-different-but-correct implementation shows; parity = the
+HIP-vs-oracle gap is inside it.
+
+Two sides, because the CPU side needs no GPU (and the GPU box's minutes are budgeted):
+
+  python scripts/psnr_parity.py oracle --seeds 0 1 2 3 4 --steps 600 --workers 5 --out profiles/r02_psnr_oracle.npz
+        CPU only (runs anywhere the oracle imports): per seed the oracle run and its 1-ulp control.
+  python scripts/psnr_parity.py hip --oracle profiles/r02_psnr_oracle.npz --out profiles/r02_psnr_parity_seeds.json
+        on the MI355X: the HIP runs on the same seeds / batches, then the merged statistics.
+
+Reduced size so the CPU side finishes: 64x80 images, 512-ray batches, coarse 64 + fine 64+128, D=8/W=256, viewdirs.
+"""
 import argparse
 import json
 import os
@@ -16,18 +31,17 @@ import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 import _inputs as I  # noqa: E402
-from consistentnerf_amd import run_nerf as R  # noqa: E402
-from oracle import nerf_oracle as O  # noqa: E402
 
-STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 H, W, FOCAL, NEAR, FAR, B = 64, 80, 180.0, 2.0, 6.0, 512
+LRATE, LRATE_DECAY = 5e-4, 250
 
 
-def main():
-    dev = torch.device("cuda:0")
-    torch.set_num_threads(min(32, os.cpu_count() or 1))
+def scene(seed):
+    """Ray bank [3*H*W, 11] + colours (shuffled with `seed`), held-out rays + colours, the two initial state dicts."""
+    from oracle import nerf_oracle as O
     K = I.intrinsics(H, W, FOCAL)
     train_poses = [I.camera_pose(th, -20.0, 4.0) for th in (0.0, 25.0, -25.0)]
     test_pose = I.camera_pose(12.0, -15.0, 4.0)
@@ -37,69 +51,183 @@ def main():
         rays.append(O.build_ray_batch(ro, rd, NEAR, FAR, True))
         cols.append(torch.from_numpy(I.analytic_scene(H, W, K, p)[1]).reshape(-1, 3))
     bank, target = torch.cat(rays), torch.cat(cols)
-    perm = torch.from_numpy(np.random.RandomState(0).permutation(bank.shape[0]))
-    bank, target = bank[perm], target[perm]
+    perm = torch.from_numpy(np.random.RandomState(seed).permutation(bank.shape[0]))
+    bank, target = bank[perm].contiguous(), target[perm].contiguous()
     ro, rd = O.get_rays(H, W, K, torch.from_numpy(test_pose))
     test_rays = O.build_ray_batch(ro, rd, NEAR, FAR, True)
     test_rgb = torch.from_numpy(I.analytic_scene(H, W, K, test_pose)[1]).reshape(-1, 3)
+    # small-gain init so the random net is well conditioned, like a real run
+    sds = [I.nerf_state_dict(8, 256, 10, 4, 5, True, seed=1000 + 2 * seed + k, gain=0.6) for k in (0, 1)]
+    return K, bank, target, test_rays, test_rgb, sds
 
-    # same initial weights on both sides (small-gain init so the random net is well conditioned, like a real run)
-    sds = [I.nerf_state_dict(8, 256, 10, 4, 5, True, seed=s, gain=0.6) for s in (1, 2)]
+
+def ulp_nudge(sds, seed):
+    """Every weight / bias moved to its fp32 neighbour, direction drawn per element."""
+    rs = np.random.RandomState(7000 + seed)
+    out = []
+    for sd in sds:
+        d = {}
+        for k, v in sd.items():
+            if k in ("temp_rgb", "temp_depth", "depth_scale"):
+                d[k] = v.copy()
+                continue
+            sign = np.where(rs.uniform(size=v.shape) < 0.5, -np.inf, np.inf).astype(np.float32)
+            d[k] = np.nextafter(v, sign).astype(np.float32)
+        out.append(d)
+    return out
+
+
+def batch_bounds(i, n):
+    lo = (i * B) % (n - B)
+    return lo, lo + B
+
+
+# ------------------------------------------------------------------------------------------------ CPU side
+def oracle_job(job):
+    seed, nudged, steps, threads = job
+    torch.set_num_threads(threads)
+    from oracle import nerf_oracle as O
+    K, bank, target, test_rays, test_rgb, sds = scene(seed)
+    if nudged:
+        sds = ulp_nudge(sds, seed)
+    osd = [O.as_tensors(sd, True) for sd in sds]
+    net, cfg = O.NetCfg(8, 256, output_ch=5), O.RenderCfg(64, 128, 1.0)
+    params = [p for d in osd for p in d.values()]
+    m = [torch.zeros_like(p) for p in params]
+    v = [torch.zeros_like(p) for p in params]
+    losses, lr, t0 = [], LRATE, time.perf_counter()
+    for i in range(steps):
+        lo, hi = batch_bounds(i, bank.shape[0])
+        out = O.render_rays_pytest(bank[lo:hi], osd[0], osd[1], net, cfg)
+        loss = O.mse(out["rgb_map"], target[lo:hi]) + O.mse(out["rgb0"], target[lo:hi])
+        grads = torch.autograd.grad(loss, params, allow_unused=True)
+        with torch.no_grad():
+            for p, g_, mm, vv in zip(params, grads, m, v):
+                if g_ is not None:
+                    O.adam_step(p, g_, mm, vv, i + 1, lr)
+        lr = O.lr_at(LRATE, i, LRATE_DECAY)
+        losses.append(loss.item())
+        if i % 100 == 0:
+            print(f"[oracle seed {seed}{' nudged' if nudged else ''}] step {i} loss {losses[-1]:.6f} "
+                  f"({time.perf_counter() - t0:.0f} s)", flush=True)
+    with torch.no_grad():
+        img = O.render_rays(test_rays, osd[0], osd[1], net, O.RenderCfg(64, 128, 0.0))["rgb_map"]
+    psnr = O.psnr_from_mse(O.mse(img, test_rgb)).item()
+    return seed, nudged, np.asarray(losses, np.float32), psnr, img.numpy().astype(np.float32), time.perf_counter() - t0
+
+
+def run_oracle(a):
+    import multiprocessing as mp
+    jobs = [(s, n, a.steps, a.threads) for s in a.seeds for n in (False, True)]
+    with mp.get_context("spawn").Pool(a.workers) as pool:
+        res = pool.map(oracle_job, jobs, chunksize=1)
+    out = {"seeds": np.asarray(a.seeds), "steps": np.asarray(a.steps)}
+    for seed, nudged, losses, psnr, img, secs in res:
+        tag = f"s{seed}_{'ctl' if nudged else 'ref'}"
+        out[tag + "_loss"], out[tag + "_psnr"], out[tag + "_img"], out[tag + "_secs"] = losses, np.float64(psnr), img, secs
+        print(f"{tag}: held-out {psnr:.3f} dB, final loss {losses[-1]:.6f}, {secs:.0f} s")
+    np.savez_compressed(a.out, **out)
+    print("wrote", a.out)
+
+
+# ------------------------------------------------------------------------------------------------ GPU side
+def hip_run(seed, steps):
+    from consistentnerf_amd import run_nerf as R
+    dev = torch.device("cuda:0")
+    K, bank, target, test_rays, test_rgb, sds = scene(seed)
     args = argparse.Namespace(
         multires=10, i_embed=0, use_viewdirs=True, multires_views=4, N_importance=128, netdepth=8, netwidth=256,
-        netdepth_fine=8, netwidth_fine=256, netchunk=1024 * 64, lrate=5e-4, basedir=tempfile.mkdtemp(), expname="p",
+        netdepth_fine=8, netwidth_fine=256, netchunk=1024 * 64, lrate=LRATE, basedir=tempfile.mkdtemp(), expname="p",
         ft_path=None, no_reload=True, perturb=1.0, N_samples=64, white_bkgd=False, raw_noise_std=0.0,
         dataset_type="dtu", no_ndc=True, lindisp=False)
     kw, kw_test, _, grad_vars, opt = R.create_nerf(args)
     kw["network_fn"].load_state_dict({k: torch.from_numpy(v) for k, v in sds[0].items()})
     kw["network_fine"].load_state_dict({k: torch.from_numpy(v) for k, v in sds[1].items()})
-    kw.update(near=NEAR, far=FAR); kw_test.update(near=NEAR, far=FAR)
-    osd = [O.as_tensors(sd, True) for sd in sds]
-    net, cfg = O.NetCfg(8, 256, output_ch=5), O.RenderCfg(64, 128, 1.0)
-    params = [p for d in osd for p in d.values()]
-    m = [torch.zeros_like(p) for p in params]; v = [torch.zeros_like(p) for p in params]
-
-    hl, ol, t_hip, t_cpu = [], [], 0.0, 0.0
-    lr = 5e-4
-    for i in range(STEPS):
-        lo = (i * B) % (bank.shape[0] - B)
-        rb, tg = bank[lo:lo + B], target[lo:lo + B]
-        # --- HIP path
-        t0 = time.perf_counter()
-        rgb, disp, acc, ex = R.render(H, W, K, chunk=32768, rays=torch.stack([rb[:, 0:3], rb[:, 3:6]]).to(dev),
-                                      retraw=True, pytest=True, **kw)
+    kw.update(near=NEAR, far=FAR)
+    kw_test.update(near=NEAR, far=FAR)
+    bank_d, target_d = bank.to(dev), target.to(dev)
+    losses = []
+    for i in range(steps):
+        lo, hi = batch_bounds(i, bank.shape[0])
+        rb, tg = bank_d[lo:hi], target_d[lo:hi]
+        rgb, disp, acc, ex = R.render(H, W, K, chunk=32768, rays=torch.stack([rb[:, 0:3], rb[:, 3:6]]), retraw=True,
+                                      pytest=True, **kw)
         opt.zero_grad()
-        loss = R.img2mse(rgb, tg.to(dev)) + R.img2mse(ex["rgb0"], tg.to(dev))
-        loss.backward(); opt.step()
-        for g_ in opt.param_groups:
-            g_["lr"] = 5e-4 * (0.1 ** (i / 250000))
-        hl.append(loss.item()); t_hip += time.perf_counter() - t0
-        # --- CPU oracle
-        t0 = time.perf_counter()
-        out = O.render_rays_pytest(rb, osd[0], osd[1], net, cfg)
-        lo_ = O.mse(out["rgb_map"], tg) + O.mse(out["rgb0"], tg)
-        grads = torch.autograd.grad(lo_, params, allow_unused=True)
-        with torch.no_grad():
-            for p, g_, mm, vv in zip(params, grads, m, v):
-                if g_ is not None:
-                    O.adam_step(p, g_, mm, vv, i + 1, lr)
-        lr = O.lr_at(5e-4, i, 250)
-        ol.append(lo_.item()); t_cpu += time.perf_counter() - t0
-        if i % 25 == 0 or i == STEPS - 1:
-            print(f"step {i:4d}  loss hip {hl[-1]:.6f}  oracle {ol[-1]:.6f}  |d| {abs(hl[-1]-ol[-1]):.2e}", flush=True)
+        loss = R.img2mse(rgb, tg) + R.img2mse(ex["rgb0"], tg)
+        loss.backward()
+        opt.step()
+        for g_ in opt.param_groups:                # R:784-788
+            g_["lr"] = LRATE * (0.1 ** (i / (LRATE_DECAY * 1000)))
+        losses.append(loss.detach())
     with torch.no_grad():
-        rgb_h, *_ = R.render(H, W, K, chunk=32768, rays=torch.stack([test_rays[:, 0:3], test_rays[:, 3:6]]).to(dev),
-                             **kw_test)
-        out = O.render_rays(test_rays, osd[0], osd[1], net, O.RenderCfg(64, 128, 0.0))
-    psnr_h = O.psnr_from_mse(O.mse(rgb_h.cpu(), test_rgb)).item()
-    psnr_o = O.psnr_from_mse(O.mse(out["rgb_map"], test_rgb)).item()
-    cross = O.psnr_from_mse(O.mse(rgb_h.cpu(), out["rgb_map"])).item()
-    res = {"steps": STEPS, "rays_per_step": B, "final_loss_hip": hl[-1], "final_loss_oracle": ol[-1],
-           "max_abs_loss_diff": float(np.max(np.abs(np.array(hl) - np.array(ol)))),
-           "heldout_psnr_hip_dB": psnr_h, "heldout_psnr_oracle_dB": psnr_o, "psnr_hip_vs_oracle_image_dB": cross,
-           "s_per_step_hip": t_hip / STEPS, "s_per_step_cpu_oracle": t_cpu / STEPS,
-           "loss_curve_hip": hl[::10], "loss_curve_oracle": ol[::10]}
-    print(json.dumps(res))
+        img, *_ = R.render(H, W, K, chunk=32768, rays=torch.stack([test_rays[:, 0:3], test_rays[:, 3:6]]).to(dev),
+                           **kw_test)
+    img = img.cpu()
+    mse = torch.mean((img - test_rgb) ** 2)
+    return torch.stack(losses).cpu().numpy(), (-10. * torch.log10(mse)).item(), img.numpy()
+
+
+def psnr_img(a, b):
+    return float(-10. * np.log10(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)))
+
+
+def run_hip(a):
+    ref = np.load(a.oracle)
+    seeds, steps = [int(s) for s in ref["seeds"]], int(ref["steps"])
+    rows = []
+    for s in seeds:
+        t0 = time.perf_counter()
+        hl, hp, himg = hip_run(s, steps)
+        ol, op, oimg = ref[f"s{s}_ref_loss"], float(ref[f"s{s}_ref_psnr"]), ref[f"s{s}_ref_img"]
+        cl, cp, cimg = ref[f"s{s}_ctl_loss"], float(ref[f"s{s}_ctl_psnr"]), ref[f"s{s}_ctl_img"]
+        first_div = lambda x, y, tol: int(np.argmax(np.abs(x - y) > tol * np.abs(y))) if np.any(np.abs(x - y) > tol * np.abs(y)) else steps  # noqa: E731
+        rows.append({
+            "seed": s, "heldout_psnr_hip_dB": hp, "heldout_psnr_oracle_dB": op, "heldout_psnr_oracle_1ulp_dB": cp,
+            "gap_hip_minus_oracle_dB": hp - op, "gap_control_minus_oracle_dB": cp - op,
+            "image_psnr_hip_vs_oracle_dB": psnr_img(himg, oimg), "image_psnr_control_vs_oracle_dB": psnr_img(cimg, oimg),
+            "final_loss_hip": float(hl[-1]), "final_loss_oracle": float(ol[-1]), "final_loss_control": float(cl[-1]),
+            "first_loss_rel_diff_hip": float(abs(hl[0] - ol[0]) / ol[0]),
+            "steps_until_loss_differs_1e-3_hip": first_div(hl, ol, 1e-3),
+            "steps_until_loss_differs_1e-3_control": first_div(cl, ol, 1e-3),
+            "mean_rel_loss_diff_hip": float(np.mean(np.abs(hl - ol) / ol)),
+            "mean_rel_loss_diff_control": float(np.mean(np.abs(cl - ol) / ol)),
+            "hip_seconds": time.perf_counter() - t0,
+        })
+        print(json.dumps(rows[-1]), flush=True)
+    gap = np.array([r["gap_hip_minus_oracle_dB"] for r in rows])
+    ctl = np.array([r["gap_control_minus_oracle_dB"] for r in rows])
+    n = len(rows)
+    sd = lambda x: float(np.std(x, ddof=1)) if n > 1 else None  # noqa: E731
+    summary = {
+        "definition": "held-out PSNR = -10 log10(mean((rgb - gt)^2)) over the 64x80 held-out view (H:10, V:2047-2048); "
+                      "gap = HIP - oracle; control = oracle started 1 ulp away - oracle; same seeds, batches and RNG hook",
+        "seeds": seeds, "steps": steps, "rays_per_step": B,
+        "gap_mean_dB": float(gap.mean()), "gap_std_dB": sd(gap), "gap_sem_dB": (sd(gap) / np.sqrt(n)) if n > 1 else None,
+        "control_mean_dB": float(ctl.mean()), "control_std_dB": sd(ctl), "control_rms_dB": float(np.sqrt(np.mean(ctl ** 2))),
+        "abs_gap_mean_dB": float(np.abs(gap).mean()), "abs_control_mean_dB": float(np.abs(ctl).mean()),
+        "parity": bool(abs(gap.mean()) <= np.sqrt(np.mean(ctl ** 2))),
+        "criterion": "|mean gap| <= rms of the control gap (the 1-sigma chaos spread about 0)",
+        "runs": rows,
+    }
+    with open(a.out, "w") as f:
+        json.dump(summary, f, indent=1)
+    print(json.dumps({k: v for k, v in summary.items() if k != "runs"}))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    sub = ap.add_subparsers(dest="side", required=True)
+    o = sub.add_parser("oracle")
+    o.add_argument("--seeds", type=int, nargs="+", default=[0, 1, 2, 3, 4])
+    o.add_argument("--steps", type=int, default=600)
+    o.add_argument("--workers", type=int, default=5)
+    o.add_argument("--threads", type=int, default=1, help="ATen threads per worker")
+    o.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_psnr_oracle.npz"))
+    h = sub.add_parser("hip")
+    h.add_argument("--oracle", default=os.path.join(ROOT, "profiles", "r02_psnr_oracle.npz"))
+    h.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_psnr_parity_seeds.json"))
+    a = ap.parse_args()
+    (run_oracle if a.side == "oracle" else run_hip)(a)
 
 
 if __name__ == "__main__":

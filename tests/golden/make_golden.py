@@ -713,7 +713,164 @@ def fx_ssloss():
     save("ssloss", **out)
 
 
-ALL = dict(ssloss=fx_ssloss, poses=fx_poses, patch=fx_patch, formats=fx_formats, raybank=fx_raybank, embed=fx_embed, mlp=fx_mlp, raw2outputs=fx_raw2outputs, sample_pdf=fx_sample_pdf,
+def sub_summary(sd, prefix):
+    """Compact pin of a parameter set: per-tensor fp64 sum / abs-sum and every 7th element."""
+    out = {}
+    for k, v in sd.items():
+        x = v.detach().double().reshape(-1)
+        out[f"{prefix}{k}.sum"], out[f"{prefix}{k}.abssum"] = x.sum().numpy(), x.abs().sum().numpy()
+        out[f"{prefix}{k}.sub"] = x[::7].float().numpy()
+    return out
+
+
+def fx_train_v():
+    """10 optimiser steps of the ConsistentNeRF loop (run_nerf_view.py train()): V.create_nerf, V.render on a coarse+fine
+    pair, the hard-mask rgb + depth losses on both levels (V:1645-1648, 1737, 1786-1788, 1865 — the reference's own
+    img2mse on its own boolean selections, use_batching branch), then the reference's OWN optimizer tail V:1982-1994
+    (loss.backward(); torch.nn.utils.clip_grad_value_(grad_vars, 0.1); optimizer.step(); lr decay), read from its source
+    at generation time and executed.  SSIM / LPIPS / MiDaS terms are out of scope and not in the loss.
+    The depth priors are deliberately unrelated to the rendered depth so that gradient elements DO exceed the 0.1 clip in
+    the first steps (counts recorded).  A second run with the clip line left out shows what the clip changes: the final
+    values of the parameters whose gradient was clipped at step 0 are stored for both runs."""
+    src = os.path.join(REF, "run_nerf_view.py")
+    bwd = _ref_lines(src, 1982, 1982, "loss.backward()")
+    tail = _ref_lines(src, 1983, 1994, "torch.nn.utils.clip_grad_value_(grad_vars, 0.1)")
+    tail_noclip = _ref_lines(src, 1985, 1994, "optimizer.step()")
+    near, far, N_rand = 2.0, 6.0, 256
+    Hh = Ww = 100
+    K = I.intrinsics(Hh, Ww, 138.0)
+    img2mse = V.img2mse
+
+    def run(with_clip):
+        with tempfile.TemporaryDirectory() as tmp:
+            os.makedirs(os.path.join(tmp, "exp"))
+            args = argparse.Namespace(
+                multires=10, i_embed=0, use_viewdirs=True, multires_views=4, N_importance=32, netdepth=4,
+                netwidth=128, netdepth_fine=4, netwidth_fine=128, netchunk=1024 * 64, lrate=5e-4, lrate_decay=250,
+                basedir=tmp, expname="exp", ft_path=None, no_reload=True, perturb=1.0, N_samples=32, stable_init=True,
+                white_bkgd=False, raw_noise_std=0.0, dataset_type="dtu", no_ndc=True, lindisp=False,
+                hardmask=True, softmask=False, hardmask_coef=0.2, with_depth_loss=True)
+            kw_train, kw_test, start, grad_vars, optimizer = V.create_nerf(args)
+        # V:321: the coarse net starts as a copy of the fine one
+        c0, f0 = kw_train["network_fn"].state_dict(), kw_train["network_fine"].state_dict()
+        assert all(torch.equal(c0[k], f0[k]) for k in c0)
+        sds = [I.nerf_state_dict(4, 128, 10, 4, 5, True, seed=s, gain=0.6) for s in (51, 52)]
+        kw_train["network_fn"].load_state_dict({k: T(v) for k, v in sds[0].items()})
+        kw_train["network_fine"].load_state_dict({k: T(v) for k, v in sds[1].items()})
+        kw_train.update(near=near, far=far)
+        log = {k: [] for k in ("loss", "img_loss", "depth_loss", "img_loss0", "depth_loss0", "n_clipped", "max_abs_grad")}
+        global_step, clipped_idx = start, None
+        for i in range(10):
+            rays = I.ray_batch(N_rand, seed=300 + i, near=near, far=far)
+            rs = np.random.RandomState(400 + i)
+            target_s = T(rs.uniform(size=(N_rand, 3)).astype(np.float32))
+            depth_cas_s = T(rs.uniform(near, far, size=(N_rand,)).astype(np.float32))
+            mask_cas_s = T((rs.uniform(size=(N_rand,)) < 0.6).astype(np.float32))
+            batch_rays = torch.stack([T(rays[:, 0:3]), T(rays[:, 3:6])], 0)
+            rgb, disp, acc, depth_pred, extras = V.render(Hh, Ww, K, chunk=32768, rays=batch_rays, verbose=False,
+                                                          retraw=True, pytest=True, **kw_train)
+            loss = 0
+            optimizer.zero_grad()
+            # V:1645-1648
+            img_loss = img2mse(rgb[mask_cas_s.squeeze() == 1], target_s[mask_cas_s.squeeze() == 1])
+            if mask_cas_s.squeeze().sum() != N_rand: img_loss += args.hardmask_coef * img2mse(rgb[mask_cas_s.squeeze() == 0], target_s[mask_cas_s.squeeze() == 0])  # noqa: E701
+            loss += img_loss
+            # V:1737
+            depth_loss = img2mse(depth_pred[mask_cas_s.squeeze() == 1]/far, depth_cas_s[mask_cas_s.squeeze() == 1]/far)
+            loss = loss + depth_loss
+            # V:1786-1788
+            img_loss0 = img2mse(extras['rgb0'][mask_cas_s.squeeze() == 1], target_s[mask_cas_s.squeeze() == 1])
+            if mask_cas_s.squeeze().sum() != N_rand: img_loss0 += args.hardmask_coef * img2mse(extras['rgb0'][mask_cas_s.squeeze() == 0], target_s[mask_cas_s.squeeze() == 0])  # noqa: E701
+            loss = loss + img_loss0
+            # V:1865
+            depth_loss0 = img2mse(extras['depth0'][mask_cas_s.squeeze() == 1]/far, depth_cas_s[mask_cas_s.squeeze() == 1]/far)
+            loss = loss + depth_loss0
+            ns = dict(torch=torch, loss=loss, grad_vars=grad_vars, optimizer=optimizer, args=args, global_step=global_step,
+                      time=types.SimpleNamespace(time=lambda: 0.0), time0=0.0)
+            exec(bwd, ns)
+            flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in grad_vars])
+            if i == 0:
+                clipped_idx = torch.nonzero(flat.abs() > 0.1).reshape(-1)
+            log["n_clipped"].append(int((flat.abs() > 0.1).sum()))
+            log["max_abs_grad"].append(float(flat.abs().max()))
+            exec(tail if with_clip else tail_noclip, ns)
+            if with_clip:
+                assert max(float(p.grad.abs().max()) for p in grad_vars if p.grad is not None) <= 0.1000001
+            global_step += 1
+            for k, v in (("loss", loss), ("img_loss", img_loss), ("depth_loss", depth_loss), ("img_loss0", img_loss0),
+                         ("depth_loss0", depth_loss0)):
+                log[k].append(v.item())
+        final_flat = torch.cat([p.detach().reshape(-1) for p in grad_vars])
+        st = optimizer.state
+        m_flat = torch.cat([(st[p]["exp_avg"] if p in st and "exp_avg" in st[p] else torch.zeros_like(p)).reshape(-1)
+                            for p in grad_vars])
+        v_flat = torch.cat([(st[p]["exp_avg_sq"] if p in st and "exp_avg_sq" in st[p] else torch.zeros_like(p)).reshape(-1)
+                            for p in grad_vars])
+        return log, kw_train, optimizer, clipped_idx, (final_flat, m_flat, v_flat)
+
+    log, kw_train, optimizer, idx, (final_flat, m_flat, v_flat) = run(True)
+    log_n, _, _, idx_n, (final_flat_n, m_flat_n, v_flat_n) = run(False)
+    assert torch.equal(idx, idx_n)
+    print("   clipped gradient elements per step:", log["n_clipped"], " max|g|:", [round(x, 3) for x in log["max_abs_grad"]])
+    assert log["n_clipped"][0] > 10, "fixture must exercise the clip"
+    delta = (final_flat[idx] - final_flat_n[idx]).abs()
+    print(f"   clip vs no clip, final values of the {idx.numel()} parameters clipped at step 0: "
+          f"median |d| {delta.median():.2e}, max {delta.max():.2e}")
+    dm = (m_flat[idx] - m_flat_n[idx]).abs() / m_flat[idx].abs().clamp_min(1e-12)
+    print(f"   Adam first moment at those parameters, clip vs no clip: median rel |d| {dm.median():.2f}")
+    dv = (v_flat[idx] - v_flat_n[idx]).abs() / v_flat[idx].abs().clamp_min(1e-20)
+    print(f"   Adam second moment: median rel |d| {dv.median():.2f}")
+    assert delta.median() > 1e-4 and dm.median() > 0.1 and dv.median() > 0.5
+    out = {k: np.array(v) for k, v in log.items()}
+    out["lr_final"] = np.array(optimizer.param_groups[0]["lr"])
+    out["clipped_idx"], out["final_at_clipped"], out["final_at_clipped_noclip"] = idx, final_flat[idx], final_flat_n[idx]
+    out["loss_noclip"] = np.array(log_n["loss"])
+    out["exp_avg_at_clipped"], out["exp_avg_at_clipped_noclip"] = m_flat[idx], m_flat_n[idx]
+    out["exp_avg_sq_at_clipped"], out["exp_avg_sq_at_clipped_noclip"] = v_flat[idx], v_flat_n[idx]
+    out["exp_avg_sub"], out["exp_avg_sq_sub"] = m_flat[::61], v_flat[::61]
+    out.update(sub_summary(kw_train["network_fn"].state_dict(), "final.c."))
+    out.update(sub_summary(kw_train["network_fine"].state_dict(), "final.f."))
+    save("train_10steps_V", **out)
+
+
+def fx_ssloss_primary():
+    """The consumers of the in-loop consistency masks (run_nerf_view_test.py VT:941-969; SURVEY calls the range VT:940-968): the primary render's rgb / depth
+    losses on both levels, each either restricted to `[mask_bound][mask]` or not by its own `random.randint(0, 1)` coin
+    (incl. the reference's quirk that the coarse rgb term falls back to the FINE rgb when its coin is 0).  The reference's
+    own statements are read from its source and executed with the coins supplied in call order."""
+    src = os.path.join(REF, "run_nerf_view_test.py")
+    block = _ref_lines(src, 941, 969, "optimizer.zero_grad()")
+    rs = np.random.RandomState(77)
+    N = 96
+    arr = dict(rgb=rs.uniform(size=(N, 3)), rgb0=rs.uniform(size=(N, 3)), depth_pred=rs.uniform(2, 6, size=(N,)),
+               depth0=rs.uniform(2, 6, size=(N,)), target_s=rs.uniform(size=(N, 3)), depth_cas_s=rs.uniform(2, 6, size=(N,)))
+    arr = {k: v.astype(np.float32) for k, v in arr.items()}
+    mask_bound = (rs.uniform(size=(1, N)) < 0.8)
+    mask = (rs.uniform(size=(int(mask_bound.sum()), 1)) < 0.5)
+    out = dict(mask_bound=mask_bound, mask=mask, **arr)
+    for with_depth in (True, False):
+        for coins in ((1, 1, 1, 1), (0, 0, 0, 0), (1, 0, 0, 1), (0, 1, 1, 0)):
+            leaf = {k: T(arr[k]).requires_grad_(True) for k in ("rgb", "rgb0", "depth_pred", "depth0")}
+            seq = list(coins if with_depth else (coins[0], coins[2]))
+            ns = dict(torch=torch, rgb=leaf["rgb"], depth_pred=leaf["depth_pred"], target_s=T(arr["target_s"]),
+                      depth_cas_s=T(arr["depth_cas_s"]), mask_bound=T(mask_bound), mask=T(mask), loss=0,
+                      extras=dict(rgb0=leaf["rgb0"], depth0=leaf["depth0"], raw=torch.zeros(N, 4, 4)),
+                      args=types.SimpleNamespace(ss_loss=True, with_depth_loss=with_depth),
+                      optimizer=types.SimpleNamespace(zero_grad=lambda: None), img2mse=VT.img2mse, mse2psnr=VT.mse2psnr,
+                      random=types.SimpleNamespace(randint=lambda a, b: seq.pop(0)))
+            exec(block, ns)
+            assert not seq, "coin order assumption broken"
+            ns["loss"].backward()
+            tag = f"{'d' if with_depth else 'n'}{''.join(map(str, coins))}."
+            out.update({tag + "loss": ns["loss"].detach(), tag + "img_loss": ns["img_loss"].detach(),
+                        tag + "img_loss0": ns["img_loss0"].detach(), tag + "psnr": ns["psnr"].detach(),
+                        tag + "psnr0": ns["psnr0"].detach()})
+            for k, t in leaf.items():
+                out[tag + "d_" + k] = t.grad if t.grad is not None else torch.zeros_like(t)
+    save("ssloss_primary", **out)
+
+
+ALL = dict(train_v=fx_train_v, ssloss_primary=fx_ssloss_primary, ssloss=fx_ssloss, poses=fx_poses, patch=fx_patch, formats=fx_formats, raybank=fx_raybank, embed=fx_embed, mlp=fx_mlp, raw2outputs=fx_raw2outputs, sample_pdf=fx_sample_pdf,
            render_rays=fx_render_rays, render_full=fx_render_full, warp=fx_warp, hardmask=fx_hardmask,
            losses=fx_losses, train=fx_train, pairs=fx_pairs)
 

@@ -196,7 +196,11 @@ def test_sample_pdf_indices(dev, tag):
     mism = inds != g["inds"]
     print(f"  index mismatches: {mism.sum()} of {mism.size} ({(mism & safe).sum()} with margin > 1e-5)")
     assert not (mism & safe).any(), "sample_pdf indices must be bit-exact away from CDF ties"
-    assert mism.mean() < 2e-3
+    # observed (r01 / r02, profiles/r02_sample_pdf_index_mismatches.json): det 32 of 32768 — every one at the u = 1.0 tie of a
+    # row — and rand 0; the bound is the observed count
+    assert mism.sum() <= (32 if tag == "det" else 0), mism.sum()
+    if tag == "det":
+        assert np.all(g["u"].reshape(-1, g["inds"].shape[-1])[..., -1] == 1.0) and not mism[:, :-1].any()
     # at a CDF tie (u == cdf_k to within round-off, e.g. u = 1.0 in det mode) the reference itself jumps by a whole
     # bin when the neighbouring CDF gap is < 1e-5 (H:246-247), so only non-tie entries are compared tightly
     sg = samples.cpu().numpy()
@@ -448,7 +452,9 @@ def test_render_full_image_and_rays(dev):
         check(rgb, g["rgb" + sfx], tol, "rgb" + sfx)
         check(acc, g["acc" + sfx], tol, "acc" + sfx)
         check(depth, g["depth" + sfx], tol * far, "depth" + sfx)
-        check(extras["rgb0"], g["rgb0" + sfx], tol, "rgb0" + sfx)
+        # the coarse level evaluates identical (bit-exact) sample depths on both sides: kernel-level tolerance there.  (Under
+        # NDC the ray origins / directions themselves carry the 1e-5 of ndc_rays above, which the encoding amplifies.)
+        check(extras["rgb0"], g["rgb0" + sfx], tol if ndc else 2e-5, "rgb0" + sfx)
         assert rgb.shape == (16, 16, 3) and depth.shape == (16, 16)
         assert torch.equal(rgb, rgb_r) and "depth_map" not in extras_r and "depth0" not in extras_r
         assert set(extras_r) == {"rgb0", "disp0", "acc0", "z_std"}
@@ -1241,3 +1247,201 @@ def test_input_gradients_fail_loudly(dev):
     with pytest.raises(ops.CnerfError):
         model(x)
     assert model(x.detach()).shape == (16, 4)
+
+
+# ------------------------------------------------------------------------------------------------
+# round 2: the branches C3 / C4 rely on — clip + grad_scale in the optimiser tail (V:1983), masked means under sharding,
+# the coin-flip consumers of the in-loop masks (VT:941-969), FusedAdam under torch.autograd.grad
+def _view_args(tmp):
+    import argparse
+    return argparse.Namespace(
+        multires=10, i_embed=0, use_viewdirs=True, multires_views=4, N_importance=32, netdepth=4, netwidth=128,
+        netdepth_fine=4, netwidth_fine=128, netchunk=1024 * 64, lrate=5e-4, lrate_decay=250, basedir=tmp, expname="exp",
+        ft_path=None, no_reload=True, perturb=1.0, N_samples=32, stable_init=True, white_bkgd=False, raw_noise_std=0.0,
+        dataset_type="dtu", no_ndc=True, lindisp=False)
+
+
+@pytest.mark.parametrize("route", ["fused_clip", "torch_clip_on_grad_views"])
+def test_train_10_steps_view_variant_golden(dev, route):
+    """The ConsistentNeRF loop against the reference's own 10 steps (`train_10steps_V`: V.create_nerf, V.render, the masked
+    rgb + depth losses on both levels V:1645-1648 / 1737 / 1786-1788 / 1865, then the reference's own tail V:1982-1994 =
+    backward, clip_grad_value_(grad_vars, 0.1), Adam, lr decay).  Two routes: the clip folded into the Adam kernel
+    (`clip_value=0.1`), and torch's own clip_grad_value_ on grad_vars (whose .grad are views of FusedAdam's flat buffer)
+    followed by the unclipped kernel.  Pinned where the clip matters: the Adam moments and final values of the parameters
+    whose gradient exceeded 0.1 at step 0 — the fixture's no-clip control differs there by 24 % / >50 % / >1e-4."""
+    import tempfile
+    from consistentnerf_amd import run_nerf_view as V
+    g = golden("train_10steps_V")
+    with tempfile.TemporaryDirectory() as tmp:
+        args = _view_args(tmp)
+        kw_train, kw_test, start, grad_vars, optimizer = V.create_nerf(args)
+    c0, f0 = kw_train["network_fn"].state_dict(), kw_train["network_fine"].state_dict()
+    assert all(torch.equal(c0[k], f0[k]) for k in c0), "V:321: the coarse net starts as a copy of the fine one"
+    for net, seed in ((kw_train["network_fn"], 51), (kw_train["network_fine"], 52)):
+        net.load_state_dict({k: T(v) for k, v in I.nerf_state_dict(4, 128, 10, 4, 5, True, seed=seed, gain=0.6).items()})
+    near, far = 2.0, 6.0
+    kw_train.update(near=near, far=far)
+    K = I.intrinsics(100, 100, 138.0)
+    if route == "fused_clip":
+        optimizer.param_groups[0]["clip_value"] = 0.1
+    global_step = start
+    for i in range(10):
+        rays = T(I.ray_batch(256, seed=300 + i, near=near, far=far), dev)
+        rs = np.random.RandomState(400 + i)
+        target = T(rs.uniform(size=(256, 3)).astype(np.float32), dev)
+        prior = T(rs.uniform(near, far, size=(256,)).astype(np.float32), dev)
+        mask = T((rs.uniform(size=(256,)) < 0.6).astype(np.float32), dev)
+        rgb, disp, acc, depth, extras = V.render(100, 100, K, chunk=32768, rays=torch.stack([rays[:, 0:3], rays[:, 3:6]], 0),
+                                                 retraw=True, pytest=True, **kw_train)
+        optimizer.zero_grad()
+        il, dl = V.hardmask_losses(rgb, target, mask, 0.2, depth, prior, far)
+        il0, dl0 = V.hardmask_losses(extras["rgb0"], target, mask, 0.2, extras["depth0"], prior, far)
+        for t, k in zip((il, dl, il0, dl0), ("img_loss", "depth_loss", "img_loss0", "depth_loss0")):
+            rel = abs(t.item() - g[k][i]) / abs(g[k][i])
+            assert rel < 1e-3, (i, k, t.item(), g[k][i])
+        loss = il + dl + il0 + dl0
+        loss.backward()
+        n_over = int((optimizer.flat_grad.abs() > 0.1).sum())
+        print(f"  step {i}: loss {loss.item():.6f} ref {g['loss'][i]:.6f}; |g| > 0.1: {n_over} (ref {int(g['n_clipped'][i])})")
+        if i == 0:
+            assert np.array_equal(torch.nonzero(optimizer.flat_grad.abs() > 0.1).reshape(-1).cpu().numpy(), g["clipped_idx"])
+        if route == "torch_clip_on_grad_views":
+            torch.nn.utils.clip_grad_value_(grad_vars, 0.1)
+            assert float(optimizer.flat_grad.abs().max()) <= 0.1000001
+        optimizer.step()
+        new_lrate = args.lrate * (0.1 ** (global_step / (args.lrate_decay * 1000)))
+        for pg in optimizer.param_groups:
+            pg["lr"] = new_lrate
+        global_step += 1
+    assert abs(optimizer.param_groups[0]["lr"] - float(g["lr_final"])) < 1e-12
+    idx = T(g["clipped_idx"], dev)
+    check(optimizer.flat_param[idx], g["final_at_clipped"], 5e-5, "final values of the clipped parameters")
+    effect = np.abs(g["final_at_clipped"] - g["final_at_clipped_noclip"])
+    assert np.median(effect) > 1e-4
+    m, m_ref, m_noclip = optimizer.exp_avg[idx].cpu().numpy(), g["exp_avg_at_clipped"], g["exp_avg_at_clipped_noclip"]
+    v, v_ref = optimizer.exp_avg_sq[idx].cpu().numpy(), g["exp_avg_sq_at_clipped"]
+    rel_m, rel_v = np.abs(m - m_ref) / np.abs(m_ref).max(), np.abs(v - v_ref) / np.abs(v_ref).max()
+    print(f"  Adam moments at the clipped parameters: rel |d m| {rel_m.max():.2e}  rel |d v| {rel_v.max():.2e}; the no-clip "
+          f"control is {(np.abs(m_noclip - m_ref) / np.abs(m_ref).max()).max():.2f} away")
+    assert rel_m.max() < 2e-2 and rel_v.max() < 2e-2
+    assert (np.abs(m_noclip - m_ref) / np.abs(m_ref).max()).max() > 0.2
+    worst = 0.0
+    for tag, net in (("c", kw_train["network_fn"]), ("f", kw_train["network_fine"])):
+        for k, p in net.state_dict().items():
+            worst = max(worst, float(np.abs(p.reshape(-1)[::7].cpu().numpy() - g[f"final.{tag}.{k}.sub"]).max()))
+    print(f"  final weights: max|d| = {worst:.3e}")
+    assert worst < 2e-4
+
+
+@pytest.mark.parametrize("clip,grad_scale", [(0.0, 1.0), (0.1, 1.0), (0.0, 0.125), (0.05, 3.0)])
+def test_adam_kernel_clip_and_grad_scale(dev, clip, grad_scale):
+    """cnerf_adam_step: gradient scaling, then clip_grad_value_ (V:1983), then torch.optim.Adam's update — 3 steps against
+    the oracle's ATen Adam on a buffer whose gradients straddle the clip."""
+    from consistentnerf_amd import ops
+    rs = np.random.RandomState(5)
+    n = 100003
+    p0 = rs.normal(size=n).astype(np.float32)
+    p, m, v = T(p0, dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    pr, mr, vr = T(p0), torch.zeros(n), torch.zeros(n)
+    for step in (1, 2, 3):
+        g = (rs.normal(size=n) * 0.2 / max(grad_scale, 1e-3) * (1.0 if step < 3 else 1e-3)).astype(np.float32)
+        ops.adam_step(p, T(g, dev), m, v, step, 5e-4, clip=clip, grad_scale=grad_scale)
+        O.adam_step(pr, T(g) * grad_scale, mr, vr, step, 5e-4, clip=clip)
+        if clip > 0 and step == 1:
+            assert (np.abs(g * grad_scale) > clip).mean() > 0.2
+    check(m, mr, 1e-7, "exp_avg"); check(v, vr, 1e-8, "exp_avg_sq"); check(p, pr, 2e-7, "param")
+
+
+@pytest.mark.parametrize("nshards", [2, 3])
+def test_masked_losses_global_counts_sharded(dev, nshards):
+    """SURVEY hard part 7: masked means under ray sharding.  Each shard calls the loss kernel with the GLOBAL set sizes
+    (`counts`, distributed.global_mask_counts): the shard losses add up to — and the shard gradients concatenate to — the
+    single-call result and the reference capture (`losses_mask`)."""
+    from consistentnerf_amd import distributed as D, run_nerf_view as V
+    g = golden("losses_mask")
+    far, c = float(g["far"]), float(g["coef"])
+    B = g["mask"].shape[0]
+    mask = T(g["mask"], dev)
+    counts = D.global_mask_counts(mask)
+    assert counts.tolist() == [float((g["mask"] == 1).sum()), float((g["mask"] == 0).sum())]
+    bounds = [D.shard_bounds(B, r, nshards) for r in range(nshards)]
+    assert bounds[0][0] == 0 and bounds[-1][1] == B and all(a[1] == b[0] for a, b in zip(bounds, bounds[1:]))
+    tot_rgb, tot_dep, d_rgb, d_dep = 0.0, 0.0, [], []
+    for lo, hi in bounds:
+        r = T(g["rgb"][lo:hi], dev).requires_grad_(True)
+        d = T(g["depth"][lo:hi], dev).requires_grad_(True)
+        lr, ld = V.hardmask_losses(r, T(g["target"][lo:hi], dev), mask[lo:hi], c, d, T(g["prior"][lo:hi], dev), far,
+                                   counts=counts)
+        (lr + ld).backward()
+        tot_rgb, tot_dep = tot_rgb + lr.item(), tot_dep + ld.item()
+        d_rgb.append(r.grad); d_dep.append(d.grad)
+    assert abs(tot_rgb - float(g["mixed.l_rgb"])) < 1e-7 and abs(tot_dep - float(g["mixed.l_depth"])) < 1e-7
+    check(torch.cat(d_rgb), g["mixed.d_rgb"], 1e-9, "d_rgb (sharded, global counts)")
+    check(torch.cat(d_dep), g["mixed.d_depth"], 1e-9, "d_depth (sharded, global counts)")
+    # without the global counts the shard means are local means: NOT the same thing (the branch is doing something)
+    lr_local, _ = V.hardmask_losses(T(g["rgb"][:bounds[0][1]], dev), T(g["target"][:bounds[0][1]], dev),
+                                    mask[:bounds[0][1]], c)
+    assert abs(lr_local.item() * 1.0 - tot_rgb) > 1e-4
+
+
+def test_ss_primary_losses_golden(dev):
+    """VT:941-969: the primary render's rgb / depth terms restricted to `[mask_bound][mask]` per coin, incl. the coarse rgb
+    term's fallback to the fine rgb — value and gradients against the reference's own statements (`ssloss_primary`)."""
+    from consistentnerf_amd import run_nerf_view as V
+    g = golden("ssloss_primary")
+    for wd in (True, False):
+        for coins in ((1, 1, 1, 1), (0, 0, 0, 0), (1, 0, 0, 1), (0, 1, 1, 0)):
+            tag = f"{'d' if wd else 'n'}{''.join(map(str, coins))}."
+            leaf = {k: T(g[k], dev).requires_grad_(True) for k in ("rgb", "rgb0", "depth_pred", "depth0")}
+            seq = coins if wd else (coins[0], coins[2])
+            loss, il, il0 = V.ss_primary_losses(leaf["rgb"], leaf["depth_pred"], dict(rgb0=leaf["rgb0"], depth0=leaf["depth0"]),
+                                                T(g["target_s"], dev), T(g["depth_cas_s"], dev), T(g["mask_bound"], dev),
+                                                T(g["mask"], dev), wd, seq)
+            check(loss, g[tag + "loss"], 2e-6, tag + "loss"); check(il, g[tag + "img_loss"], 2e-7, tag + "img_loss")
+            check(il0, g[tag + "img_loss0"], 2e-7, tag + "img_loss0")
+            check(V.mse2psnr(il), g[tag + "psnr"], 2e-5, tag + "psnr")
+            loss.backward()
+            for k, t in leaf.items():
+                got = t.grad if t.grad is not None else torch.zeros_like(t)
+                check(got, g[tag + "d_" + k], 2e-8 if "rgb" in k else 2e-6, tag + "d_" + k)
+    # coins=None draws like the reference: random.randint(0, 1) in call order
+    import random
+    random.seed(3)
+    expect = [random.randint(0, 1) for _ in range(4)]
+    random.seed(3)
+    leaf = {k: T(g[k], dev) for k in ("rgb", "rgb0", "depth_pred", "depth0")}
+    a = V.ss_primary_losses(leaf["rgb"], leaf["depth_pred"], dict(rgb0=leaf["rgb0"], depth0=leaf["depth0"]),
+                            T(g["target_s"], dev), T(g["depth_cas_s"], dev), T(g["mask_bound"], dev), T(g["mask"], dev), True)
+    b = V.ss_primary_losses(leaf["rgb"], leaf["depth_pred"], dict(rgb0=leaf["rgb0"], depth0=leaf["depth0"]),
+                            T(g["target_s"], dev), T(g["depth_cas_s"], dev), T(g["mask_bound"], dev), T(g["mask"], dev), True,
+                            expect)
+    assert a[0].item() == b[0].item()
+
+
+def test_fused_adam_params_under_autograd_grad(dev):
+    """torch.autograd.grad on FusedAdam-owned parameters: the engine captures instead of accumulating, so _MlpFn.backward
+    must hand back real tensors and must NOT touch the optimizer's flat gradient (it used to write into it and return
+    None).  .backward() afterwards still takes the direct route (no per-tensor gradients, flat buffer filled)."""
+    from consistentnerf_amd import ops, run_nerf as R
+    from consistentnerf_amd.optim import FusedAdam
+    coarse, _ = make_model(4, 128, True, 5, 93, dev)
+    fine, _ = make_model(4, 128, True, 5, 94, dev)
+    kw = _kwargs(coarse, fine, 16, 16, 0.0, False, 0.0, False)
+    rays, tgt = T(I.ray_batch(40, seed=4), dev), torch.rand(40, 3, device=dev)
+
+    def loss_of():
+        o = R.render_rays(rays, **kw)
+        return R.img2mse(o["rgb_map"], tgt) + R.img2mse(o["rgb0"], tgt)
+    params = [p for m in (coarse, fine) for p in m.kernel_tensors()]
+    ref = torch.autograd.grad(loss_of(), params)                      # plain nn.Parameters: tensor route
+    opt = FusedAdam(list(coarse.parameters()) + list(fine.parameters()), lr=5e-4)
+    opt.zero_grad()
+    got = torch.autograd.grad(loss_of(), params)                      # FusedAdam-owned: must still be the tensor route
+    for a, b in zip(got, ref):
+        assert a is not None and torch.equal(a, b)
+    assert float(opt.flat_grad.abs().max()) == 0.0, "autograd.grad must not write into the optimizer's gradient buffer"
+    loss_of().backward()
+    flat_ref = torch.cat([(dict(zip(map(id, params), ref)).get(id(p), torch.zeros_like(p))).reshape(-1) for p in opt.params])
+    assert float((opt.flat_grad - flat_ref).abs().max()) <= 1e-6 * float(flat_ref.abs().max())
+    loss_of().backward(inputs=params)                                 # accumulating backward with explicit inputs: direct too
+    assert float((opt.flat_grad - 2 * flat_ref).abs().max()) <= 2e-6 * float(flat_ref.abs().max())

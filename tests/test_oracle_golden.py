@@ -213,6 +213,70 @@ def test_train_10_steps():
     assert float(g["test_perturb"]) == 0.0
 
 
+def test_train_10_steps_view_variant():
+    """The ConsistentNeRF loop's wiring: masked rgb + depth losses on both levels (V:1645-1648, 1737, 1786-1788, 1865),
+    clip_grad_value_(0.1) before Adam (V:1983), lr decay — against the reference's own 10 steps (`train_10steps_V`)."""
+    g = golden("train_10steps_V")
+    sds = [O.as_tensors(I.nerf_state_dict(4, 128, 10, 4, 5, True, seed=s, gain=0.6), True) for s in (51, 52)]
+    net, cfg = O.NetCfg(D=4, W=128, output_ch=5), O.RenderCfg(32, 32, 1.0)
+    params = [p for sd in sds for p in sd.values()]
+    m = [torch.zeros_like(p) for p in params]
+    v = [torch.zeros_like(p) for p in params]
+    near, far, lr = 2.0, 6.0, 5e-4
+    for i in range(10):
+        rays = T(I.ray_batch(256, seed=300 + i, near=near, far=far))
+        rs = np.random.RandomState(400 + i)
+        target = T(rs.uniform(size=(256, 3)).astype(np.float32))
+        prior = T(rs.uniform(near, far, size=(256,)).astype(np.float32))
+        mask = T((rs.uniform(size=(256,)) < 0.6).astype(np.float32))
+        out = O.render_rays_pytest(rays, sds[0], sds[1], net, cfg)
+        terms = (O.masked_rgb_loss(out["rgb_map"], target, mask, 0.2), O.masked_depth_loss(out["depth_map"], prior, mask, far),
+                 O.masked_rgb_loss(out["rgb0"], target, mask, 0.2), O.masked_depth_loss(out["depth0"], prior, mask, far))
+        for t, k in zip(terms, ("img_loss", "depth_loss", "img_loss0", "depth_loss0")):
+            assert abs(t.item() - g[k][i]) <= 5e-5 * abs(g[k][i]), (i, k, t.item(), g[k][i])
+        loss = terms[0] + terms[1] + terms[2] + terms[3]
+        grads = torch.autograd.grad(loss, params, allow_unused=True)
+        flat = torch.cat([(gr if gr is not None else torch.zeros_like(p)).reshape(-1) for p, gr in zip(params, grads)])
+        assert int((flat.abs() > 0.1).sum()) == int(g["n_clipped"][i]), (i, int((flat.abs() > 0.1).sum()), g["n_clipped"][i])
+        if i == 0:
+            assert np.array_equal(torch.nonzero(flat.abs() > 0.1).reshape(-1).numpy(), g["clipped_idx"])
+        with torch.no_grad():
+            for p, gr, mm, vv in zip(params, grads, m, v):
+                if gr is not None:
+                    O.adam_step(p, gr, mm, vv, i + 1, lr, clip=0.1)
+        lr = O.lr_at(5e-4, i, 250)
+    assert abs(lr - float(g["lr_final"])) < 1e-12
+    idx = torch.from_numpy(g["clipped_idx"])
+    flat_p = torch.cat([p.detach().reshape(-1) for p in params])
+    flat_m, flat_v = torch.cat([x.reshape(-1) for x in m]), torch.cat([x.reshape(-1) for x in v])
+    # what the clip changes is far above the tolerance: the fixture's own no-clip control differs by 1e-4 (weights),
+    # 24 % (first moment) and >50 % (second moment) at these positions
+    close(flat_p[idx], g["final_at_clipped"], rtol=0, atol=2e-5)
+    close(flat_m[idx], g["exp_avg_at_clipped"], rtol=2e-3, atol=1e-7)
+    close(flat_v[idx], g["exp_avg_sq_at_clipped"], rtol=2e-3, atol=1e-12)
+    assert np.abs(g["final_at_clipped"] - g["final_at_clipped_noclip"]).max() > 2e-4
+    for tag, sd in (("c", sds[0]), ("f", sds[1])):
+        for k, p in sd.items():
+            assert np.abs(p.detach().reshape(-1)[::7].numpy() - g[f"final.{tag}.{k}.sub"]).max() <= 2e-5, (tag, k)
+
+
+def test_ss_primary_losses():
+    """VT:941-969: the coin-flip masked consumers of the in-loop consistency masks."""
+    g = golden("ssloss_primary")
+    for wd in (True, False):
+        for coins in ((1, 1, 1, 1), (0, 0, 0, 0), (1, 0, 0, 1), (0, 1, 1, 0)):
+            tag = f"{'d' if wd else 'n'}{''.join(map(str, coins))}."
+            leaf = {k: T(g[k]).requires_grad_(True) for k in ("rgb", "rgb0", "depth_pred", "depth0")}
+            seq = coins if wd else (coins[0], coins[2])
+            loss, il, il0 = O.ss_primary_losses(leaf["rgb"], leaf["depth_pred"], leaf["rgb0"], leaf["depth0"], T(g["target_s"]),
+                                                T(g["depth_cas_s"]), T(g["mask_bound"]), T(g["mask"]), wd, seq)
+            eq(loss, g[tag + "loss"]); eq(il, g[tag + "img_loss"]); eq(il0, g[tag + "img_loss0"])
+            eq(O.psnr_from_mse(il), g[tag + "psnr"]); eq(O.psnr_from_mse(il0), g[tag + "psnr0"])
+            loss.backward()
+            for k, t in leaf.items():
+                eq(t.grad if t.grad is not None else torch.zeros_like(t), g[tag + "d_" + k], tag + k)
+
+
 def test_ray_bank_and_samplers_golden():
     """the oracle's ray bank / batching / --no_batching sampler against the statements of the
     reference's train() replayed around its own get_rays_np / get_rays (tests/golden/make_golden.py::fx_raybank)."""
