@@ -61,6 +61,9 @@ SIGNATURES = {
     "cnerf_mlp_fwd_embedded": (_i, [_NetP, _vp, _vp, _i64, _vp, _vp, _vp]),
     "cnerf_mlp_bwd_ws_floats": (_i64, [_NetP, _i64]),
     "cnerf_mlp_bwd": (_i, [_NetP, _vp, _vp, _i64, _i, _vp, _vp, _PtrsP, _i, _vp]),
+    "cnerf_mlp_bwd_pair": (_i, [_NetP, _vp, _vp, _i64, _i, _vp, _vp, _PtrsP, _NetP, _vp, _vp, _i64, _i, _vp, _vp, _PtrsP, _i, _vp]),
+    "cnerf_mlp_dgrad_pair": (_i, [_NetP, _vp, _vp, _i64, _i, _vp, _vp, _NetP, _vp, _vp, _i64, _i, _vp, _vp, _vp]),
+    "cnerf_mlp_wgrad_pair": (_i, [_NetP, _i64, _i, _vp, _vp, _PtrsP, _NetP, _i64, _i, _vp, _vp, _PtrsP, _i, _vp]),
     "cnerf_mlp_dgrad": (_i, [_NetP, _vp, _vp, _i64, _i, _vp, _vp, _vp]),
     "cnerf_mlp_wgrad": (_i, [_NetP, _i64, _i, _vp, _vp, _PtrsP, _i, _vp]),
     "cnerf_composite_fwd": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -77,6 +80,7 @@ SIGNATURES = {
     "cnerf_warp_points": (_i, [_vp, _i64, C.POINTER(_f), _f, _f, _f, _f, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "cnerf_hard_mask_pair": (_i, [_i, _i, _f, _f, _f, _f, C.POINTER(_f), C.POINTER(_f), _vp, _vp, _f, _i, _vp,
                                   _vp, _vp]),
+    "cnerf_mse": (_i, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "cnerf_loss_ws_floats": (_i64, []),
     "cnerf_masked_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
     "cnerf_patch_depth_loss": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp, _vp]),

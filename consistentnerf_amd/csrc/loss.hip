@@ -166,6 +166,31 @@ __global__ void patch_depth_loss_k(const float* __restrict__ depth, const float*
 
 }  // namespace
 
+// img2mse (H:9): loss = mean((x - y)^2) over n elements + the gradient seed 2 (x - y) / n, one launch (replaces ATen's
+// sub, pow, mean and their three backward kernels).  One workgroup, fixed order, fp64 accumulation.
+namespace {
+__global__ __launch_bounds__(T) void mse_k(const float* __restrict__ x, const float* __restrict__ y, int64_t n,
+                                           float* __restrict__ loss, float* __restrict__ d_x) {
+  __shared__ double sh[T / 64];
+  double s = 0;
+  const float w = (float)(2.0 / (double)n);
+  for (int64_t i = threadIdx.x; i < n; i += T) {
+    const float d = x[i] - y[i];
+    s += (double)(d * d);
+    if (d_x) d_x[i] = w * d;
+  }
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) loss[0] = (float)(s / (double)n);
+}
+}  // namespace
+
+extern "C" int cnerf_mse(const float* x, const float* y, int64_t n, float* loss, float* d_x, void* stream) {
+  if (!x || !y || !loss || n <= 0) return CNERF_E_ARG;
+  hipLaunchKernelGGL(mse_k, dim3(1), dim3(T), 0, cn_stream(stream), x, y, n, loss, d_x);
+  CN_CHECK_LAUNCH();
+  return CNERF_OK;
+}
+
 extern "C" int64_t cnerf_loss_ws_floats(void) { return 0; }
 
 extern "C" int cnerf_masked_loss(const float* rgb, const float* target, const float* depth, const float* prior,

@@ -12,13 +12,18 @@
 
 int cn_wgrad_launch(const NetGeom& g, const float* stash, const float* G, int64_t M, int64_t Mp, float* partials,
                     int nsplit, const cnerf_ptrs* grads, int accumulate, hipStream_t st);
+int cn_wgrad_launch_n(int n, const NetGeom* const* g, const float* const* stash, const float* const* G, const int64_t* Mp,
+                      float* const* partials, const int* nsplit, const cnerf_ptrs* const* grads, int accumulate,
+                      hipStream_t st);
 int cn_wgrad_nsplit(int64_t Mp);
 int64_t cn_param_floats(const NetGeom& g);
 
 namespace {
 
-struct BwdArgs {
-  NetGeom g;
+// One level's operands.  A launch carries up to two levels of the SAME architecture (the coarse and the fine network of a
+// training step: independent once the forward is done): blocks [0, nb0) walk level 0, the rest level 1 — one grid, so the
+// 8 rounds of the coarse level ride behind the 24 of the fine one instead of paying their own ramp and tail.
+struct BwdLevel {
   const float* packed;
   const float* d_raw;
   const float* stash;
@@ -26,14 +31,27 @@ struct BwdArgs {
   int64_t M, Mp;
 };
 
+struct BwdArgs {
+  NetGeom g;
+  BwdLevel lv[2];
+  unsigned nb0;
+};
+
+#define CN_CONST __attribute__((address_space(4)))
+
 template <int NT, bool VD>
-__global__ __launch_bounds__(64) void mlp_dgrad_k(BwdArgs a) {
+__global__ __launch_bounds__(64) void mlp_dgrad_k(BwdArgs args_by_value) {
   constexpr int W = NT * 32;
   constexpr int NTH = NT / 2 > 0 ? NT / 2 : 1;
   constexpr int MD = (NT + 1) / 2, MDV = (NTH + 1) / 2;
-  const NetGeom& g = a.g;
+  (void)args_by_value;   // read in place from the kernarg segment (scalar loads; the level is picked by blockIdx.x)
+  const CN_CONST BwdArgs& args = *(const CN_CONST BwdArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  const CN_CONST NetGeom& g = args.g;
+  const unsigned nb0 = args.nb0;
+  const bool second = blockIdx.x >= nb0;
+  const CN_CONST BwdLevel& a = args.lv[second ? 1 : 0];
   const int lane = threadIdx.x, m = lane & 31, hh = lane >> 5;
-  const int64_t p0 = (int64_t)blockIdx.x * 32;
+  const int64_t p0 = (int64_t)(blockIdx.x - (second ? nb0 : 0u)) * 32;
   const int64_t p = p0 + m;
   const int nvalid = a.M - p0 < 32 ? (int)(a.M - p0) : 32;
   const int64_t pc = p < a.M ? p : a.M - 1;
@@ -164,16 +182,29 @@ __global__ __launch_bounds__(64) void mlp_dgrad_k(BwdArgs a) {
 }
 
 template <int NT>
-int launch(const BwdArgs& a, hipStream_t st) {
-  const unsigned grid = (unsigned)cn_div_up(a.M, 32);
-  if (a.Mp > a.M) {   // last gradient tile row holds padding points: the kernel drops their stores, wgrad reads them
-    hipError_t e = hipMemsetAsync(a.G + (a.Mp - 32) * a.g.g_rows, 0, (size_t)32 * a.g.g_rows * sizeof(float), st);
-    if (e != hipSuccess) return (int)e;
+int launch(const BwdArgs& a, int nlev, hipStream_t st) {
+  unsigned grid = 0;
+  for (int i = 0; i < nlev; ++i) {
+    const BwdLevel& L = a.lv[i];
+    grid += (unsigned)cn_div_up(L.M, 32);
+    if (L.Mp > L.M) {   // last gradient tile row holds padding points: the kernel drops their stores, wgrad reads them
+      hipError_t e = hipMemsetAsync(L.G + (L.Mp - 32) * a.g.g_rows, 0, (size_t)32 * a.g.g_rows * sizeof(float), st);
+      if (e != hipSuccess) return (int)e;
+    }
   }
   if (a.g.viewdirs) hipLaunchKernelGGL((mlp_dgrad_k<NT, true>), dim3(grid), dim3(64), 0, st, a);
   else hipLaunchKernelGGL((mlp_dgrad_k<NT, false>), dim3(grid), dim3(64), 0, st, a);
   CN_CHECK_LAUNCH();
   return CNERF_OK;
+}
+
+int dispatch(const BwdArgs& a, int nlev, hipStream_t st) {
+  switch (a.g.NT) {
+    case 2: return launch<2>(a, nlev, st);
+    case 4: return launch<4>(a, nlev, st);
+    case 8: return launch<8>(a, nlev, st);
+  }
+  return CNERF_E_UNSUPPORTED;
 }
 
 }  // namespace
@@ -196,15 +227,10 @@ extern "C" int cnerf_mlp_dgrad(const cnerf_net* net, const float* packed, const 
   if (rc) return rc;
   if (!packed || !d_raw || !stash || !workspace || B < 0 || S <= 0) return CNERF_E_ARG;
   if (B == 0) return CNERF_OK;
-  a.packed = packed; a.d_raw = d_raw; a.stash = stash; a.G = workspace;
-  a.M = B * S; a.Mp = cn_round_up(a.M, 32);
-  hipStream_t st = cn_stream(stream);
-  switch (a.g.NT) {
-    case 2: return launch<2>(a, st);
-    case 4: return launch<4>(a, st);
-    case 8: return launch<8>(a, st);
-  }
-  return CNERF_E_UNSUPPORTED;
+  a.lv[0] = BwdLevel{packed, d_raw, stash, workspace, B * S, cn_round_up(B * S, 32)};
+  a.lv[1] = a.lv[0];
+  a.nb0 = (unsigned)cn_div_up(B * S, 32);
+  return dispatch(a, 1, cn_stream(stream));
 }
 
 extern "C" int cnerf_mlp_wgrad(const cnerf_net* net, int64_t B, int S, const float* stash, float* workspace,
@@ -227,4 +253,75 @@ extern "C" int cnerf_mlp_bwd(const cnerf_net* net, const float* packed, const fl
   int rc = cnerf_mlp_dgrad(net, packed, d_raw, B, S, stash, workspace, stream);
   if (rc) return rc;
   return cnerf_mlp_wgrad(net, B, S, stash, workspace, grads, accumulate, stream);
+}
+
+// Backward of TWO independent networks in one dgrad grid + one wgrad grid (+ one reduction): the coarse and the fine
+// network of a render_rays training step (R:311-421) — their backward passes share nothing once the forward is done
+// (the fine level's sample depths are detached, R:397).  The dgrad grid is shared when both have the same architecture,
+// otherwise two dgrad launches; the wgrad grid is always shared.  net0 / net1 must be different parameter sets (two
+// reductions into one gradient tensor would race).  Workspaces as for cnerf_mlp_bwd, one per network.
+extern "C" int cnerf_mlp_dgrad_pair(const cnerf_net* net0, const float* packed0, const float* d_raw0, int64_t B0, int S0,
+                                    const float* stash0, float* workspace0, const cnerf_net* net1, const float* packed1,
+                                    const float* d_raw1, int64_t B1, int S1, const float* stash1, float* workspace1,
+                                    void* stream) {
+  BwdArgs a;
+  NetGeom g1;
+  int rc = cn_make_geom(net0, &a.g);
+  if (rc) return rc;
+  if ((rc = cn_make_geom(net1, &g1))) return rc;
+  if (!packed0 || !d_raw0 || !stash0 || !workspace0 || !packed1 || !d_raw1 || !stash1 || !workspace1 || B0 < 0 || B1 < 0 ||
+      S0 <= 0 || S1 <= 0)
+    return CNERF_E_ARG;
+  const int64_t M0 = B0 * S0, M1 = B1 * S1;
+  const bool same = net0->D == net1->D && net0->W == net1->W && net0->multires == net1->multires &&
+                    net0->multires_views == net1->multires_views && net0->use_viewdirs == net1->use_viewdirs &&
+                    net0->output_ch == net1->output_ch && net0->skip == net1->skip;
+  if (same && M0 > 0 && M1 > 0) {
+    a.lv[0] = BwdLevel{packed0, d_raw0, stash0, workspace0, M0, cn_round_up(M0, 32)};
+    a.lv[1] = BwdLevel{packed1, d_raw1, stash1, workspace1, M1, cn_round_up(M1, 32)};
+    a.nb0 = (unsigned)cn_div_up(M0, 32);
+    return dispatch(a, 2, cn_stream(stream));
+  }
+  if ((rc = cnerf_mlp_dgrad(net0, packed0, d_raw0, B0, S0, stash0, workspace0, stream))) return rc;
+  return cnerf_mlp_dgrad(net1, packed1, d_raw1, B1, S1, stash1, workspace1, stream);
+}
+
+extern "C" int cnerf_mlp_wgrad_pair(const cnerf_net* net0, int64_t B0, int S0, const float* stash0, float* workspace0,
+                                    const cnerf_ptrs* grads0, const cnerf_net* net1, int64_t B1, int S1,
+                                    const float* stash1, float* workspace1, const cnerf_ptrs* grads1, int accumulate,
+                                    void* stream) {
+  if (!grads0 || !grads1 || !stash0 || !stash1 || !workspace0 || !workspace1 || B0 < 0 || B1 < 0 || S0 <= 0 || S1 <= 0)
+    return CNERF_E_ARG;
+  if (B0 == 0) return cnerf_mlp_wgrad(net1, B1, S1, stash1, workspace1, grads1, accumulate, stream);
+  if (B1 == 0) return cnerf_mlp_wgrad(net0, B0, S0, stash0, workspace0, grads0, accumulate, stream);
+  for (int i = 0; i < CNERF_MAX_TENSORS; ++i)
+    if (grads0->p[i] && grads0->p[i] == grads1->p[i]) return CNERF_E_ARG;
+  NetGeom g0, g1;
+  int rc = cn_make_geom(net0, &g0);
+  if (rc) return rc;
+  if ((rc = cn_make_geom(net1, &g1))) return rc;
+  const int64_t Mp0 = cn_round_up(B0 * S0, 32), Mp1 = cn_round_up(B1 * S1, 32);
+  const NetGeom* gs[2] = {&g0, &g1};
+  const float* stashes[2] = {stash0, stash1};
+  const float* Gs[2] = {workspace0, workspace1};
+  const int64_t Mps[2] = {Mp0, Mp1};
+  const int ns[2] = {cn_wgrad_nsplit(Mp0), cn_wgrad_nsplit(Mp1)};
+  float* parts[2] = {workspace0 + (int64_t)g0.g_rows * Mp0, workspace1 + (int64_t)g1.g_rows * Mp1};
+  const cnerf_ptrs* grs[2] = {grads0, grads1};
+  return cn_wgrad_launch_n(2, gs, stashes, Gs, Mps, parts, ns, grs, accumulate, cn_stream(stream));
+}
+
+extern "C" int cnerf_mlp_bwd_pair(const cnerf_net* net0, const float* packed0, const float* d_raw0, int64_t B0, int S0,
+                                  const float* stash0, float* workspace0, const cnerf_ptrs* grads0,
+                                  const cnerf_net* net1, const float* packed1, const float* d_raw1, int64_t B1, int S1,
+                                  const float* stash1, float* workspace1, const cnerf_ptrs* grads1, int accumulate,
+                                  void* stream) {
+  if (!grads0 || !grads1) return CNERF_E_ARG;
+  for (int i = 0; i < CNERF_MAX_TENSORS; ++i)
+    if (grads0->p[i] && grads0->p[i] == grads1->p[i]) return CNERF_E_ARG;
+  int rc = cnerf_mlp_dgrad_pair(net0, packed0, d_raw0, B0, S0, stash0, workspace0, net1, packed1, d_raw1, B1, S1, stash1,
+                                workspace1, stream);
+  if (rc) return rc;
+  return cnerf_mlp_wgrad_pair(net0, B0, S0, stash0, workspace0, grads0, net1, B1, S1, stash1, workspace1, grads1, accumulate,
+                              stream);
 }

@@ -12,7 +12,8 @@ struct Layout {            // float offsets into the workspace
   int64_t z0, raw0, w0;    // coarse level: z[B,Nc], raw[B,Nc,C0], weights[B,Nc]
   int64_t z1, raw1, w1;    // fine level (Nf > 0): z[B,S1], raw[B,S1,C1], weights[B,S1]
   int64_t stash0, stash1;  // training stashes
-  int64_t d_raw, bwd;      // backward scratch: d_raw of one level, cnerf_mlp_bwd workspace of one level
+  int64_t d_raw, bwd;      // backward scratch: d_raw of the coarse level, cnerf_mlp_bwd workspace of the coarse level
+  int64_t d_raw1, bwd1;    // ... of the fine level (both levels are in flight together: cnerf_mlp_bwd_pair)
   int64_t total;
   int C0, C1, S1;
 };
@@ -31,14 +32,16 @@ int make_layout(const cnerf_net* coarse, const cnerf_net* fine, const cnerf_rend
   L->z0 = take(B * Nc); L->raw0 = take(B * Nc * L->C0); L->w0 = take(B * Nc);
   L->z1 = L->raw1 = L->w1 = L->stash0 = L->stash1 = -1;
   if (cfg->Nf > 0) { L->z1 = take(B * S1); L->raw1 = take(B * S1 * L->C1); L->w1 = take(B * S1); }
-  L->d_raw = L->bwd = -1;
+  L->d_raw = L->bwd = L->d_raw1 = L->bwd1 = -1;
   if (cfg->train) {
     L->stash0 = take(cnerf_mlp_stash_floats(coarse, B * Nc));
     if (cfg->Nf > 0) L->stash1 = take(cnerf_mlp_stash_floats(n1, B * S1));
-    const int64_t d0 = B * Nc * L->C0, d1 = cfg->Nf > 0 ? B * S1 * L->C1 : 0;
-    L->d_raw = take(d0 > d1 ? d0 : d1);
-    const int64_t b0 = cnerf_mlp_bwd_ws_floats(coarse, B * Nc), b1 = cfg->Nf > 0 ? cnerf_mlp_bwd_ws_floats(n1, B * S1) : 0;
-    L->bwd = take(b0 > b1 ? b0 : b1);
+    L->d_raw = take(B * Nc * L->C0);
+    L->bwd = take(cnerf_mlp_bwd_ws_floats(coarse, B * Nc));
+    if (cfg->Nf > 0) {
+      L->d_raw1 = take(B * S1 * L->C1);
+      L->bwd1 = take(cnerf_mlp_bwd_ws_floats(n1, B * S1));
+    }
   }
   L->total = o;
   return CNERF_OK;
@@ -116,16 +119,28 @@ extern "C" int cnerf_render_bwd(const cnerf_net* coarse, const float* packed_coa
   float* ws = workspace;
   const int Nc = cfg->Nc, rs = cfg->ray_stride;
   const bool two = cfg->Nf > 0;
-  int acc0 = accumulate;
-  if (two) {   // fine level first (the order autograd runs it)
-    const cnerf_net* n1 = fine ? fine : coarse;
+  if (two && fine) {
+    // two networks: their backward passes are independent (the fine depths are detached, R:397) -> both compositing
+    // backwards, then ONE dgrad grid + ONE wgrad grid for both (fine level first: the larger blocks lead the grid)
     if ((rc = cnerf_composite_bwd(ws + L.raw1, L.C1, ws + L.z1, rays, rs, noise1, B, L.S1, cfg->white_bkgd, g->g_rgb_map,
-                                  g->g_disp_map, g->g_acc_map, g->g_depth_map, ws + L.d_raw, stream)))
+                                  g->g_disp_map, g->g_acc_map, g->g_depth_map, ws + L.d_raw1, stream)))
       return rc;
-    if ((rc = cnerf_mlp_bwd(n1, fine ? packed_fine : packed_coarse, ws + L.d_raw, B, L.S1, ws + L.stash1, ws + L.bwd,
-                            fine ? grads_fine : grads_coarse, accumulate, stream)))
+    if ((rc = cnerf_composite_bwd(ws + L.raw0, L.C0, ws + L.z0, rays, rs, noise0, B, Nc, cfg->white_bkgd, g->g_rgb0,
+                                  g->g_disp0, g->g_acc0, g->g_depth0, ws + L.d_raw, stream)))
       return rc;
-    if (!fine) acc0 = 1;   // one network, two levels: the coarse pass adds to what the fine pass wrote
+    return cnerf_mlp_bwd_pair(fine, packed_fine, ws + L.d_raw1, B, L.S1, ws + L.stash1, ws + L.bwd1, grads_fine,
+                              coarse, packed_coarse, ws + L.d_raw, B, Nc, ws + L.stash0, ws + L.bwd, grads_coarse,
+                              accumulate, stream);
+  }
+  int acc0 = accumulate;
+  if (two) {   // one network serving both levels (R:402): fine level first (the order autograd runs it)
+    if ((rc = cnerf_composite_bwd(ws + L.raw1, L.C1, ws + L.z1, rays, rs, noise1, B, L.S1, cfg->white_bkgd, g->g_rgb_map,
+                                  g->g_disp_map, g->g_acc_map, g->g_depth_map, ws + L.d_raw1, stream)))
+      return rc;
+    if ((rc = cnerf_mlp_bwd(coarse, packed_coarse, ws + L.d_raw1, B, L.S1, ws + L.stash1, ws + L.bwd1, grads_coarse,
+                            accumulate, stream)))
+      return rc;
+    acc0 = 1;   // the coarse pass adds to what the fine pass wrote
   }
   if ((rc = cnerf_composite_bwd(ws + L.raw0, L.C0, ws + L.z0, rays, rs, noise0, B, Nc, cfg->white_bkgd,
                                 two ? g->g_rgb0 : g->g_rgb_map, two ? g->g_disp0 : g->g_disp_map,

@@ -39,6 +39,7 @@ constexpr int DUMMY_BYTES = 1024;           // landing zone of the no-op DMA pie
 constexpr int LDS_FLOATS = (LDS_BYTES - DUMMY_BYTES) / 4;
 
 struct WgJob {
+  int net;            // which operand set (WgArgs::net) the job reads / writes: 0, or 1 for the second network of a pair
   int xcol, ycol;     // first column of X in G rows, of Y in stash rows
   int N, K;           // output rows [n_lo, N) x cols [0, K) of the slab product are valid
   int n_lo;           // (rows below n_lo belong to another GEMM that shares the X columns; keeps DMA 16-B aligned)
@@ -48,8 +49,10 @@ struct WgJob {
   int gk, an, ak;     // wave grid: wave w -> (wn, wk) = (w / gk, w % gk) owns an x ak tiles of 32x32
 };
 
-struct WgArgs {
-  WgJob job[MAX_WG_JOBS];
+// One network's operands.  A launch carries up to two (the coarse and the fine network of a training step, whose
+// backward passes are independent once the forward is done): their GEMMs share ONE grid, so the small launch of the
+// coarse level (14 jobs x 64 point ranges on 256 CUs) rides in the tail of the fine one instead of having its own.
+struct WgNet {
   int64_t toff[CNERF_MAX_TENSORS];   // offset of each tensor in the partial (parameter-space) buffer
   const float* stash;
   const float* G;
@@ -57,7 +60,22 @@ struct WgArgs {
   int64_t Mp, pstride;               // pstride = floats per split slice
   int64_t chunk;                     // points per split (multiple of 32)
   int s_rows, g_rows;
+  int nsplit;                        // point ranges of this network (blocks with blockIdx.x >= nsplit have no work)
 };
+
+struct WgArgs {
+  WgJob job[MAX_WG_JOBS];
+  WgNet net[2];
+};
+
+// The kernel argument block is read IN PLACE through the constant address space (scalar loads from the kernarg
+// segment).  Taken by value and indexed with blockIdx.y, the compiler copies the whole struct to scratch first (2.7 KB
+// per lane, ~200 scratch instructions, and every scratch access in the slab loop drains vmcnt, i.e. waits for the DMA
+// in flight).
+#define CN_CONST __attribute__((address_space(4)))
+typedef const CN_CONST WgArgs WgArgsC;
+typedef const CN_CONST WgJob WgJobC;
+typedef const CN_CONST WgNet WgNetC;
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
@@ -82,7 +100,7 @@ __device__ __forceinline__ i32x4 dma_rsrc(const float* base, unsigned bytes) {
 
 // Body for a compile-time per-wave tile block AN x AK (<= 4 x 4); BS: this wave also sums the X columns (bias).
 template <int AN, int AK, bool BS>
-__device__ __forceinline__ void wgrad_body(const WgArgs& a, const WgJob& jb, float* lds) {
+__device__ __forceinline__ void wgrad_body(WgNetC& a, WgJobC& jb, float* lds) {
   const int split = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, i31 = lane & 31, hh = lane >> 5;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform on the scalar unit: addresses stay SALU
@@ -295,15 +313,19 @@ __device__ __forceinline__ void wgrad_body(const WgArgs& a, const WgJob& jb, flo
 }
 
 template <int AN, int AK>
-__device__ __forceinline__ void wgrad_disp(const WgArgs& a, const WgJob& jb, float* lds) {
+__device__ __forceinline__ void wgrad_disp(WgNetC& a, WgJobC& jb, float* lds) {
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (jb.bias_tensor >= 0 && wv % jb.gk == 0) wgrad_body<AN, AK, true>(a, jb, lds);
   else wgrad_body<AN, AK, false>(a, jb, lds);
 }
 
-__global__ __launch_bounds__(64 * NWAVES) void wgrad_k(WgArgs a) {
+__global__ __launch_bounds__(64 * NWAVES) void wgrad_k(WgArgs a_by_value) {
   extern __shared__ __attribute__((aligned(16))) float lds[];   // [2 buffers][X slab | Y slab]
-  const WgJob& jb = a.job[blockIdx.y];
+  (void)a_by_value;   // (the first and only explicit kernel argument: offset 0 of the kernarg segment)
+  WgArgsC& args = *(WgArgsC*)__builtin_amdgcn_kernarg_segment_ptr();
+  WgJobC& jb = args.job[blockIdx.y];
+  WgNetC& a = args.net[jb.net];
+  if ((int)blockIdx.x >= a.nsplit) return;   // block-uniform: the grid's x extent is the larger network's range count
   switch (jb.an * 8 + jb.ak) {     // block-uniform
     case 4 * 8 + 4: wgrad_disp<4, 4>(a, jb, lds); break;
     case 4 * 8 + 2: wgrad_disp<4, 2>(a, jb, lds); break;
@@ -317,14 +339,14 @@ __global__ __launch_bounds__(64 * NWAVES) void wgrad_k(WgArgs a) {
   }
 }
 
-struct RedArgs {
-  float* grad[CNERF_MAX_TENSORS];
-  int64_t toff[CNERF_MAX_TENSORS];
-  int64_t numel[CNERF_MAX_TENSORS];
-  int touched[CNERF_MAX_TENSORS];
-  const float* partials;
-  int64_t pstride;
-  int nsplit, accumulate;
+struct RedArgs {    // entries [0, nt0) belong to the first network, [nt0, nt0 + nt1) to the second
+  float* grad[2 * CNERF_MAX_TENSORS];
+  const float* part[2 * CNERF_MAX_TENSORS];   // the tensor's slot in split slice 0
+  int64_t numel[2 * CNERF_MAX_TENSORS];
+  int64_t pstride[2 * CNERF_MAX_TENSORS];
+  int nsplit[2 * CNERF_MAX_TENSORS];
+  int touched[2 * CNERF_MAX_TENSORS];
+  int accumulate;
 };
 
 // Fixed-order sum of the split partials (bit-reproducible).  Bandwidth-bound (nsplit x ~2.4 MB): 16-byte loads, 8
@@ -334,21 +356,23 @@ __global__ __launch_bounds__(256) void wgrad_reduce_k(RedArgs a) {
   float* g = a.grad[t];
   if (g == nullptr) return;
   const int64_t n = a.numel[t], n4 = n >> 2;
-  const float* p0 = a.partials + a.toff[t];   // tensor offsets are multiples of 4 floats, pstride of 64
+  const float* p0 = a.part[t];   // tensor offsets are multiples of 4 floats, pstride of 64
+  const int nsplit = a.nsplit[t];
+  const int64_t pstride = a.pstride[t];
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (a.touched[t]) {
       const f32x4* p = reinterpret_cast<const f32x4*>(p0) + i;
-      const int64_t st = a.pstride >> 2;
+      const int64_t st = pstride >> 2;
       int k = 0;
-      for (; k + 8 <= a.nsplit; k += 8) {
+      for (; k + 8 <= nsplit; k += 8) {
         f32x4 v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(k + u) * st];
 #pragma unroll
         for (int u = 0; u < 8; ++u) s += v[u];   // in split order
       }
-      for (; k < a.nsplit; ++k) s += p[(int64_t)k * st];
+      for (; k < nsplit; ++k) s += p[(int64_t)k * st];
     }
     f32x4* gp = reinterpret_cast<f32x4*>(g) + i;
     if ((reinterpret_cast<uintptr_t>(g) & 15) == 0) {
@@ -362,7 +386,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_k(RedArgs a) {
   for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     float s = 0.f;
     if (a.touched[t])
-      for (int k = 0; k < a.nsplit; ++k) s += p0[i + (int64_t)k * a.pstride];
+      for (int k = 0; k < nsplit; ++k) s += p0[i + (int64_t)k * pstride];
     g[i] = a.accumulate ? g[i] + s : s;
   }
 }
@@ -400,25 +424,30 @@ int cn_wgrad_nsplit(int64_t Mp) {
   return (int)s;
 }
 
-int cn_wgrad_launch(const NetGeom& g, const float* stash, const float* G, int64_t M, int64_t Mp, float* partials,
-                    int nsplit, const cnerf_ptrs* grads, int accumulate, hipStream_t st) {
-  (void)M;   // padding points [M, Mp) are stored as zeros by the producers: no masking here
+namespace {
+
+// Appends one network's GEMMs to the job table / reduction table.  Returns false when a shape is outside the envelope.
+bool add_net_jobs(const NetGeom& g, int netidx, const float* stash, const float* G, int64_t Mp, float* partials,
+                  int nsplit, const cnerf_ptrs* grads, WgArgs& a, int& nj, RedArgs& r, int& nr) {
   cnerf_net net{g.D, g.W, g.L, g.Ld, g.viewdirs, g.out_ch, g.skip};
-  WgArgs a;
-  RedArgs r;
+  WgNet& wn = a.net[netidx];
   const int nt = cnerf_num_tensors(&net);
+  const int r0 = nr;
   int64_t off = 0;
   for (int i = 0; i < nt; ++i) {
     int64_t rr, cc;
     cnerf_tensor_shape(&net, i, &rr, &cc);
-    a.toff[i] = r.toff[i] = off;
-    r.numel[i] = rr * cc;
-    r.grad[i] = grads->p[i];
-    r.touched[i] = 0;
+    wn.toff[i] = off;
+    r.numel[r0 + i] = rr * cc;
+    r.grad[r0 + i] = grads->p[i];
+    r.part[r0 + i] = partials + off;
+    r.nsplit[r0 + i] = nsplit;
+    r.touched[r0 + i] = 0;
     off += cn_round_up(rr * cc, 4);
   }
+  nr += nt;
   const int64_t pstride = cn_round_up(off, 64);
-  int nj = 0;
+  for (int i = 0; i < nt; ++i) r.pstride[r0 + i] = pstride;
   const int D = g.D, W = g.W, Wh = g.Wh;
   bool ok = true;
   auto add = [&](int xcol, int ycol, int N, int K, int tensor, int ld, int col0, int bias_tensor, int n_lo = 0) {
@@ -433,14 +462,13 @@ int cn_wgrad_launch(const NetGeom& g, const float* stash, const float* G, int64_
       const int cost = an * ak * 16 + an + ak;
       if (cost < best_cost) { best_cost = cost; best_gk = gk; best_an = an; best_ak = ak; }
     }
-    if (best_gk == 0 || best_an == 3 || best_ak == 3 || ntn > 8 || ntk > 8) ok = false;
-    a.job[nj++] = WgJob{xcol, ycol, N, K, n_lo, tensor, ld, col0, bias_tensor, best_gk ? best_gk : 2, best_an,
+    if (best_gk == 0 || best_an == 3 || best_ak == 3 || ntn > 8 || ntk > 8 || nj >= MAX_WG_JOBS) { ok = false; return; }
+    a.job[nj++] = WgJob{netidx, xcol, ycol, N, K, n_lo, tensor, ld, col0, bias_tensor, best_gk ? best_gk : 2, best_an,
                         best_ak};
-    r.touched[tensor] = 1;
-    if (bias_tensor >= 0) r.touched[bias_tensor] = 1;
+    r.touched[r0 + tensor] = 1;
+    if (bias_tensor >= 0) r.touched[r0 + bias_tensor] = 1;
   };
   const int base = 2 * D;
-  // largest GEMMs first (the grid is dispatched job-major): the small ones fill the tail
   for (int l = 1; l < D; ++l) {
     const bool sk = g.skip >= 0 && l == g.skip + 1;
     add(g.g_z[l], g.s_h[l - 1], W, W, 2 * l, sk ? W + g.in_ch : W, sk ? g.in_ch : 0, 2 * l + 1);
@@ -458,12 +486,38 @@ int cn_wgrad_launch(const NetGeom& g, const float* stash, const float* G, int64_
   } else {
     add(g.g_out, g.s_h[D - 1], g.out_ch, W, base + 2, W, 0, base + 3);
   }
-  if (!ok || nj > MAX_WG_JOBS) return CNERF_E_UNSUPPORTED;
-  a.stash = stash; a.G = G; a.partials = partials; a.Mp = Mp; a.pstride = pstride;
-  a.s_rows = g.s_rows; a.g_rows = g.g_rows;
-  a.chunk = cn_round_up(cn_div_up(Mp, nsplit), TM);
+  wn.stash = stash; wn.G = G; wn.partials = partials; wn.Mp = Mp; wn.pstride = pstride;
+  wn.s_rows = g.s_rows; wn.g_rows = g.g_rows; wn.nsplit = nsplit;
+  wn.chunk = cn_round_up(cn_div_up(Mp, nsplit), TM);
   // a split's operand rows sit behind one buffer resource each: 32-bit byte offsets
-  if (a.chunk * (int64_t)(g.s_rows > g.g_rows ? g.s_rows : g.g_rows) * 4 >= (int64_t)0x7fffffff) return CNERF_E_UNSUPPORTED;
+  if (wn.chunk * (int64_t)(g.s_rows > g.g_rows ? g.s_rows : g.g_rows) * 4 >= (int64_t)0x7fffffff) ok = false;
+  return ok;
+}
+
+}  // namespace
+
+// Weight gradients of one network (n = 1) or of two independent ones in one grid (n = 2; cnerf_mlp_bwd_pair).
+int cn_wgrad_launch_n(int n, const NetGeom* const* g, const float* const* stash, const float* const* G, const int64_t* Mp,
+                      float* const* partials, const int* nsplit, const cnerf_ptrs* const* grads, int accumulate,
+                      hipStream_t st) {
+  WgArgs a;
+  RedArgs r;
+  int nj = 0, nr = 0, max_split = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!add_net_jobs(*g[i], i, stash[i], G[i], Mp[i], partials[i], nsplit[i], grads[i], a, nj, r, nr))
+      return CNERF_E_UNSUPPORTED;
+    max_split = nsplit[i] > max_split ? nsplit[i] : max_split;
+  }
+  if (n == 1) a.net[1] = a.net[0];
+  // largest workgroups first (the grid is dispatched job-major): the busiest wave's tile count x the points of a range;
+  // the small ones fill the tail.  Stable, so one network's GEMMs keep their order.
+  auto cost = [&](const WgJob& j) { return (int64_t)j.an * j.ak * a.net[j.net].chunk; };
+  for (int i = 1; i < nj; ++i) {
+    const WgJob j = a.job[i];
+    int k = i - 1;
+    for (; k >= 0 && cost(a.job[k]) < cost(j); --k) a.job[k + 1] = a.job[k];
+    a.job[k + 1] = j;
+  }
   const size_t lds_bytes = LDS_BYTES;
   // the 160 KiB dynamic-LDS opt-in is a per-device function attribute: set it once per device this process launches on
   // (idempotent, so a race between two host threads only repeats the call)
@@ -476,10 +530,17 @@ int cn_wgrad_launch(const NetGeom& g, const float* stash, const float* G, int64_
       return (int)hipGetLastError();
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL(wgrad_k, dim3(nsplit, nj), dim3(64 * NWAVES), lds_bytes, st, a);
+  hipLaunchKernelGGL(wgrad_k, dim3(max_split, nj), dim3(64 * NWAVES), lds_bytes, st, a);
   CN_CHECK_LAUNCH();
-  r.partials = partials; r.pstride = pstride; r.nsplit = nsplit; r.accumulate = accumulate;
-  hipLaunchKernelGGL(wgrad_reduce_k, dim3(64, nt), dim3(256), 0, st, r);
+  r.accumulate = accumulate;
+  hipLaunchKernelGGL(wgrad_reduce_k, dim3(64, nr), dim3(256), 0, st, r);
   CN_CHECK_LAUNCH();
   return CNERF_OK;
+}
+
+int cn_wgrad_launch(const NetGeom& g, const float* stash, const float* G, int64_t M, int64_t Mp, float* partials,
+                    int nsplit, const cnerf_ptrs* grads, int accumulate, hipStream_t st) {
+  (void)M;   // padding points [M, Mp) are stored as zeros by the producers: no masking here
+  const NetGeom* gp = &g;
+  return cn_wgrad_launch_n(1, &gp, &stash, &G, &Mp, &partials, &nsplit, &grads, accumulate, st);
 }

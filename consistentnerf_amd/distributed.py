@@ -78,11 +78,78 @@ def allreduce_sum_(flat_grad: torch.Tensor) -> torch.Tensor:
     return flat_grad
 
 
+class GradReducer:
+    """The step's ONE gradient exchange, issued in contiguous slices of FusedAdam's flat fp32 gradient as they become
+    final, so that a slice travels over xGMI while the rest of the backward still computes.
+
+    Each network's parameters are one contiguous slice of the flat buffer.  `_MlpFn.backward` (run_nerf.py) reports a
+    network when the LAST of its pending backward nodes has accumulated into the buffer (a network evaluated twice in a
+    step — one net for both levels R:402, the second render of ss_consistency — is reported once, after both); the slice's
+    all-reduce is issued right there with async_op=True: RCCL's stream waits for the wgrad reduction that produced the
+    slice (an event on the launch stream), the launch stream carries on with the other network's backward.
+    `finish()` — call it between loss.backward() and optimizer.step() — issues whatever was not reported (networks
+    whose backward did not run still contribute zeros on this rank), makes the launch stream wait for the collectives
+    and applies the 1/world scale (`mean=True`: per-rank losses are means over equal shards; `mean=False`: per-ray weights
+    were already normalised by global counts, `global_mask_counts`).  With the coarse and fine backward merged into one
+    dgrad and one wgrad grid (the default when both networks are FusedAdam-owned, run_nerf._MlpFn), both slices become
+    final together and go out as two back-to-back messages (2 x 2.38 MB at C2); with CNERF_MERGE_BWD=0 the fine slice's
+    exchange overlaps the coarse network's backward.  Without an initialised process group everything is a no-op.
+
+    Timing (bench.py): `last_exposed_ms()` = HIP-event time on the launch stream from the moment the last slice was
+    issued (all gradient compute queued) to the moment the launch stream may proceed — the part of the exchange the step
+    actually waits for."""
+
+    def __init__(self, optimizer, modules, mean: bool = True, timing: bool = False):
+        self.opt, self.mean, self.timing = optimizer, mean, timing
+        self.modules = [m for m in modules if m is not None]
+        self.slices = {}
+        for m in self.modules:
+            self.slices[id(m)] = optimizer.slice_of(list(m.parameters()))
+            m._cnerf_reducer = self
+            m._cnerf_pending = 0
+        self._works, self._done, self._ev = [], set(), None
+        self.bytes_per_step = 4 * sum(hi - lo for lo, hi in self.slices.values())
+        self.exposed = []
+
+    def _issue(self, m):
+        lo, hi = self.slices[id(m)]
+        self._done.add(id(m))
+        if not dist.is_initialized():
+            return
+        if self.timing and len(self._done) == len(self.modules):
+            self._ev = torch.cuda.Event(enable_timing=True)
+            self._ev.record(torch.cuda.current_stream())
+        self._works.append(dist.all_reduce(self.opt.flat_grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+
+    def network_ready(self, m):
+        """called by _MlpFn.backward when network `m` has no backward node pending in this step"""
+        if id(m) in self.slices and id(m) not in self._done:
+            self._issue(m)
+
+    def finish(self):
+        for m in self.modules:
+            if id(m) not in self._done:
+                self._issue(m)
+            m._cnerf_pending = 0
+        for w in self._works:
+            w.wait()                 # the launch stream waits for RCCL's stream; the host does not block
+        if self.timing and self._ev is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record(torch.cuda.current_stream())
+            self.exposed.append((self._ev, e1))
+        if self.mean and world() > 1:
+            self.opt.flat_grad.mul_(1.0 / world())
+        self._works, self._done, self._ev = [], set(), None
+
+    def exposed_ms(self):
+        return [a.elapsed_time(b) for a, b in self.exposed]
+
+
 def global_mask_counts(mask: torch.Tensor) -> torch.Tensor:
     """(n_masked, n_unmasked) over ALL ranks as a 2-float tensor (8-byte all-reduce), for hardmask_losses."""
     m = mask.reshape(-1)
     c = torch.stack([(m == 1).sum(), (m == 0).sum()]).to(torch.float32)
-    if world() > 1:
+    if dist.is_initialized():
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
     return c
 

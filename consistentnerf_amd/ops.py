@@ -222,6 +222,28 @@ def mlp_backward(spec: NetSpec, packed: Tensor, d_raw: Tensor, B: int, S: int, s
     return grads
 
 
+def mlp_backward_pair(spec0: NetSpec, packed0: Tensor, d_raw0: Tensor, B0: int, S0: int, stash0: Tensor, grads0: List[Tensor],
+                      spec1: NetSpec, packed1: Tensor, d_raw1: Tensor, B1: int, S1: int, stash1: Tensor, grads1: List[Tensor],
+                      accumulate: bool = False):
+    """cnerf_mlp_bwd_pair: the backward of two independent networks (coarse / fine) as one dgrad grid, one wgrad grid and
+    one reduction; gradients are written (or accumulated) into grads0 / grads1."""
+    lib = _lib.load()
+    n0, n1 = spec0.c(), spec1.c()
+    d_raw0, d_raw1 = _chk(d_raw0, "d_raw0"), _chk(d_raw1, "d_raw1")
+    dev = packed0.device
+    ws0 = torch.empty(lib.cnerf_mlp_bwd_ws_floats(C.byref(n0), B0 * S0), device=dev, dtype=torch.float32)
+    ws1 = torch.empty(lib.cnerf_mlp_bwd_ws_floats(C.byref(n1), B1 * S1), device=dev, dtype=torch.float32)
+    p0, p1 = _ptrs(grads0), _ptrs(grads1)
+    with _timed("mlp_dgrad", B0 * S0 + B1 * S1):
+        _lib.check(lib.cnerf_mlp_dgrad_pair(C.byref(n0), _p(packed0), _p(d_raw0), B0, S0, _p(stash0), _p(ws0),
+                                            C.byref(n1), _p(packed1), _p(d_raw1), B1, S1, _p(stash1), _p(ws1), _stream()),
+                   "cnerf_mlp_dgrad_pair")
+    with _timed("mlp_wgrad", B0 * S0 + B1 * S1):
+        _lib.check(lib.cnerf_mlp_wgrad_pair(C.byref(n0), B0, S0, _p(stash0), _p(ws0), C.byref(p0),
+                                            C.byref(n1), B1, S1, _p(stash1), _p(ws1), C.byref(p1), int(accumulate),
+                                            _stream()), "cnerf_mlp_wgrad_pair")
+
+
 # ------------------------------------------------------------------------------------------ render_rays as one call
 class RenderState:
     """What cnerf_render_bwd needs from the forward call it follows: the workspace (z, raw, weights, stashes) and the
@@ -377,6 +399,15 @@ def masked_loss(rgb, target, depth, prior, mask, far: float, coef: float, counts
                                              float(coef), _p(counts), float(g_scale), _p(loss), _p(d_rgb), _p(d_depth),
                                              None, _stream()), "cnerf_masked_loss")
     return loss, d_rgb, d_depth
+
+
+def mse(x: Tensor, y: Tensor, want_grad: bool = True):
+    """cnerf_mse: (mean((x - y)^2) as a 0-d tensor, d loss / d x | None)."""
+    x, y = _chk(x, "x"), _chk(y, "y")
+    loss = torch.empty(1, device=x.device)
+    d_x = torch.empty_like(x) if want_grad else None
+    _lib.check(_lib.load().cnerf_mse(_p(x), _p(y), x.numel(), _p(loss), _p(d_x), _stream()), "cnerf_mse")
+    return loss[0], d_x
 
 
 def patch_depth_loss(depth_pred: Tensor, mono: Tensor, P: int, n: int, g_scale: float = 1.0, want_grad: bool = True):

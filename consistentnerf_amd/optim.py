@@ -30,6 +30,7 @@ class FusedAdam:
         for n in sizes:
             self._offsets.append(self._offsets[-1] + n)
         total = self._offsets[-1]
+        self._index = {id(p): i for i, p in enumerate(self.params)}
         self.flat_param = torch.empty(total, device=dev, dtype=torch.float32)
         self.flat_grad = torch.zeros(total, device=dev, dtype=torch.float32)
         self.exp_avg = torch.zeros(total, device=dev, dtype=torch.float32)
@@ -40,6 +41,13 @@ class FusedAdam:
                 p.data = self.flat_param[o:o + n].view(p.shape)
                 p.grad = self.flat_grad[o:o + n].view(p.shape)
                 p._cnerf_direct_grad = True     # _MlpFn.backward accumulates into this view directly
+
+    def slice_of(self, params):
+        """[lo, hi) of the flat buffers covered by `params` (e.g. one network's parameters); they must be contiguous in it."""
+        idx = sorted(self._index[id(p)] for p in params)
+        if idx != list(range(idx[0], idx[-1] + 1)):
+            raise ValueError("parameters are not contiguous in the flat buffer")
+        return self._offsets[idx[0]], self._offsets[idx[-1] + 1]
 
     # -- torch.optim surface -------------------------------------------------------------------
     def zero_grad(self, set_to_none: bool = False):

@@ -12,6 +12,7 @@ masked losses) on top of this module.
 """
 import os
 import time
+import weakref
 
 import numpy as np
 import torch
@@ -38,17 +39,31 @@ class RayPoints:
         return self.rays[:, None, 0:3] + self.rays[:, None, 3:6] * self.z_vals[..., None]
 
 
-def _packed(model):
-    """Kernel-layout weights of `model`, re-packed only when a parameter changed (optimizer step / load)."""
+def _packed_gen(model):
+    """Kernel-layout weights of `model`, re-packed only when a parameter changed (optimizer step / load).  Two buffers
+    alternate, so the copy a forward pass used stays intact for its backward without a per-step clone: it is overwritten
+    by the SECOND re-pack after it — two parameter updates between a forward and its backward, where the reference
+    itself fails (autograd's version check on the modified weights).  Returns (buffer, generation)."""
     ts = model.kernel_tensors()
     key = tuple((t.data_ptr(), t._version, getattr(t, "_cnerf_epoch", 0)) for t in ts)
-    cache = getattr(model, "_cnerf_packed", None)
+    cache = model.__dict__.get("_cnerf_packed")
     if cache is None or cache[0] != key:
+        gen = 0 if cache is None else cache[2] + 1
+        bufs = [None, None] if cache is None else cache[3]
         with torch.no_grad():
-            packed = ops.pack_weights(model.spec(), ts, None if cache is None else cache[1])
-        cache = (key, packed)
-        model._cnerf_packed = cache
-    return cache[1]
+            bufs[gen & 1] = ops.pack_weights(model.spec(), ts, bufs[gen & 1])
+        cache = (key, bufs[gen & 1], gen, bufs)
+        model.__dict__["_cnerf_packed"] = cache
+    return cache[1], cache[2]
+
+
+def _packed(model):
+    return _packed_gen(model)[0]
+
+
+def _packed_still_valid(model, gen):
+    cache = model.__dict__.get("_cnerf_packed")
+    return cache is not None and cache[2] - gen <= 1
 
 
 def _engine_accumulates(p):
@@ -63,13 +78,51 @@ def _engine_accumulates(p):
         return False
 
 
+# The coarse and the fine network's backward passes share nothing once the forward is done (z is detached at R:397): when
+# both are FusedAdam-owned they run as ONE dgrad grid + ONE wgrad grid (cnerf_mlp_bwd_pair) instead of two of each — the
+# 8-round coarse launches otherwise pay their own ramp and tail.  CNERF_MERGE_BWD=0 keeps them separate.
+MERGE_BWD = os.environ.get("CNERF_MERGE_BWD", "1") != "0"
+
+
+class _LevelPair:
+    """Links the coarse and the fine _MlpFn node of one render_rays call.  The fine node runs first in the backward pass
+    (it was created last); if the engine is going to run the coarse node too, it parks its inputs here and the coarse node
+    launches both."""
+    __slots__ = ("coarse", "fine", "parked")
+
+    def __init__(self, coarse_node, fine_node):
+        self.coarse, self.fine, self.parked = weakref.ref(coarse_node), weakref.ref(fine_node), None
+
+
+def _link_levels(raw_coarse, raw_fine):
+    nc, nf = raw_coarse.grad_fn, raw_fine.grad_fn
+    if not MERGE_BWD or nc is None or nf is None:
+        return
+    if getattr(nc, "stash", None) is None or getattr(nf, "stash", None) is None or nc.model is nf.model:
+        return
+    nc.pair = nf.pair = _LevelPair(nc, nf)
+
+
+def _direct_ok(needs, params):
+    return all(needs) and all(getattr(p, "_cnerf_direct_grad", False) and p.grad is not None and p.grad.is_contiguous()
+                              for p in params)
+
+
+def _report_ready(model, direct):
+    """One backward node of `model` has accumulated into the flat gradient: tell the GradReducer when it was the last."""
+    if hasattr(model, "_cnerf_pending"):
+        model._cnerf_pending -= 1
+        if direct and model._cnerf_pending <= 0:
+            model._cnerf_reducer.network_ready(model)
+
+
 class _MlpFn(torch.autograd.Function):
     """Fused gamma(x), gamma(d) + MLP (replaces R:37-52 + H:44-45 + H:107-130 and their autograd)."""
 
     @staticmethod
     def forward(ctx, model, B, S, pts, rays, z, dirs, emb, *params):
         spec = model.spec()
-        packed = _packed(model)
+        packed, gen = _packed_gen(model)
         if any(ctx.needs_input_grad[3:8]):
             # fail loudly rather than return silently-missing gradients: the reference never differentiates through the
             # sample positions (z is detached at R:397, rays come from the data), and the dgrad kernel stops at layer 0
@@ -81,27 +134,56 @@ class _MlpFn(torch.autograd.Function):
         else:
             raw, stash = ops.mlp_forward(spec, packed, B, S, pts=pts, rays=rays, z=z, dirs=dirs, want_stash=train)
         if train:
-            # the packed buffer is reused by the next pack; keep this step's copy for the backward
-            ctx.spec, ctx.B, ctx.S, ctx.stash, ctx.packed = spec, B, S, stash, packed.clone()
-            ctx.params = params
+            ctx.spec, ctx.B, ctx.S, ctx.stash, ctx.packed, ctx.packed_gen = spec, B, S, stash, packed, gen
+            ctx.params, ctx.model = params, model
+            if hasattr(model, "_cnerf_pending"):     # distributed.GradReducer counts this network's backward nodes
+                model._cnerf_pending += 1
         return raw
 
     @staticmethod
     def backward(ctx, g_raw):
         params = ctx.params
+        if not _packed_still_valid(ctx.model, ctx.packed_gen):
+            raise ops.CnerfError("the network's weights were updated twice between this forward pass and its backward "
+                                 "(the kernel-layout copy it used has been re-packed)")
         # Parameters owned by FusedAdam carry their .grad as a view into the flat gradient buffer: under loss.backward()
         # the wgrad reduction accumulates straight into it (what AccumulateGrad would do with ~50 add/copy launches per
         # step) and autograd gets no per-tensor gradients back.  Anything else — plain nn.Parameters, and
         # torch.autograd.grad() on FusedAdam-owned ones, where the engine captures gradients instead of accumulating them
         # — takes the tensor route and leaves the flat buffer untouched.
-        direct = all(ctx.needs_input_grad[8:]) and all(
-            getattr(p, "_cnerf_direct_grad", False) and p.grad is not None and p.grad.is_contiguous() for p in params) \
-            and _engine_accumulates(params[0])
+        direct = _direct_ok(ctx.needs_input_grad[8:], params) and _engine_accumulates(params[0])
+        pair = getattr(ctx, "pair", None)
+        nret = (None,) * (8 + len(params))
+        if direct and pair is not None and pair.fine() is ctx and pair.parked is None:
+            c = pair.coarse()
+            # park only when the coarse node is certain to run in this very pass, on the direct route as well
+            if (c is not None and c.stash is not None and _direct_ok(c.needs_input_grad[8:], c.params)
+                    and torch._C._will_engine_execute_node(c)):
+                pair.parked = (ctx.spec, ctx.packed, g_raw.contiguous(), ctx.B, ctx.S, ctx.stash, [p.grad for p in params],
+                               ctx.model)
+                ctx.stash = ctx.packed = ctx.params = ctx.model = None
+                return nret
+        parked = None
+        if pair is not None and pair.coarse() is ctx and pair.parked is not None:
+            parked, pair.parked = pair.parked, None
+        if parked is not None and direct:
+            fs, fp, fg, fB, fS, fst, fgr, fmodel = parked
+            ops.mlp_backward_pair(fs, fp, fg, fB, fS, fst, fgr, ctx.spec, ctx.packed, g_raw.contiguous(), ctx.B, ctx.S,
+                                  ctx.stash, [p.grad for p in params], accumulate=True)
+            _report_ready(fmodel, True)
+            _report_ready(ctx.model, True)
+            ctx.stash = ctx.packed = ctx.params = ctx.model = None
+            return nret
+        if parked is not None:        # (cannot happen — the fine node checked this node's route — but never drop a gradient)
+            fs, fp, fg, fB, fS, fst, fgr, fmodel = parked
+            ops.mlp_backward(fs, fp, fg, fB, fS, fst, grads=fgr, accumulate=True)
+            _report_ready(fmodel, True)
         out = [p.grad for p in params] if direct else None
         grads = ops.mlp_backward(ctx.spec, ctx.packed, g_raw.contiguous(), ctx.B, ctx.S, ctx.stash, grads=out,
                                  accumulate=direct)
-        ctx.stash = ctx.packed = ctx.params = None
-        return (None,) * 8 + ((None,) * len(params) if direct else tuple(grads))
+        _report_ready(ctx.model, direct)
+        ctx.stash = ctx.packed = ctx.params = ctx.model = None
+        return nret if direct else (None,) * 8 + tuple(grads)
 
 
 class _CompositeFn(torch.autograd.Function):
@@ -391,7 +473,9 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
         u = sample_u(N_rays, N_importance, perturb == 0., pytest, dev)
         z_vals, z_std = ops.resample(z_vals, weights, u)          # R:395-399 + R:415, no gradient (R:397)
         run_fn = network_fn if network_fine is None else network_fine
+        raw_coarse = raw
         raw = network_query_fn(RayPoints(rays, z_vals), viewdirs, run_fn)
+        _link_levels(raw_coarse, raw)
         noise = _density_noise((N_rays, N_samples + N_importance), raw_noise_std, pytest, dev)
         rgb_map, disp_map, acc_map, weights, depth_map = _CompositeFn.apply(raw, z_vals, rays, noise,
                                                                             bool(white_bkgd))

@@ -18,7 +18,32 @@ from . import ops
 from .ops import NetSpec
 
 # Misc (H:9-11)
-img2mse = lambda x, y: torch.mean((x - y) ** 2)  # noqa: E731
+class _MseFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y):
+        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        loss, d_x = ops.mse(x, y, need)
+        if need:
+            ctx.save_for_backward(d_x)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        d_x, = ctx.saved_tensors
+        gx = d_x * g
+        return (gx if ctx.needs_input_grad[0] else None), (-gx if ctx.needs_input_grad[1] else None)
+
+
+def img2mse(x, y):
+    """H:9 `torch.mean((x - y) ** 2)`.  Same-shape fp32 GPU tensors (every use on the hot path: [N_rays, 3] colours,
+    [N_rays] depths) take one fused kernel that also emits the gradient seed; anything else (broadcasting, other dtypes)
+    is the reference's expression on ATen's GPU kernels."""
+    if (torch.is_tensor(x) and torch.is_tensor(y) and x.is_cuda and y.is_cuda and x.shape == y.shape and x.numel() > 0
+            and x.dtype == torch.float32 and y.dtype == torch.float32):
+        return _MseFn.apply(x, y)
+    return torch.mean((x - y) ** 2)
+
+
 mse2psnr = lambda x: -10. * torch.log(x) / torch.log(torch.tensor([10.], device=x.device))  # noqa: E731
 to8b = lambda x: (255 * np.clip(x, 0, 1)).astype(np.uint8)  # noqa: E731
 

@@ -97,6 +97,25 @@ int64_t cnerf_mlp_bwd_ws_floats(const cnerf_net* net, int64_t M);
 int cnerf_mlp_bwd(const cnerf_net* net, const float* packed, const float* d_raw, int64_t B, int S,
                   const float* stash, float* workspace, const cnerf_ptrs* grads, int accumulate,
                   void* stream);
+/* Backward of TWO independent networks at once — the coarse and the fine network of a render_rays training step
+ * (run_nerf.py:311-421; the fine level's sample depths are detached, run_nerf.py:397, so the two backward passes share
+ * nothing once the forward is done): ONE activation-gradient grid (when both networks have the same architecture; two
+ * otherwise), ONE weight-gradient grid and ONE reduction for both, so the smaller level does not pay its own ramp and
+ * tail.  Results are identical to two cnerf_mlp_bwd calls.  The two gradient sets must be distinct tensors
+ * (CNERF_E_ARG otherwise: one network serving both levels, run_nerf.py:402, takes two cnerf_mlp_bwd calls).
+ * workspaceN = cnerf_mlp_bwd_ws_floats(netN, BN*SN) floats each. */
+int cnerf_mlp_bwd_pair(const cnerf_net* net0, const float* packed0, const float* d_raw0, int64_t B0, int S0,
+                       const float* stash0, float* workspace0, const cnerf_ptrs* grads0,
+                       const cnerf_net* net1, const float* packed1, const float* d_raw1, int64_t B1, int S1,
+                       const float* stash1, float* workspace1, const cnerf_ptrs* grads1, int accumulate, void* stream);
+/* Its two halves (cf. cnerf_mlp_dgrad / cnerf_mlp_wgrad). */
+int cnerf_mlp_dgrad_pair(const cnerf_net* net0, const float* packed0, const float* d_raw0, int64_t B0, int S0,
+                         const float* stash0, float* workspace0, const cnerf_net* net1, const float* packed1,
+                         const float* d_raw1, int64_t B1, int S1, const float* stash1, float* workspace1, void* stream);
+int cnerf_mlp_wgrad_pair(const cnerf_net* net0, int64_t B0, int S0, const float* stash0, float* workspace0,
+                         const cnerf_ptrs* grads0, const cnerf_net* net1, int64_t B1, int S1, const float* stash1,
+                         float* workspace1, const cnerf_ptrs* grads1, int accumulate, void* stream);
+
 /* The two halves of cnerf_mlp_bwd, separately launchable (same workspace): activation gradients
  * (fused dgrad chain, one wave per 32 points) and weight gradients (point-contracted GEMMs + reduction). */
 int cnerf_mlp_dgrad(const cnerf_net* net, const float* packed, const float* d_raw, int64_t B, int S,
@@ -195,6 +214,10 @@ int cnerf_warp_points(const float* P, int64_t N, const float* w2c_host, float fx
 int cnerf_hard_mask_pair(int H, int W, float fx, float fy, float cx, float cy, const float* c2w_tgt_host,
                          const float* w2c_ref_host, const float* depth_tgt, const float* depth_ref,
                          float thr0, int chunk, uint8_t* mask, float* thr_out, void* stream);
+
+/* img2mse (run_nerf_helpers.py:9): loss[0] = mean((x - y)^2) over n elements; d_x (nullable) = 2 (x - y) / n, the
+ * gradient of the loss w.r.t. x.  One launch, fixed summation order. */
+int cnerf_mse(const float* x, const float* y, int64_t n, float* loss, float* d_x, void* stream);
 
 /* ---- a14: masked photometric / depth losses  (V:1645-1648, V:1737, V:1786-1788, V:1865) --------- */
 /* loss[0] = mean_{m==1}(rgb-t)^2 + coef*mean_{m==0}(rgb-t)^2 (second term only if some m==0);

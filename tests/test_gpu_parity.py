@@ -1445,3 +1445,205 @@ def test_fused_adam_params_under_autograd_grad(dev):
     assert float((opt.flat_grad - flat_ref).abs().max()) <= 1e-6 * float(flat_ref.abs().max())
     loss_of().backward(inputs=params)                                 # accumulating backward with explicit inputs: direct too
     assert float((opt.flat_grad - 2 * flat_ref).abs().max()) <= 2e-6 * float(flat_ref.abs().max())
+
+
+DIST_GPU_WORKER = r"""
+import os, sys, tempfile, numpy as np, torch
+ROOT = sys.argv[1]
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import _inputs as I
+from test_gpu_parity import _view_args
+from consistentnerf_amd import distributed as D, run_nerf_view as V
+import torch.distributed as dist
+dev = torch.device("cuda:0")
+
+def run(use_dist):
+    with tempfile.TemporaryDirectory() as tmp:
+        args = _view_args(tmp)
+        kw, _, start, grad_vars, opt = V.create_nerf(args)
+    for net, seed in ((kw["network_fn"], 51), (kw["network_fine"], 52)):
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in I.nerf_state_dict(4, 128, 10, 4, 5, True, seed=seed, gain=0.6).items()})
+    kw.update(near=2.0, far=6.0)
+    opt.param_groups[0]["clip_value"] = 0.1
+    red = D.GradReducer(opt, [kw["network_fn"], kw["network_fine"]], mean=False, timing=True) if use_dist else None
+    K = I.intrinsics(100, 100, 138.0)
+    losses = []
+    for i in range(3):
+        rays = torch.from_numpy(I.ray_batch(256, seed=300 + i)).to(dev)
+        rs = np.random.RandomState(400 + i)
+        target = torch.from_numpy(rs.uniform(size=(256, 3)).astype(np.float32)).to(dev)
+        prior = torch.from_numpy(rs.uniform(2, 6, size=(256,)).astype(np.float32)).to(dev)
+        mask = torch.from_numpy((rs.uniform(size=(256,)) < 0.6).astype(np.float32)).to(dev)
+        rays, target, prior, mask = D.shard_batch(rays, target, prior, mask)      # this rank's rays (all of them at world 1)
+        counts = D.global_mask_counts(mask) if use_dist else None
+        rgb, disp, acc, depth, ex = V.render(100, 100, K, chunk=32768, rays=torch.stack([rays[:, 0:3], rays[:, 3:6]], 0),
+                                             retraw=True, pytest=True, **kw)
+        opt.zero_grad()
+        il, dl = V.hardmask_losses(rgb, target, mask, 0.2, depth, prior, 6.0, counts=counts)
+        il0, dl0 = V.hardmask_losses(ex["rgb0"], target, mask, 0.2, ex["depth0"], prior, 6.0, counts=counts)
+        loss = il + dl + il0 + dl0
+        loss.backward()
+        if use_dist:
+            red.finish()
+        opt.step()
+        losses.append(loss.item())
+    torch.cuda.synchronize()
+    return opt.flat_param.clone(), losses, (red.exposed_ms() if use_dist else None)
+
+p0, l0, _ = run(False)
+assert not dist.is_initialized()
+rank, world, local = D.init_from_env("nccl")            # CNERF_FORCE_DIST=1: a 1-rank RCCL group
+assert dist.is_initialized() and dist.get_backend() == "nccl" and world == 1
+p1, l1, ms = run(True)
+assert l0 == l1, (l0, l1)
+assert torch.equal(p0, p1), float((p0 - p1).abs().max())
+assert len(ms) == 3 and all(m >= 0 for m in ms)
+D.barrier()
+dist.destroy_process_group()
+print("DIST_GPU_OK", l1, ms)
+"""
+
+
+def test_forced_dist_world1_step_is_bit_identical(dev, tmp_path):
+    """The full product step of the data-parallel path — shard_batch -> global_mask_counts (RCCL) -> hardmask_losses(counts=)
+    -> backward (HIP kernels accumulate into FusedAdam.flat_grad) -> GradReducer (RCCL all-reduce of the per-network slices,
+    issued from _MlpFn.backward) -> FusedAdam(clip) — on a 1-rank `nccl` group (CNERF_FORCE_DIST=1), 3 steps: losses and
+    final parameters bit-identical to the same steps without a process group.  (World > 1 needs more than the one GPU of the
+    test box; the 2-rank logic runs under gloo in tests/test_host.py.)"""
+    import subprocess
+    import sys
+    script = tmp_path / "dist_gpu_worker.py"
+    script.write_text(DIST_GPU_WORKER)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CNERF_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29577", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script), root], capture_output=True, text=True, env=env, timeout=900)
+    print(r.stdout[-1500:])
+    assert r.returncode == 0 and "DIST_GPU_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("cfg0,cfg1,M0,M1", [((8, 256, True, 5), (8, 256, True, 5), 3 * 192, 3 * 64),
+                                             ((8, 256, True, 5), (4, 128, True, 5), 2 * 192 + 7, 1000),
+                                             ((4, 128, False, 5), (4, 128, False, 5), 33, 4097)])
+def test_bwd_pair_equals_two_separate_backwards(dev, cfg0, cfg1, M0, M1):
+    """cnerf_mlp_bwd_pair (one dgrad grid when the architectures match, one wgrad grid + one reduction always) against two
+    cnerf_mlp_bwd calls: bit-identical gradients, overwrite and accumulate, ragged point counts, mixed architectures."""
+    from consistentnerf_amd import ops
+    nets = []
+    for (D, W, vd, och), M, seed in ((cfg0, M0, 61), (cfg1, M1, 62)):
+        model, _ = make_model(D, W, vd, och, seed, dev)
+        spec = model.spec()
+        packed = ops.pack_weights(spec, model.kernel_tensors())
+        rs = np.random.RandomState(seed)
+        pts = T(rs.uniform(-2, 2, size=(M, 3)).astype(np.float32), dev)
+        dirs = T(rs.normal(size=(M, 3)).astype(np.float32), dev) if vd else None
+        raw, stash = ops.mlp_forward(spec, packed, M, 1, pts=pts, dirs=dirs, want_stash=True)
+        d_raw = T(rs.normal(size=tuple(raw.shape)).astype(np.float32), dev)
+        nets.append((spec, packed, d_raw, M, stash))
+    sep = [ops.mlp_backward(sp, pk, dr, M, 1, st) for sp, pk, dr, M, st in nets]
+    got = [[torch.full_like(g, 7.0) for g in gs] for gs in sep]
+    (s0, p0, d0, m0, st0), (s1, p1, d1, m1, st1) = nets
+    ops.mlp_backward_pair(s0, p0, d0, m0, 1, st0, got[0], s1, p1, d1, m1, 1, st1, got[1], accumulate=False)
+    for a, b in zip(got[0] + got[1], sep[0] + sep[1]):
+        assert torch.equal(a, b)
+    ops.mlp_backward_pair(s0, p0, d0, m0, 1, st0, got[0], s1, p1, d1, m1, 1, st1, got[1], accumulate=True)
+    for a, b in zip(got[0] + got[1], sep[0] + sep[1]):
+        assert torch.equal(a, b + b)
+    with pytest.raises(ops.CnerfError):      # one gradient set for both networks would race in the reduction
+        ops.mlp_backward_pair(s0, p0, d0, m0, 1, st0, got[0], s0, p0, d0, m0, 1, st0, got[0])
+
+
+def test_training_step_merges_the_two_levels_backward(dev):
+    """With both networks FusedAdam-owned, loss.backward() runs ONE dgrad and ONE wgrad launch for the coarse and the fine
+    level together (the fine node parks its inputs, the coarse node launches the pair); the flat gradient is bit-identical
+    to the unmerged route (CNERF_MERGE_BWD=0), also when only the fine level is in the loss (nothing is parked then), and
+    torch.autograd.grad still returns per-tensor gradients."""
+    from consistentnerf_amd import ops, run_nerf as R
+    from consistentnerf_amd.optim import FusedAdam
+    coarse, fine, rays = _c2(dev, 192)
+    kw = _kwargs(coarse, fine, 64, 128, 0.0, False, 0.0, False)
+    tgt = torch.rand(192, 3, device=dev)
+    opt = FusedAdam(list(coarse.parameters()) + list(fine.parameters()), lr=5e-4)
+
+    def run(merge, both=True):
+        old, R.MERGE_BWD = R.MERGE_BWD, merge
+        try:
+            ops.PROFILE = []
+            opt.zero_grad()
+            out = R.render_rays(rays, **kw)
+            loss = R.img2mse(out["rgb_map"], tgt) + (R.img2mse(out["rgb0"], tgt) if both else 0.0)
+            loss.backward()
+            kinds = [n for n, *_ in ops.PROFILE]
+        finally:
+            ops.PROFILE, R.MERGE_BWD = None, old
+        return opt.flat_grad.clone(), kinds
+    g_sep, k_sep = run(False)
+    g_mrg, k_mrg = run(True)
+    assert k_sep.count("mlp_dgrad") == 2 and k_sep.count("mlp_wgrad") == 2
+    assert k_mrg.count("mlp_dgrad") == 1 and k_mrg.count("mlp_wgrad") == 1
+    assert torch.equal(g_sep, g_mrg) and float(g_mrg.abs().max()) > 0
+    g1, k1 = run(True, both=False)            # the coarse node does not run: the fine node must not park
+    g2, k2 = run(False, both=False)
+    assert k1.count("mlp_dgrad") == 1 and torch.equal(g1, g2)
+    n_c = sum(p.numel() for p in coarse.parameters())
+    assert float(g1[:n_c].abs().max()) == 0.0 and float(g1[n_c:].abs().max()) > 0
+    params = [p for m in (coarse, fine) for p in m.kernel_tensors()]
+    opt.zero_grad()
+    out = R.render_rays(rays, **kw)
+    gs = torch.autograd.grad(R.img2mse(out["rgb_map"], tgt) + R.img2mse(out["rgb0"], tgt), params)
+    assert all(g is not None for g in gs) and float(opt.flat_grad.abs().max()) == 0.0
+    flat = torch.cat([(dict(zip(map(id, params), gs)).get(id(p), torch.zeros_like(p))).reshape(-1) for p in opt.params])
+    assert float((flat - g_mrg).abs().max()) <= 1e-6 * float(g_mrg.abs().max())
+
+
+def test_img2mse_fused_kernel(dev):
+    """img2mse (H:9) as one kernel: value and both gradients against ATen's expression, any shape; broadcasting inputs
+    take the reference's expression."""
+    from consistentnerf_amd import run_nerf as R
+    rs = np.random.RandomState(3)
+    for shape in ((4096, 3), (4096,), (7, 5, 3), (1,)):
+        x = T(rs.uniform(size=shape).astype(np.float32), dev).requires_grad_(True)
+        y = T(rs.uniform(size=shape).astype(np.float32), dev).requires_grad_(True)
+        l = R.img2mse(x, y)
+        (3.0 * l).backward()
+        xr, yr = x.detach().clone().requires_grad_(True), y.detach().clone().requires_grad_(True)
+        lr = torch.mean((xr - yr) ** 2)
+        (3.0 * lr).backward()
+        assert l.shape == lr.shape and abs(l.item() - lr.item()) <= 2e-7 * max(lr.item(), 1e-30) + 1e-12
+        check(x.grad, xr.grad, 1e-9, f"d img2mse / dx {shape}"); check(y.grad, yr.grad, 1e-9, f"d img2mse / dy {shape}")
+    a, b = torch.rand(5, 3, device=dev), torch.rand(3, device=dev)
+    assert torch.equal(R.img2mse(a, b), torch.mean((a - b) ** 2))
+
+
+def test_packed_weights_double_buffer(dev):
+    """The kernel-layout weights a forward pass used survive ONE parameter update before its backward (two buffers
+    alternate, no per-step clone); after two updates the backward refuses instead of differentiating through overwritten
+    weights (the reference fails there too: autograd's version check)."""
+    from consistentnerf_amd import ops, run_nerf as R
+    from consistentnerf_amd.optim import FusedAdam
+    coarse, _ = make_model(4, 128, True, 5, 93, dev)
+    fine, _ = make_model(4, 128, True, 5, 94, dev)
+    kw = _kwargs(coarse, fine, 16, 16, 0.0, False, 0.0, False)
+    rays, tgt = T(I.ray_batch(40, seed=4), dev), torch.rand(40, 3, device=dev)
+    opt = FusedAdam(list(coarse.parameters()) + list(fine.parameters()), lr=1e-2)
+
+    def fwd():
+        o = R.render_rays(rays, **kw)
+        return R.img2mse(o["rgb_map"], tgt) + R.img2mse(o["rgb0"], tgt)
+    opt.zero_grad()
+    fwd().backward()
+    ref = opt.flat_grad.clone()
+    l = fwd()                     # forward with the current weights ...
+    opt.step()                    # ... one update (re-packed into the OTHER buffer by the next forward) ...
+    with torch.no_grad():
+        R.render_rays(rays, **kw)
+    opt.zero_grad()
+    l.backward()                  # ... and the backward still sees the weights its forward used
+    assert torch.equal(opt.flat_grad, ref)
+    l = fwd()
+    for _ in range(2):
+        opt.step()
+        with torch.no_grad():
+            R.render_rays(rays, **kw)
+    with pytest.raises(ops.CnerfError):
+        l.backward()

@@ -119,6 +119,32 @@ fref = torch.cat([(x if x is not None else torch.zeros_like(p)).reshape(-1) for 
 err = (flat - fref).abs().max().item() / fref.abs().max().item()
 assert err < 1e-5, err
 t = torch.ones(3); D.allreduce_mean_(t); assert torch.allclose(t, torch.ones(3))
+# GradReducer: the flat gradient goes out in per-network slices as the networks' backward nodes finish
+class FakeOpt:                       # the two members of FusedAdam the reducer uses (FusedAdam itself needs a GPU)
+    def __init__(self, mods):
+        self.params = [p for m in mods for p in m.parameters()]
+        self.offs = np.cumsum([0] + [p.numel() for p in self.params]).tolist()
+        self.flat_grad = torch.zeros(self.offs[-1])
+        self.index = {id(p): i for i, p in enumerate(self.params)}
+    def slice_of(self, params):
+        idx = sorted(self.index[id(p)] for p in params)
+        assert idx == list(range(idx[0], idx[-1] + 1))
+        return self.offs[idx[0]], self.offs[idx[-1] + 1]
+mods = [torch.nn.Linear(5, 3), torch.nn.Linear(4, 2)]
+opt = FakeOpt(mods)
+for mean in (True, False):
+    red = D.GradReducer(opt, mods, mean=mean)
+    assert red.bytes_per_step == 4 * opt.offs[-1] and [red.slices[id(m)] for m in mods] == [(0, 18), (18, 28)]
+    mine = torch.arange(28, dtype=torch.float32) * (rank + 1)
+    opt.flat_grad.copy_(mine)
+    mods[1]._cnerf_pending = 2                     # a network with two backward nodes reports after the second one
+    import consistentnerf_amd.run_nerf as RN
+    RN._report_ready(mods[1], True); assert not red._done
+    RN._report_ready(mods[1], True); assert red._done == {id(mods[1])}     # fine-first order; mods[0] never reports
+    red.finish()
+    want = torch.arange(28, dtype=torch.float32) * sum(r + 1 for r in range(world)) * ((1.0 / world) if mean else 1.0)
+    assert torch.allclose(opt.flat_grad, want), (opt.flat_grad, want)
+    assert not red._works and not red._done and mods[1]._cnerf_pending == 0
 D.barrier()
 if rank == 0: print("DIST_OK", world, err)
 dist.destroy_process_group()
