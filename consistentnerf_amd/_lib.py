@@ -30,6 +30,13 @@ class RenderCfg(C.Structure):
                 ("ray_stride", C.c_int32), ("train", C.c_int32)]
 
 
+class RayGen(C.Structure):
+    """struct cnerf_raygen"""
+    _fields_ = [("H", C.c_int32), ("W", C.c_int32), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("c2w", C.c_float * 12), ("near", C.c_float), ("far", C.c_float), ("use_viewdirs", C.c_int32),
+                ("ndc", C.c_int32), ("ndc_ax", C.c_float), ("ndc_ay", C.c_float), ("first", C.c_int64)]
+
+
 class RenderOut(C.Structure):
     """struct cnerf_render_out"""
     _fields_ = [(n, C.c_void_p) for n in ("rgb_map", "disp_map", "acc_map", "depth_map", "rgb0", "disp0", "acc0",
@@ -73,6 +80,8 @@ SIGNATURES = {
     "cnerf_render_ws_floats": (_i64, [_NetP, _NetP, C.POINTER(RenderCfg), _i64]),
     "cnerf_render_fwd": (_i, [_NetP, _vp, _NetP, _vp, _vp, _i64, C.POINTER(RenderCfg), _vp, _vp, _vp, _i64, _vp, _vp,
                               C.POINTER(RenderOut), _vp, _vp]),
+    "cnerf_render_fwd_cam": (_i, [_NetP, _vp, _NetP, _vp, C.POINTER(RayGen), _i64, C.POINTER(RenderCfg), _vp, _vp, _vp, _i64, _vp,
+                                  _vp, C.POINTER(RenderOut), _vp, _vp]),
     "cnerf_render_bwd": (_i, [_NetP, _vp, _NetP, _vp, _vp, _i64, C.POINTER(RenderCfg), _vp, _vp, C.POINTER(RenderGrads),
                               _vp, _PtrsP, _PtrsP, _i, _vp]),
     "cnerf_gen_rays": (_i, [_i, _i, _f, _f, _f, _f, C.POINTER(_f), _f, _f, _i, _i, _f, _f, _vp, _vp]),

@@ -3,7 +3,7 @@
 // transmittance product is a lane-local sequential product + one wave scan, carried in fp64 and
 // rounded to fp32 per sample (the CPU reference's cumprod accumulates fp32 inputs in fp64).
 // HBM-bound: 24 B per ray-sample forward (raw 16 + z 4 in, weights 4 out), 40 B backward.
-#include "common.hpp"
+#include "raygen.hpp"
 
 namespace {
 
@@ -87,14 +87,22 @@ __global__ __launch_bounds__(WAVES * 64) void composite_fwd_k(const float* __res
                                                               const float* __restrict__ noise, int64_t B, int S,
                                                               int white, float* __restrict__ rgb,
                                                               float* __restrict__ disp, float* __restrict__ acc,
-                                                              float* __restrict__ depth, float* __restrict__ weights) {
+                                                              float* __restrict__ depth, float* __restrict__ weights,
+                                                              RayGenDev cam) {
   const int lane = threadIdx.x & 63;
   const int64_t b = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
   if (b >= B) return;
   Sample sm[C];
   float T[C];
-  load_samples<C>(sm, raw + b * S * ch, ch, z + b * S, noise ? noise + b * S : nullptr, ray_norm(rays + b * rs), S,
-                  lane);
+  float dn;
+  if (rays != nullptr) {
+    dn = ray_norm(rays + b * rs);
+  } else {   // the ray of a camera, generated here (raygen.hpp): R:280-283 scales the sample distances by |rays_d|
+    float o[3], d[3], v[3];
+    cn_gen_ray(cam, cam.first + b, o, d, v);
+    dn = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  }
+  load_samples<C>(sm, raw + b * S * ch, ch, z + b * S, noise ? noise + b * S : nullptr, dn, S, lane);
   transmittance<C>(sm, T, lane);
   double sr = 0, sg = 0, sb = 0, sd = 0, sa = 0;
 #pragma unroll
@@ -223,7 +231,22 @@ extern "C" int cnerf_composite_fwd(const float* raw, int raw_ch, const float* z,
     constexpr int C = decltype(c)::value;
     hipLaunchKernelGGL((composite_fwd_k<C>), dim3((unsigned)cn_div_up(B, WAVES)), dim3(WAVES * 64), 0,
                        cn_stream(stream), raw, raw_ch, z, rays, ray_stride, noise, B, S, white_bkgd, rgb, disp, acc,
-                       depth, weights);
+                       depth, weights, cn_no_raygen());
+    CN_CHECK_LAUNCH();
+    return CNERF_OK;
+  });
+}
+
+// compositing for the rays of a camera generated in-kernel; used by cnerf_render_fwd_cam
+int cn_composite_fwd_cam(const float* raw, int raw_ch, const float* z, const RayGenDev& cam, const float* noise, int64_t B,
+                         int S, int white_bkgd, float* rgb, float* disp, float* acc, float* depth, float* weights,
+                         hipStream_t st) {
+  if (!raw || !z || B < 0 || S <= 0 || raw_ch < 4) return CNERF_E_ARG;
+  if (B == 0) return CNERF_OK;
+  return dispatch_c(S, [&](auto c) -> int {
+    constexpr int C = decltype(c)::value;
+    hipLaunchKernelGGL((composite_fwd_k<C>), dim3((unsigned)cn_div_up(B, WAVES)), dim3(WAVES * 64), 0, st, raw, raw_ch, z,
+                       (const float*)nullptr, 0, noise, B, S, white_bkgd, rgb, disp, acc, depth, weights, cam);
     CN_CHECK_LAUNCH();
     return CNERF_OK;
   });

@@ -14,6 +14,7 @@
 // run (the tile is that GEMM's B operand, it stays live), plus 1 bit per hidden unit (ReLU sign) for the backward.
 // MFMA-bound by construction: 593 920 MAC per point at D=8/W=256 incl. K padding.
 #include "mlp_common.hpp"
+#include "raygen.hpp"
 
 namespace {
 
@@ -29,6 +30,7 @@ struct FwdArgs {
   float* stash;
   int64_t M, Mp;
   int S, rs;
+  RayGenDev cam;      // cam.on: the rays are those of a camera, generated here (rays == nullptr)
 };
 
 // gamma(v) of this lane's point into the LDS tile T[m][0..chp): half-wave hh takes the frequencies l = hh, hh+2, ...
@@ -100,12 +102,17 @@ __global__ __launch_bounds__(64) void mlp_fwd_k(FwdArgs args_by_value) {
   if (pre == nullptr) {
     if (a.pts != nullptr) {
       x[0] = a.pts[pc * 3 + 0]; x[1] = a.pts[pc * 3 + 1]; x[2] = a.pts[pc * 3 + 2];
+    } else if (a.cam.on) {   // rays of a camera: generated per point (a few dozen flops next to 600 k MACs)
+      float o[3], d[3];
+      cn_gen_ray(a.cam, a.cam.first + ray, o, d, v);
+      const float zz = a.z[pc];
+      x[0] = o[0] + d[0] * zz; x[1] = o[1] + d[1] * zz; x[2] = o[2] + d[2] * zz;   // R:384 (no FMA contraction)
     } else {
       const float* r = a.rays + ray * a.rs;
       const float zz = a.z[pc];
       x[0] = r[0] + r[3] * zz; x[1] = r[1] + r[4] * zz; x[2] = r[2] + r[5] * zz;   // R:384 (no FMA contraction)
     }
-    if (VD) {
+    if (VD && !(a.pts == nullptr && a.cam.on)) {
       const float* dsrc = a.dirs != nullptr ? a.dirs + ray * 3 : a.rays + ray * a.rs + (a.rs - 3);
       v[0] = dsrc[0]; v[1] = dsrc[1]; v[2] = dsrc[2];
     }
@@ -314,6 +321,22 @@ extern "C" int cnerf_mlp_fwd(const cnerf_net* net, const float* packed, const fl
   a.packed = packed; a.pts = pts; a.rays = rays; a.dirs = dirs; a.z = z; a.emb = nullptr; a.raw = raw;
   a.stash = stash;
   a.M = B * S; a.Mp = cn_round_up(a.M, 32); a.S = S; a.rs = ray_stride;
+  a.cam = cn_no_raygen();
+  return dispatch(a, stream);
+}
+
+// the fused encoding + MLP on the rays of a camera generated in-kernel (inference); used by cnerf_render_fwd_cam
+int cn_mlp_fwd_cam(const cnerf_net* net, const float* packed, const RayGenDev& cam, const float* z, int64_t B, int S,
+                   float* raw, void* stream) {
+  FwdArgs a;
+  int rc = cn_make_geom(net, &a.g);
+  if (rc) return rc;
+  if (!packed || !raw || !z || B < 0 || S <= 0 || (a.g.viewdirs && !cam.vd)) return CNERF_E_ARG;
+  if (B == 0) return CNERF_OK;
+  a.packed = packed; a.pts = nullptr; a.rays = nullptr; a.dirs = nullptr; a.z = z; a.emb = nullptr; a.raw = raw;
+  a.stash = nullptr;
+  a.M = B * S; a.Mp = cn_round_up(a.M, 32); a.S = S; a.rs = 0;
+  a.cam = cam;
   return dispatch(a, stream);
 }
 
@@ -327,5 +350,6 @@ extern "C" int cnerf_mlp_fwd_embedded(const cnerf_net* net, const float* packed,
   a.packed = packed; a.pts = nullptr; a.rays = nullptr; a.dirs = nullptr; a.z = nullptr; a.emb = x_embedded;
   a.raw = raw; a.stash = stash;
   a.M = M; a.Mp = cn_round_up(M, 32); a.S = 1; a.rs = 0;
+  a.cam = cn_no_raygen();
   return dispatch(a, stream);
 }

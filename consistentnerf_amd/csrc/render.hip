@@ -4,7 +4,15 @@
 // and backwards  composite_bwd -> dgrad -> wgrad  per level (no gradient through the resampling, R:397).
 // Host code only: every launch goes through the public entry points of this library, on the caller's stream, inside
 // the caller's workspace; nothing is allocated and nothing synchronises.
-#include "common.hpp"
+#include "raygen.hpp"
+
+int cn_coarse_z_cam(float near, float far, int64_t B, int Nc, const float* t_vals, const float* t_rand, int lindisp,
+                    float* z, hipStream_t st);
+int cn_composite_fwd_cam(const float* raw, int raw_ch, const float* z, const RayGenDev& cam, const float* noise, int64_t B,
+                         int S, int white_bkgd, float* rgb, float* disp, float* acc, float* depth, float* weights,
+                         hipStream_t st);
+int cn_mlp_fwd_cam(const cnerf_net* net, const float* packed, const RayGenDev& cam, const float* z, int64_t B, int S,
+                   float* raw, void* stream);
 
 namespace {
 
@@ -96,6 +104,55 @@ extern "C" int cnerf_render_fwd(const cnerf_net* coarse, const float* packed_coa
   }
   // optional copies of the last level's per-sample tensors (retraw, R:412)
   hipStream_t st = cn_stream(stream);
+  if (out->raw && hipMemcpyAsync(out->raw, raw_last, (size_t)B * S_last * C_last * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+    return (int)hipGetLastError();
+  if (out->z_vals && hipMemcpyAsync(out->z_vals, z_last, (size_t)B * S_last * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+    return (int)hipGetLastError();
+  if (out->weights && hipMemcpyAsync(out->weights, w_last, (size_t)B * S_last * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+    return (int)hipGetLastError();
+  return CNERF_OK;
+}
+
+extern "C" int cnerf_render_fwd_cam(const cnerf_net* coarse, const float* packed_coarse, const cnerf_net* fine,
+                                    const float* packed_fine, const cnerf_raygen* cam_in, int64_t B,
+                                    const cnerf_render_cfg* cfg_in, const float* t_vals, const float* t_rand, const float* u,
+                                    int64_t u_row_stride, const float* noise0, const float* noise1,
+                                    const cnerf_render_out* out, float* workspace, void* stream) {
+  if (!cfg_in || cfg_in->train) return CNERF_E_ARG;
+  cnerf_render_cfg cfg = *cfg_in;
+  cfg.ray_stride = 11;
+  RayGenDev cam;
+  int rc = cn_make_raygen(cam_in, &cam);
+  if (rc) return rc;
+  if (cam.first + B > (int64_t)cam_in->H * cam_in->W) return CNERF_E_ARG;
+  Layout L;
+  if ((rc = make_layout(coarse, fine, &cfg, B, &L))) return rc;
+  if (!packed_coarse || !t_vals || !out || !workspace || (fine && !packed_fine) || (cfg.Nf > 0 && !u)) return CNERF_E_ARG;
+  if (B == 0) return CNERF_OK;
+  float* ws = workspace;
+  hipStream_t st = cn_stream(stream);
+  const int Nc = cfg.Nc;
+  const bool two = cfg.Nf > 0;
+  if ((rc = cn_coarse_z_cam(cam.near, cam.far, B, Nc, t_vals, t_rand, cfg.lindisp, ws + L.z0, st))) return rc;
+  if ((rc = cn_mlp_fwd_cam(coarse, packed_coarse, cam, ws + L.z0, B, Nc, ws + L.raw0, stream))) return rc;
+  if ((rc = cn_composite_fwd_cam(ws + L.raw0, L.C0, ws + L.z0, cam, noise0, B, Nc, cfg.white_bkgd,
+                                 two ? out->rgb0 : out->rgb_map, two ? out->disp0 : out->disp_map,
+                                 two ? out->acc0 : out->acc_map, two ? out->depth0 : out->depth_map, ws + L.w0, st)))
+    return rc;
+  const float *z_last = ws + L.z0, *raw_last = ws + L.raw0, *w_last = ws + L.w0;
+  int S_last = Nc, C_last = L.C0;
+  if (two) {
+    const cnerf_net* n1 = fine ? fine : coarse;
+    const float* p1 = fine ? packed_fine : packed_coarse;
+    if ((rc = cnerf_resample(ws + L.z0, ws + L.w0, u, u_row_stride, B, Nc, cfg.Nf, ws + L.z1, out->z_std, nullptr,
+                             nullptr, stream)))
+      return rc;
+    if ((rc = cn_mlp_fwd_cam(n1, p1, cam, ws + L.z1, B, L.S1, ws + L.raw1, stream))) return rc;
+    if ((rc = cn_composite_fwd_cam(ws + L.raw1, L.C1, ws + L.z1, cam, noise1, B, L.S1, cfg.white_bkgd, out->rgb_map,
+                                   out->disp_map, out->acc_map, out->depth_map, ws + L.w1, st)))
+      return rc;
+    z_last = ws + L.z1; raw_last = ws + L.raw1; w_last = ws + L.w1; S_last = L.S1; C_last = L.C1;
+  }
   if (out->raw && hipMemcpyAsync(out->raw, raw_last, (size_t)B * S_last * C_last * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
     return (int)hipGetLastError();
   if (out->z_vals && hipMemcpyAsync(out->z_vals, z_last, (size_t)B * S_last * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)

@@ -16,12 +16,13 @@ __device__ __forceinline__ float zlin(float near, float far, float t, int lindis
 
 __global__ void coarse_z_k(const float* __restrict__ rays, int rs, int64_t B, int Nc,
                            const float* __restrict__ t_vals, const float* __restrict__ t_rand, int lindisp,
-                           float* __restrict__ z) {
+                           float* __restrict__ z, float cam_near, float cam_far) {
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= B * Nc) return;
   int64_t b = idx / Nc;
   int i = (int)(idx - b * Nc);
-  float near = rays[b * rs + 6], far = rays[b * rs + 7];
+  // (rays == nullptr: the rays of a camera, generated in the consumers — near / far are the camera's constants)
+  float near = rays ? rays[b * rs + 6] : cam_near, far = rays ? rays[b * rs + 7] : cam_far;
   float zi = zlin(near, far, t_vals[i], lindisp);
   if (t_rand != nullptr) {
     float lower, upper;
@@ -199,7 +200,19 @@ extern "C" int cnerf_coarse_z(const float* rays, int ray_stride, int64_t B, int 
   if (B == 0) return CNERF_OK;
   int64_t n = B * Nc;
   hipLaunchKernelGGL(coarse_z_k, dim3((unsigned)cn_div_up(n, 256)), dim3(256), 0, cn_stream(stream), rays, ray_stride,
-                     B, Nc, t_vals, t_rand, lindisp, z);
+                     B, Nc, t_vals, t_rand, lindisp, z, 0.f, 0.f);
+  CN_CHECK_LAUNCH();
+  return CNERF_OK;
+}
+
+// coarse depths for the rays of a camera (near / far are its constants); used by cnerf_render_fwd_cam
+int cn_coarse_z_cam(float near, float far, int64_t B, int Nc, const float* t_vals, const float* t_rand, int lindisp,
+                    float* z, hipStream_t st) {
+  if (!t_vals || !z || B < 0 || Nc <= 0) return CNERF_E_ARG;
+  if (B == 0) return CNERF_OK;
+  int64_t n = B * Nc;
+  hipLaunchKernelGGL(coarse_z_k, dim3((unsigned)cn_div_up(n, 256)), dim3(256), 0, st, (const float*)nullptr, 0, B, Nc,
+                     t_vals, t_rand, lindisp, z, near, far);
   CN_CHECK_LAUNCH();
   return CNERF_OK;
 }

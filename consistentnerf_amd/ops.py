@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import CnerfError, Net, Ptrs, RenderCfg, RenderGrads, RenderOut
+from ._lib import CnerfError, Net, Ptrs, RayGen, RenderCfg, RenderGrads, RenderOut
 
 Tensor = torch.Tensor
 
@@ -287,6 +287,44 @@ def render_forward(spec_c: NetSpec, packed_c: Tensor, spec_f: Optional[NetSpec],
     st = RenderState(spec_c=spec_c, packed_c=packed_c, spec_f=spec_f, packed_f=packed_f, rays=rays, B=B, cfg=cfg,
                      noise0=noise0, noise1=noise1, ws=ws)
     return o, st
+
+
+def render_forward_cam(spec_c: NetSpec, packed_c: Tensor, spec_f: Optional[NetSpec], packed_f: Optional[Tensor], H: int, W: int,
+                       K, c2w, near: float, far: float, use_viewdirs: bool, ndc: bool, ndc_coef, first: int, B: int, Nc: int,
+                       Nf: int, t_rand: Optional[Tensor] = None, u: Optional[Tensor] = None, noise0: Optional[Tensor] = None,
+                       noise1: Optional[Tensor] = None, lindisp: bool = False, white_bkgd: bool = False, retraw: bool = False):
+    """cnerf_render_fwd_cam: render_rays (inference) of the image chunk [first, first + B) of a camera whose rays are
+    generated inside the kernels — no [H*W, 11] ray tensor.  Returns the dict of cnerf_render_fwd."""
+    lib = _lib.load()
+    t_rand, u, noise0, noise1 = _chk(t_rand, "t_rand"), _chk(u, "u"), _chk(noise0, "noise0"), _chk(noise1, "noise1")
+    dev = packed_c.device
+    cfg = RenderCfg(int(Nc), int(Nf), int(lindisp), int(white_bkgd), 11, 0)
+    nc, nf = spec_c.c(), (spec_f.c() if spec_f is not None else None)
+    nfp = C.byref(nf) if nf is not None else None
+    n = lib.cnerf_render_ws_floats(C.byref(nc), nfp, C.byref(cfg), B)
+    if n < 0:
+        raise CnerfError("cnerf_render_ws_floats: inconsistent arguments")
+    ws = torch.empty(n, device=dev, dtype=torch.float32)
+    if isinstance(c2w, torch.Tensor):
+        c2w = c2w.detach().cpu().numpy()
+    cam = RayGen(int(H), int(W), float(K[0][0]), float(K[1][1]), float(K[0][2]), float(K[1][2]), _f4(c2w), float(near),
+                 float(far), int(use_viewdirs), int(ndc), float(ndc_coef[0]), float(ndc_coef[1]), int(first))
+    S = Nc + Nf
+    ch = (spec_f if (spec_f is not None and Nf > 0) else spec_c).raw_ch
+    o = {k: torch.empty(B, 3, device=dev) if k.startswith("rgb") else torch.empty(B, device=dev)
+         for k in ("rgb_map", "disp_map", "acc_map", "depth_map")}
+    if Nf > 0:
+        o.update({k: torch.empty(B, 3, device=dev) if k.startswith("rgb") else torch.empty(B, device=dev)
+                  for k in ("rgb0", "disp0", "acc0", "depth0", "z_std")})
+    if retraw:
+        o["raw"] = torch.empty(B, S, ch, device=dev)
+    out = RenderOut(**{k: v.data_ptr() for k, v in o.items()})
+    stride = 0 if (u is None or u.dim() == 1 or u.shape[0] == 1) else Nf
+    with _timed("render_fwd_cam", B * (Nc + (S if Nf > 0 else 0))):
+        _lib.check(lib.cnerf_render_fwd_cam(C.byref(nc), _p(packed_c), nfp, _p(packed_f), C.byref(cam), B, C.byref(cfg),
+                                            _p(_t_vals(Nc, dev)), _p(t_rand), _p(u), stride, _p(noise0), _p(noise1),
+                                            C.byref(out), _p(ws), _stream()), "cnerf_render_fwd_cam")
+    return o
 
 
 def render_backward(st: RenderState, grads_in: dict, grads_c: List[Tensor], grads_f: Optional[List[Tensor]],

@@ -310,9 +310,65 @@ def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far
     return _render(H, W, K, chunk, rays, c2w, ndc, near, far, use_viewdirs, c2w_staticcam, False, kwargs)
 
 
+def _camera_path_ok(rays, c2w, near, far, use_viewdirs, c2w_staticcam, kwargs):
+    """render(c2w=...) of a whole image for inference can generate its rays inside the kernels (cnerf_render_fwd_cam):
+    that needs the stock network_query_fn of create_nerf (the kernels ARE that query), scalar near / far, no static
+    camera, and no autograd graph to build."""
+    net, fine = kwargs.get("network_fn"), kwargs.get("network_fine")
+    if rays is not None or c2w is None or c2w_staticcam is not None or torch.is_tensor(near) or torch.is_tensor(far):
+        return False
+    if not getattr(kwargs.get("network_query_fn"), "_cnerf_stock", False) or not isinstance(net, NeRF):
+        return False
+    if fine is not None and not isinstance(fine, NeRF):
+        return False
+    if kwargs.get("verbose") and DEBUG:
+        return False
+    nets = [net] + ([fine] if fine is not None else [])
+    if any(bool(n.use_viewdirs) != bool(use_viewdirs) for n in nets):
+        return False
+    return not (torch.is_grad_enabled() and any(p.requires_grad for n in nets for p in n.parameters()))
+
+
+def _render_camera(H, W, K, chunk, c2w, ndc, near, far, use_viewdirs, with_depth, kwargs):
+    """batchify_rays (R:55-67) + render_rays (R:311-421) over the image of one camera, rays generated in-kernel: one C
+    call per chunk, the same random streams in the same order as the ray-tensor path (bit-identical results)."""
+    net, fine = kwargs["network_fn"], kwargs.get("network_fine")
+    Nc, Nf = kwargs["N_samples"], kwargs.get("N_importance", 0)
+    perturb, pytest = kwargs.get("perturb", 0.), kwargs.get("pytest", False)
+    std, dev = kwargs.get("raw_noise_std", 0.), next(net.parameters()).device
+    coef = ndc_coefficients(H, W, K[0][0]) if ndc else (0., 0.)
+    two_nets = fine is not None and Nf > 0
+    all_ret = {}
+    for first in range(0, H * W, chunk):
+        B = min(chunk, H * W - first)
+        t_rand = None
+        if perturb > 0.:
+            t_rand = pytest_uniform((B, Nc), dev) if pytest else torch.rand(B, Nc, device=dev)
+        noise0 = _density_noise((B, Nc), std, pytest, dev)
+        u = sample_u(B, Nf, perturb == 0., pytest, dev) if Nf > 0 else None
+        noise1 = _density_noise((B, Nc + Nf), std, pytest, dev) if Nf > 0 else None
+        o = ops.render_forward_cam(net.spec(), _packed(net), fine.spec() if two_nets else None,
+                                   _packed(fine) if two_nets else None, H, W, K, c2w, near, far, use_viewdirs, ndc, coef, first,
+                                   B, Nc, Nf, t_rand, u, noise0, noise1, bool(kwargs.get("lindisp", False)),
+                                   bool(kwargs.get("white_bkgd", False)), bool(kwargs.get("retraw", False)))
+        if not with_depth:
+            o.pop("depth_map", None)
+            o.pop("depth0", None)
+        for k, v in o.items():
+            all_ret.setdefault(k, []).append(v)
+    return {k: (v[0] if len(v) == 1 else torch.cat(v, 0)) for k, v in all_ret.items()}
+
+
 def _render(H, W, K, chunk, rays, c2w, ndc, near, far, use_viewdirs, c2w_staticcam, with_depth, kwargs):
     net = kwargs.get("network_fn")
     device = next(net.parameters()).device if net is not None else _default_device()
+    if _camera_path_ok(rays, c2w, near, far, use_viewdirs, c2w_staticcam, kwargs):
+        kw = {k: v for k, v in kwargs.items()}
+        all_ret = _render_camera(H, W, K, chunk, c2w, ndc, near, far, use_viewdirs, with_depth, kw)
+        for k in all_ret:
+            all_ret[k] = torch.reshape(all_ret[k], [H, W] + list(all_ret[k].shape[1:]))
+        k_extract = ['rgb_map', 'disp_map', 'acc_map'] + (['depth_map'] if with_depth else [])
+        return [all_ret[k] for k in k_extract] + [{k: all_ret[k] for k in all_ret if k not in k_extract}]
     batch, sh = _ray_batch(H, W, K, rays, c2w, ndc, near, far, use_viewdirs, c2w_staticcam, device)
     all_ret = batchify_rays(batch, chunk, _with_depth=with_depth, **kwargs)
     for k in all_ret:
@@ -399,6 +455,7 @@ def _create_nerf(args, model_cls, view_variant):
         return run_network(inputs, viewdirs, network_fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn,
                            netchunk=args.netchunk)
 
+    network_query_fn._cnerf_stock = True     # render(c2w=...) may replace it by the single-call camera path
     optimizer = FusedAdam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999))
     start = 0
     basedir, expname = args.basedir, args.expname

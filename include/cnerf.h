@@ -156,6 +156,20 @@ int cnerf_resample(const float* z, const float* weights, const float* u, int64_t
  * Randomness stays the caller's: t_rand[B,Nc] (NULL: no jitter), u[B,Nf] (row stride 0 broadcasts one row),
  * noise0[B,Nc] / noise1[B,Nc+Nf] already scaled by raw_noise_std (NULL: none); t_vals[Nc] = linspace(0,1,Nc).
  * fine == NULL with Nf > 0 evaluates the second level with the coarse network (R:402) and its gradients add up. */
+/* A pinhole camera whose rays are generated inside the kernels that consume them (get_rays run_nerf_helpers.py:164-173,
+ * viewdirs = d/|d| of the pre-NDC direction run_nerf.py:103-110, ndc_rays run_nerf_helpers.py:186-202 with near plane 1):
+ * ray i of a call is pixel (first + i) of the H x W image, row-major.  What render(c2w=...) (run_nerf.py:97-101) and
+ * render_path (run_nerf.py:140-178) feed the renderer, without the [H*W, 11] ray tensor in HBM. */
+typedef struct cnerf_raygen {
+  int32_t H, W;
+  float fx, fy, cx, cy;        /* K[0][0], K[1][1], K[0][2], K[1][2]                                   */
+  float c2w[12];               /* camera-to-world [3,4], row-major                                      */
+  float near, far;
+  int32_t use_viewdirs, ndc;
+  float ndc_ax, ndc_ay;        /* -1/(W/(2 focal)), -1/(H/(2 focal)) (run_nerf_helpers.py:193-199)      */
+  int64_t first;
+} cnerf_raygen;
+
 typedef struct cnerf_render_cfg {
   int32_t Nc, Nf;        /* N_samples, N_importance                                      */
   int32_t lindisp;       /* sample linearly in inverse depth (R:362-364)                  */
@@ -184,6 +198,15 @@ int cnerf_render_bwd(const cnerf_net* coarse, const float* packed_coarse, const 
                      const float* packed_fine, const float* rays, int64_t B, const cnerf_render_cfg* cfg,
                      const float* noise0, const float* noise1, const cnerf_render_grads* g, float* workspace,
                      const cnerf_ptrs* grads_coarse, const cnerf_ptrs* grads_fine, int accumulate, void* stream);
+
+/* cnerf_render_fwd for the rays of a camera generated in-kernel: the chunk [cam->first, cam->first + B) of the image.
+ * Inference (cfg->train must be 0; cfg->ray_stride is ignored: viewdirs per cam->use_viewdirs).  Same workspace size
+ * (cnerf_render_ws_floats with ray_stride 11) and bit-identical outputs to cnerf_gen_rays + cnerf_render_fwd. */
+int cnerf_render_fwd_cam(const cnerf_net* coarse, const float* packed_coarse, const cnerf_net* fine,
+                         const float* packed_fine, const cnerf_raygen* cam, int64_t B, const cnerf_render_cfg* cfg,
+                         const float* t_vals, const float* t_rand, const float* u, int64_t u_row_stride,
+                         const float* noise0, const float* noise1, const cnerf_render_out* out, float* workspace,
+                         void* stream);
 
 /* ---- a1: ray generation  (get_rays H:164-173, ndc_rays H:186-202, render R:100-125) ------------- */
 /* Builds rays[H*W, 8|11] = o, d, near, far, (viewdirs) for a full image from c2w[3,4] (12 floats,

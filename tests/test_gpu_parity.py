@@ -1647,3 +1647,125 @@ def test_packed_weights_double_buffer(dev):
             R.render_rays(rays, **kw)
     with pytest.raises(ops.CnerfError):
         l.backward()
+
+
+# ------------------------------------------------------------------------------------------------
+# round 2: BASELINE configs[4] (C5) and configs[2] (C3) at FULL size, through size-independent properties
+def test_c5_full_frame_properties(dev):
+    """One 756x1008 NDC frame (C5: 762 048 rays x (64 + 192) samples, D=8/W=256, perturb 0) through render(c2w=...):
+    finite, chunk-invariant (R:79-80) bit for bit, and equal to the frame assembled from a 3-way row split through
+    render(rays=...) (what three ranks of distributed.render_path_sharded compute)."""
+    from consistentnerf_amd import distributed as D, run_nerf as R
+    from consistentnerf_amd.run_nerf_helpers import get_rays
+    H, W, focal = 756, 1008, 815.0
+    coarse, fine, _ = _c2(dev, 1)
+    kw = _kwargs(coarse, fine, 64, 128, 0.0, False, 0.0, False)
+    kw.pop("lindisp")
+    kw.update(ndc=True, near=0.0, far=1.0, use_viewdirs=True)
+    K = I.intrinsics(H, W, focal)
+    c2w = T(I.camera_pose(5.0, 0.0, 4.0), dev)
+    with torch.no_grad():
+        rgb, disp, acc, ex = R.render(H, W, K, chunk=32768, c2w=c2w, **kw)
+        rgb2, disp2, acc2, _ = R.render(H, W, K, chunk=131072, c2w=c2w, **kw)
+    assert rgb.shape == (H, W, 3) and disp.shape == (H, W)
+    assert torch.isfinite(rgb).all() and torch.isfinite(acc).all() and float(rgb.min()) >= 0.0 and float(rgb.max()) <= 1.0
+    assert float(acc.min()) >= 0.0 and float(acc.max()) <= 1.0 + 1e-5
+    assert torch.equal(rgb, rgb2) and torch.equal(acc, acc2) and torch.equal(torch.nan_to_num(disp), torch.nan_to_num(disp2))
+    assert float(rgb.std()) > 1e-3, "a random-init net still has to produce a non-constant image"
+    ro, rd = get_rays(H, W, K, c2w[:3, :4])
+    parts = []
+    for r in range(3):
+        lo, hi, idx = D.row_block(H, r, 3)
+        with torch.no_grad():
+            out = R.render(H, W, K, chunk=32768, rays=torch.stack([ro[idx.to(dev)], rd[idx.to(dev)]], 0), **kw)
+        parts.append(out[0][:hi - lo])
+    assert torch.equal(torch.cat(parts, 0), rgb)
+
+
+def test_c3_full_step_is_additive_over_half_batches(dev):
+    """The C3 training step at full size (5120 rays, 64 + 128 samples, D=8/W=256: hard-mask rgb + depth losses on both
+    levels + the monocular patch term on the first 4 x 256 rays, through FusedAdam's flat gradient): the gradient of the
+    whole batch equals the sum of the gradients of its two halves when each half normalises by the GLOBAL mask counts
+    (what two ranks compute before the all-reduce; SURVEY hard part 7) — up to fp32 summation order."""
+    from consistentnerf_amd import distributed as D, run_nerf_view as V
+    from consistentnerf_amd.optim import FusedAdam
+    B, far = 5120, 12.0
+    coarse, fine, _ = _c2(dev, 1)
+    rays = T(I.ray_batch(B, seed=17, near=1.2, far=far), dev)
+    kw = _kwargs(coarse, fine, 64, 128, 0.0, False, 0.0, False)
+    opt = FusedAdam(list(coarse.parameters()) + list(fine.parameters()), lr=5e-4)
+    rs = np.random.RandomState(9)
+    target = T(rs.uniform(size=(B, 3)).astype(np.float32), dev)
+    prior = T(rs.uniform(1.2, far, size=(B,)).astype(np.float32), dev)
+    mask = T((rs.uniform(size=(B,)) < 0.55).astype(np.float32), dev)
+    mono = T(rs.uniform(0.05, 1.0, size=(1024,)).astype(np.float32), dev)
+    counts = D.global_mask_counts(mask)
+
+    def accumulate(sl, counts_, patch):
+        out = V.render_rays(rays[sl], **kw)
+        il, dl = V.hardmask_losses(out["rgb_map"], target[sl], mask[sl], 0.2, out["depth_map"], prior[sl], far, counts=counts_)
+        il0, dl0 = V.hardmask_losses(out["rgb0"], target[sl], mask[sl], 0.2, out["depth0"], prior[sl], far, counts=counts_)
+        loss = il + il0 + 0.1 * (dl + dl0)
+        if patch:
+            loss = loss + 0.001 * (V.midas_patch_loss(out["depth_map"], mono, 4, 16) + V.midas_patch_loss(out["depth0"], mono, 4, 16))
+        loss.backward()
+        return loss.item()
+    opt.zero_grad()
+    l_full = accumulate(slice(0, B), None, True)
+    g_full = opt.flat_grad.clone()
+    opt.zero_grad()
+    l_a = accumulate(slice(0, B // 2), counts, True)       # the patch rays are the first 1024: they sit in the first half
+    l_b = accumulate(slice(B // 2, B), counts, False)
+    g_sum = opt.flat_grad.clone()
+    assert np.isfinite(l_full) and abs((l_a + l_b) - l_full) <= 1e-5 * abs(l_full)
+    scale = float(g_full.abs().max())
+    assert scale > 0 and float((g_sum - g_full).abs().max()) <= 2e-5 * scale
+
+
+@pytest.mark.parametrize("ndc,perturb,noise,white", [(False, 0.0, 0.0, False), (True, 0.0, 0.0, False), (False, 1.0, 1.0, True),
+                                                      (True, 1.0, 0.0, False)])
+def test_camera_path_generates_rays_in_kernel(dev, ndc, perturb, noise, white):
+    """render(c2w=...) for inference (SURVEY 8 f-2 last clause): the rays of the camera are generated inside coarse_z / the
+    MLP forward / compositing (cnerf_render_fwd_cam, one C call per chunk) instead of being written to HBM as an
+    [H*W, 11] tensor first — bit-identical to the ray-tensor path on every output, NDC on and off, with the reference's
+    deterministic jitter / noise hooks, ragged last chunk; the R and V surfaces; with autograd on, the ray-tensor path."""
+    from consistentnerf_amd import ops, run_nerf as R, run_nerf_view as V
+    g = golden("render_full_tiny")
+    K, c2w = g["K"], T(g["c2w"], dev)
+    coarse, _ = make_model(4, 128, True, 5, 31, dev)
+    fine, _ = make_model(4, 128, True, 5, 32, dev)
+    H, W = 13, 16
+    kw = _kwargs(coarse, fine, 16, 16, perturb, white, noise, False)
+    if ndc:
+        kw.pop("lindisp")
+    near, far = (0.0, 1.0) if ndc else (2.0, 6.0)
+    kw.update(ndc=ndc, near=near, far=far, use_viewdirs=True, pytest=True, retraw=True)
+
+    def run(stock, mod):
+        kw["network_query_fn"]._cnerf_stock = stock
+        ops.PROFILE = []
+        try:
+            with torch.no_grad():
+                out = mod.render(H, W, K, chunk=100, c2w=c2w, **kw)
+            kinds = [n for n, *_ in ops.PROFILE]
+        finally:
+            ops.PROFILE = None
+        return out, kinds
+    for mod in (R, V):
+        ref, k_ref = run(False, mod)
+        got, k_got = run(True, mod)
+        assert "render_fwd_cam" in k_got and "mlp_fwd" not in k_got and "render_fwd_cam" not in k_ref
+        assert k_got.count("render_fwd_cam") == 3      # 208 rays in chunks of 100
+        for a, b in zip(got[:-1], ref[:-1]):
+            assert a.shape == b.shape and torch.equal(torch.nan_to_num(a), torch.nan_to_num(b))
+        assert set(got[-1]) == set(ref[-1])
+        for k in ref[-1]:
+            assert torch.equal(torch.nan_to_num(got[-1][k]), torch.nan_to_num(ref[-1][k])), k
+    kw["network_query_fn"]._cnerf_stock = True
+    ops.PROFILE = []
+    try:
+        out = R.render(H, W, K, chunk=100, c2w=c2w, **kw)       # autograd on: a graph is needed -> the ray-tensor path
+        kinds = [n for n, *_ in ops.PROFILE]
+    finally:
+        ops.PROFILE = None
+    assert "render_fwd_cam" not in kinds and out[0].requires_grad
