@@ -66,6 +66,9 @@ SIGNATURES = {
     "cnerf_mlp_stash_floats": (_i64, [_NetP, _i64]),
     "cnerf_mlp_fwd": (_i, [_NetP, _vp, _vp, _vp, _i, _vp, _vp, _i64, _i, _vp, _vp, _vp]),
     "cnerf_mlp_fwd_embedded": (_i, [_NetP, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "cnerf_packed_bf_bytes": (_i64, [_NetP, _i]),
+    "cnerf_pack_weights_bf": (_i, [_NetP, _PtrsP, _i, _vp, _vp]),
+    "cnerf_mlp_fwd_bf": (_i, [_NetP, _vp, _i, _vp, _vp, _i, _vp, _vp, _i64, _i, _vp, _vp]),
     "cnerf_mlp_bwd_ws_floats": (_i64, [_NetP, _i64]),
     "cnerf_mlp_bwd": (_i, [_NetP, _vp, _vp, _i64, _i, _vp, _vp, _PtrsP, _i, _vp]),
     "cnerf_mlp_bwd_pair": (_i, [_NetP, _vp, _vp, _i64, _i, _vp, _vp, _PtrsP, _NetP, _vp, _vp, _i64, _i, _vp, _vp, _PtrsP, _i, _vp]),

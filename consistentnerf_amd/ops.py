@@ -188,6 +188,36 @@ def mlp_forward(spec: NetSpec, packed: Tensor, B: int, S: int, *, pts: Optional[
     return raw, stash
 
 
+PRECISION_PLANES = {"bf16": 1, "bf16x2": 2, "bf16x3": 3}
+
+
+def pack_weights_bf(spec: NetSpec, params: Sequence[Tensor], planes: int, out: Optional[Tensor] = None) -> Tensor:
+    """cnerf_pack_weights_bf: the bf16-plane panels of the opt-in reduced-precision inference forward (a byte buffer)."""
+    lib, net = _lib.load(), spec.c()
+    params = [_chk(p, f"param{i}") for i, p in enumerate(params)]
+    n = lib.cnerf_packed_bf_bytes(C.byref(net), int(planes))
+    if n < 0:
+        raise CnerfError(f"reduced-precision inference is not compiled for {spec} with {planes} plane(s)")
+    if out is None:
+        out = torch.empty(n, device=params[0].device, dtype=torch.uint8)
+    ptrs = _ptrs(params)
+    _lib.check(lib.cnerf_pack_weights_bf(C.byref(net), C.byref(ptrs), int(planes), _p(out), _stream()), "cnerf_pack_weights_bf")
+    return out
+
+
+def mlp_forward_bf(spec: NetSpec, packed_bf: Tensor, planes: int, B: int, S: int, *, pts: Optional[Tensor] = None,
+                   rays: Optional[Tensor] = None, z: Optional[Tensor] = None, dirs: Optional[Tensor] = None) -> Tensor:
+    """cnerf_mlp_fwd_bf: inference forward on the bf16 matrix cores (opt-in)."""
+    lib, net = _lib.load(), spec.c()
+    pts, rays, z, dirs = _chk(pts, "pts"), _chk(rays, "rays"), _chk(z, "z"), _chk(dirs, "dirs")
+    raw = torch.empty(B, S, spec.raw_ch, device=packed_bf.device, dtype=torch.float32)
+    rs = rays.shape[1] if rays is not None else 0
+    with _timed("mlp_fwd_bf%d" % planes, B * S):
+        _lib.check(lib.cnerf_mlp_fwd_bf(C.byref(net), _p(packed_bf), int(planes), _p(pts), _p(rays), rs, _p(dirs), _p(z), B, S,
+                                        _p(raw), _stream()), "cnerf_mlp_fwd_bf")
+    return raw
+
+
 def mlp_forward_embedded(spec: NetSpec, packed: Tensor, x: Tensor, want_stash: bool = False):
     """NeRF.forward on pre-embedded inputs x[M, in_ch + in_ch_views]."""
     lib, net = _lib.load(), spec.c()

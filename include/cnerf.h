@@ -90,6 +90,18 @@ int cnerf_mlp_fwd(const cnerf_net* net, const float* packed, const float* pts, c
  * the stash (and therefore cnerf_mlp_bwd with B=M, S=1) works unchanged. */
 int cnerf_mlp_fwd_embedded(const cnerf_net* net, const float* packed, const float* x_embedded, int64_t M,
                            float* raw, float* stash, void* stream);
+/* ---- OPT-IN reduced-precision inference forward (never the default path, never used for training) -------------------
+ * The same fused encoding + MLP as cnerf_mlp_fwd (run_nerf.py:37-52, run_nerf_helpers.py:107-130), its GEMMs on the bf16
+ * matrix cores with every operand split into `planes` bf16 terms and fp32 accumulation:
+ *   planes = 1 plain bf16 (error per product ~2^-9), 2 "bf16x2": w0x0 + w0x1 + w1x0 (~2^-16), 3 "bf16x3": the 6 cross terms
+ *   with i + j < 3 (~2^-23, fp32-like).  Encodings, biases, the sigma / rgb heads and accumulators stay fp32.
+ * Networks with view directions, W in {128, 256}.  packed_bf: cnerf_packed_bf_bytes(net, planes) bytes, filled by
+ * cnerf_pack_weights_bf from the same 2D+8 parameter tensors as cnerf_pack_weights. */
+int64_t cnerf_packed_bf_bytes(const cnerf_net* net, int planes);
+int cnerf_pack_weights_bf(const cnerf_net* net, const cnerf_ptrs* params, int planes, void* packed_bf, void* stream);
+int cnerf_mlp_fwd_bf(const cnerf_net* net, const void* packed_bf, int planes, const float* pts, const float* rays,
+                     int ray_stride, const float* dirs, const float* z, int64_t B, int S, float* raw, void* stream);
+
 /* Backward of the above (autograd of R:37-52 / H:107-130): d_raw[M,C] -> gradients of every parameter
  * tensor.  `grads` holds device pointers laid out like `params`; accumulate!=0 adds into them.
  * workspace size = cnerf_mlp_bwd_ws_floats(net, M). */

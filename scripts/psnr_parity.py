@@ -84,9 +84,15 @@ def batch_bounds(i, n):
 
 # ------------------------------------------------------------------------------------------------ CPU side
 def oracle_job(job):
-    seed, nudged, steps, threads = job
+    seed, nudged, milestones, threads, cores, partdir = job
+    if cores:                               # each worker on its own cores (no OpenMP pool sharing cores with another's)
+        os.sched_setaffinity(0, cores)
     torch.set_num_threads(threads)
     from oracle import nerf_oracle as O
+    tag = f"s{seed}_{'ctl' if nudged else 'ref'}"
+    steps = milestones[-1]
+    if os.path.exists(os.path.join(partdir, f"{tag}_m{steps}.npz")):
+        return tag
     K, bank, target, test_rays, test_rgb, sds = scene(seed)
     if nudged:
         sds = ulp_nudge(sds, seed)
@@ -107,27 +113,60 @@ def oracle_job(job):
                     O.adam_step(p, g_, mm, vv, i + 1, lr)
         lr = O.lr_at(LRATE, i, LRATE_DECAY)
         losses.append(loss.item())
-        if i % 100 == 0:
-            print(f"[oracle seed {seed}{' nudged' if nudged else ''}] step {i} loss {losses[-1]:.6f} "
-                  f"({time.perf_counter() - t0:.0f} s)", flush=True)
-    with torch.no_grad():
-        img = O.render_rays(test_rays, osd[0], osd[1], net, O.RenderCfg(64, 128, 0.0))["rgb_map"]
-    psnr = O.psnr_from_mse(O.mse(img, test_rgb)).item()
-    return seed, nudged, np.asarray(losses, np.float32), psnr, img.numpy().astype(np.float32), time.perf_counter() - t0
+        if i in (2, 20) or i % 100 == 0:
+            print(f"[oracle {tag}] step {i} loss {losses[-1]:.6f} ({time.perf_counter() - t0:.0f} s)", flush=True)
+        if i + 1 in milestones:             # a milestone's result survives an interrupted run
+            with torch.no_grad():
+                img = O.render_rays(test_rays, osd[0], osd[1], net, O.RenderCfg(64, 128, 0.0))["rgb_map"]
+            psnr = O.psnr_from_mse(O.mse(img, test_rgb)).item()
+            np.savez_compressed(os.path.join(partdir, f"{tag}_m{i + 1}.npz"), loss=np.asarray(losses, np.float32), psnr=psnr,
+                                img=img.numpy().astype(np.float32), secs=time.perf_counter() - t0, steps=i + 1)
+            print(f"[oracle {tag}] milestone {i + 1}: held-out {psnr:.3f} dB ({time.perf_counter() - t0:.0f} s)", flush=True)
+    return tag
+
+
+def merge_parts(partdir, out):
+    """Largest milestone every (seed, run) pair reached -> one .npz (what the GPU side reads)."""
+    import glob
+    import re
+    have = {}
+    for f in glob.glob(os.path.join(partdir, "s*_m*.npz")):
+        mo = re.match(r"s(\d+)_(ref|ctl)_m(\d+)\.npz", os.path.basename(f))
+        have.setdefault((int(mo.group(1)), mo.group(2)), set()).add(int(mo.group(3)))
+    seeds = sorted({s for s, _ in have if (s, "ref") in have and (s, "ctl") in have})
+    if not seeds:
+        raise SystemExit("no seed has both runs")
+    common = set.intersection(*[have[(s, t)] for s in seeds for t in ("ref", "ctl")])
+    if not common:
+        raise SystemExit(f"no common milestone: {have}")
+    steps = max(common)
+    res = {"seeds": np.asarray(seeds), "steps": np.asarray(steps)}
+    for s in seeds:
+        for t in ("ref", "ctl"):
+            d = np.load(os.path.join(partdir, f"s{s}_{t}_m{steps}.npz"))
+            for k in ("loss", "psnr", "img", "secs"):
+                res[f"s{s}_{t}_{k}"] = d[k]
+            print(f"s{s}_{t}: {steps} steps, held-out {float(d['psnr']):.3f} dB, final loss {d['loss'][-1]:.6f}, {float(d['secs']):.0f} s")
+    np.savez_compressed(out, **res)
+    print("wrote", out, "seeds", seeds, "steps", steps)
 
 
 def run_oracle(a):
     import multiprocessing as mp
-    jobs = [(s, n, a.steps, a.threads) for s in a.seeds for n in (False, True)]
+    partdir = a.out + ".parts"
+    os.makedirs(partdir, exist_ok=True)
+    milestones = sorted(set(m for m in a.milestones if m <= a.steps) | {a.steps})
+    avail = sorted(os.sched_getaffinity(0))
+    jobs = []
+    for k, (s, n) in enumerate((s, n) for s in a.seeds for n in (False, True)):
+        cores = set(avail[(k * a.cores_per_worker) % len(avail):][:a.cores_per_worker]) if a.cores_per_worker else None
+        jobs.append((s, n, milestones, a.threads, cores, partdir))
+    print(f"{len(jobs)} jobs, {a.workers} workers x {a.threads} threads, {a.cores_per_worker} cores each of {len(avail)} usable; "
+          f"milestones {milestones}", flush=True)
     with mp.get_context("spawn").Pool(a.workers) as pool:
-        res = pool.map(oracle_job, jobs, chunksize=1)
-    out = {"seeds": np.asarray(a.seeds), "steps": np.asarray(a.steps)}
-    for seed, nudged, losses, psnr, img, secs in res:
-        tag = f"s{seed}_{'ctl' if nudged else 'ref'}"
-        out[tag + "_loss"], out[tag + "_psnr"], out[tag + "_img"], out[tag + "_secs"] = losses, np.float64(psnr), img, secs
-        print(f"{tag}: held-out {psnr:.3f} dB, final loss {losses[-1]:.6f}, {secs:.0f} s")
-    np.savez_compressed(a.out, **out)
-    print("wrote", a.out)
+        for tag in pool.imap_unordered(oracle_job, jobs, chunksize=1):
+            print("finished", tag, flush=True)
+    merge_parts(partdir, a.out)
 
 
 # ------------------------------------------------------------------------------------------------ GPU side
@@ -222,12 +261,19 @@ def main():
     o.add_argument("--steps", type=int, default=600)
     o.add_argument("--workers", type=int, default=5)
     o.add_argument("--threads", type=int, default=1, help="ATen threads per worker")
+    o.add_argument("--cores-per-worker", type=int, default=0, help="pin worker k to its own block of this many cores (0: no pinning)")
+    o.add_argument("--milestones", type=int, nargs="*", default=[300, 450], help="also evaluate + save at these step counts")
+    mg = sub.add_parser("merge", help="assemble <out> from the milestone files of an interrupted oracle run")
+    mg.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_psnr_oracle.npz"))
     o.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_psnr_oracle.npz"))
     h = sub.add_parser("hip")
     h.add_argument("--oracle", default=os.path.join(ROOT, "profiles", "r02_psnr_oracle.npz"))
     h.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_psnr_parity_seeds.json"))
     a = ap.parse_args()
-    (run_oracle if a.side == "oracle" else run_hip)(a)
+    if a.side == "merge":
+        merge_parts(a.out + ".parts", a.out)
+    else:
+        (run_oracle if a.side == "oracle" else run_hip)(a)
 
 
 if __name__ == "__main__":

@@ -1315,7 +1315,7 @@ def test_train_10_steps_view_variant_golden(dev, route):
         global_step += 1
     assert abs(optimizer.param_groups[0]["lr"] - float(g["lr_final"])) < 1e-12
     idx = T(g["clipped_idx"], dev)
-    check(optimizer.flat_param[idx], g["final_at_clipped"], 5e-5, "final values of the clipped parameters")
+    check(optimizer.flat_param[idx], g["final_at_clipped"], 2e-6, "final values of the clipped parameters")   # measured 7e-9
     effect = np.abs(g["final_at_clipped"] - g["final_at_clipped_noclip"])
     assert np.median(effect) > 1e-4
     m, m_ref, m_noclip = optimizer.exp_avg[idx].cpu().numpy(), g["exp_avg_at_clipped"], g["exp_avg_at_clipped_noclip"]
@@ -1323,14 +1323,14 @@ def test_train_10_steps_view_variant_golden(dev, route):
     rel_m, rel_v = np.abs(m - m_ref) / np.abs(m_ref).max(), np.abs(v - v_ref) / np.abs(v_ref).max()
     print(f"  Adam moments at the clipped parameters: rel |d m| {rel_m.max():.2e}  rel |d v| {rel_v.max():.2e}; the no-clip "
           f"control is {(np.abs(m_noclip - m_ref) / np.abs(m_ref).max()).max():.2f} away")
-    assert rel_m.max() < 2e-2 and rel_v.max() < 2e-2
+    assert rel_m.max() < 2e-4 and rel_v.max() < 2e-4       # measured 1.4e-6 / 1.3e-5; the no-clip control is O(1) away
     assert (np.abs(m_noclip - m_ref) / np.abs(m_ref).max()).max() > 0.2
     worst = 0.0
     for tag, net in (("c", kw_train["network_fn"]), ("f", kw_train["network_fine"])):
         for k, p in net.state_dict().items():
             worst = max(worst, float(np.abs(p.reshape(-1)[::7].cpu().numpy() - g[f"final.{tag}.{k}.sub"]).max()))
     print(f"  final weights: max|d| = {worst:.3e}")
-    assert worst < 2e-4
+    assert worst < 5e-5                                    # measured 3.3e-6
 
 
 @pytest.mark.parametrize("clip,grad_scale", [(0.0, 1.0), (0.1, 1.0), (0.0, 0.125), (0.05, 3.0)])
@@ -1349,7 +1349,9 @@ def test_adam_kernel_clip_and_grad_scale(dev, clip, grad_scale):
         O.adam_step(pr, T(g) * grad_scale, mr, vr, step, 5e-4, clip=clip)
         if clip > 0 and step == 1:
             assert (np.abs(g * grad_scale) > clip).mean() > 0.2
-    check(m, mr, 1e-7, "exp_avg"); check(v, vr, 1e-8, "exp_avg_sq"); check(p, pr, 2e-7, "param")
+    # one fp32 rounding per operation on each side, in slightly different association (lerp / addcmul / addcdiv): a few ulp
+    check(m, mr, 4e-7 * float(mr.abs().max()), "exp_avg"); check(v, vr, 4e-7 * float(vr.abs().max()), "exp_avg_sq")
+    check(p, pr, 4e-7 * float(pr.abs().max()), "param")
 
 
 @pytest.mark.parametrize("nshards", [2, 3])
@@ -1610,7 +1612,8 @@ def test_img2mse_fused_kernel(dev):
         lr = torch.mean((xr - yr) ** 2)
         (3.0 * lr).backward()
         assert l.shape == lr.shape and abs(l.item() - lr.item()) <= 2e-7 * max(lr.item(), 1e-30) + 1e-12
-        check(x.grad, xr.grad, 1e-9, f"d img2mse / dx {shape}"); check(y.grad, yr.grad, 1e-9, f"d img2mse / dy {shape}")
+        tol = 4e-7 * float(xr.grad.abs().max())     # (2/n) (x - y) g: the same three factors, associated differently
+        check(x.grad, xr.grad, tol, f"d img2mse / dx {shape}"); check(y.grad, yr.grad, tol, f"d img2mse / dy {shape}")
     a, b = torch.rand(5, 3, device=dev), torch.rand(3, device=dev)
     assert torch.equal(R.img2mse(a, b), torch.mean((a - b) ** 2))
 
