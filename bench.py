@@ -170,7 +170,33 @@ def c5_leg(dev):
         dt = time.perf_counter() - t0
     n = H * W * (NC + NC + NF)
     tf = n * 2 * MAC_FWD / dt / 1e12
+    # the same frame through the OPT-IN reduced-precision inference forward (bf16 matrix cores, 1 / 2 / 3 bf16 planes per
+    # operand, fp32 accumulation; csrc/mlp_fwd_bf.hip): reported beside the exact render with its own dtype and its image
+    # PSNR against it — never part of `value`, never the default path
+    reduced = {}
+    nets = [kw_test["network_fn"], kw_test["network_fine"]]
+    try:
+        for prec in ("bf16x3", "bf16x2", "bf16"):
+            for m in nets:
+                m.inference_precision = prec
+            with torch.no_grad():
+                R.render(H // 4, W // 4, K, chunk=32768, c2w=poses[0], **kw_test)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                rgb_r, *_ = R.render(H, W, K, chunk=32768, c2w=poses[1], **kw_test)
+                rgb_r_host = rgb_r.cpu().numpy()
+                torch.cuda.synchronize()
+                dtr = time.perf_counter() - t1
+            mse = float(np.mean((rgb_r_host.astype(np.float64) - rgb_host.astype(np.float64)) ** 2))
+            reduced[prec] = {"frame_s": dtr, "speedup_vs_fp32": dt / dtr, "ray_samples_per_s": n / dtr,
+                             "image_psnr_vs_fp32_render_dB": (None if mse == 0 else -10.0 * np.log10(mse)),
+                             "dtype": {"bf16": "bf16 x bf16 -> f32", "bf16x2": "2 bf16 planes per operand, 3 cross terms -> f32",
+                                       "bf16x3": "3 bf16 planes per operand, 6 cross terms -> f32"}[prec]}
+    finally:
+        for m in nets:
+            m.inference_precision = "fp32"
     return {"frame_s": dt, "gpu_frame_s": e0.elapsed_time(e1) * 1e-3, "rays": H * W, "ray_samples_per_s": n / dt,
+            "opt_in_reduced_precision": reduced,
             "frame": f"{H}x{W} NDC, chunk 32768, perturb 0, 64+128 samples, D=8 W=256 (random init), D2H of the frame included",
             "finite": bool(np.isfinite(rgb_host).all()),
             "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -249,25 +275,30 @@ def c3_leg(dev, steps=20):
 
 def pmc_traffic(kernel, points):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
-    each in their own `--pmc` run, scripts/gpu_pmc.sh -> profiles/r01_pmc_final/): KB units, FETCH_SIZE doubled per the
-    gfx950 correction of MI355X_MICROARCH.md (16-byte-per-lane streaming reads are tallied at half).  None when no
-    pass of that kernel at that launch size is on file (counters cannot be sampled from inside this process)."""
+    each in their own `--pmc` run, scripts/gpu_pmc.sh -> profiles/r02_pmc/, r01_pmc_final/ as a fallback): KB units,
+    FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md (16-byte-per-lane streaming reads are tallied at
+    half).  A STATIC LOOKUP, not a measurement of this run (counters cannot be sampled from inside this process); None when
+    no pass of that kernel at that launch size is on file."""
     import csv
     here = os.path.dirname(os.path.abspath(__file__))
     name = {"mlp_wgrad": "wgrad", "mlp_dgrad": "mlp_dgrad", "mlp_fwd_train": "mlp_fwd_train", "mlp_fwd": "mlp_fwd_inf"}.get(kernel)
-    val = {}
-    for f, ctr in (("pass2_summary.csv", "FETCH_SIZE"), ("pass3_summary.csv", "WRITE_SIZE")):
-        path = os.path.join(here, "profiles", "r01_pmc_final", f)
-        if not os.path.exists(path):
-            return None
-        rows = [r for r in csv.DictReader(open(path)) if r["kernel"] == name and r["counter"] == ctr]
-        # forward / dgrad launch 64 threads per 32 points; wgrad's grid does not encode M: take the larger (fine) launch
-        pick = [r for r in rows if int(r["grid_threads"]) == 2 * points] or (sorted(rows, key=lambda r: -int(r["grid_threads"]))[:1]
-                                                                            if name == "wgrad" and points == 786432 else [])
-        if not pick:
-            return None
-        val[ctr] = float(pick[0]["avg_per_launch"]) * 1024.0
-    return int(2 * val["FETCH_SIZE"] + val["WRITE_SIZE"])
+    # grid threads of the launch: forward / dgrad run 64 threads per 32 points; wgrad's grid is (point ranges) x (GEMMs) x
+    # 256 threads: 128 x 14 for the fine level alone (round 1), 128 x 28 for both levels in one grid (round 2)
+    want = {"wgrad": {786432: 128 * 14 * 256, 1048576: 128 * 28 * 256}.get(points)}.get(name, 2 * points)
+    for d in ("r02_pmc", "r01_pmc_final"):
+        val = {}
+        for f, ctr in (("pass2_summary.csv", "FETCH_SIZE"), ("pass3_summary.csv", "WRITE_SIZE")):
+            path = os.path.join(here, "profiles", d, f)
+            if not os.path.exists(path):
+                break
+            pick = [r for r in csv.DictReader(open(path)) if r["kernel"] == name and r["counter"] == ctr
+                    and int(r["grid_threads"]) == want]
+            if not pick:
+                break
+            val[ctr] = float(pick[0]["avg_per_launch"]) * 1024.0
+        if len(val) == 2:
+            return int(2 * val["FETCH_SIZE"] + val["WRITE_SIZE"])
+    return None
 
 
 def main():

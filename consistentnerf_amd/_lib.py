@@ -96,7 +96,7 @@ SIGNATURES = {
     "cnerf_loss_ws_floats": (_i64, []),
     "cnerf_masked_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
     "cnerf_patch_depth_loss": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp, _vp]),
-    "cnerf_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _f, _f, _f, _f, _f, _f, _vp]),
+    "cnerf_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _i, C.c_double, C.c_double, C.c_double, C.c_double, _f, _f, _vp]),
 }
 
 _lib = None
@@ -121,7 +121,7 @@ def load():
         except AttributeError as e:
             raise CnerfError(f"libcnerf_hip.so does not export {name}") from e
         fn.restype, fn.argtypes = res, args
-    if lib.cnerf_abi_version() != 1:
+    if lib.cnerf_abi_version() != 2:
         raise CnerfError("libcnerf_hip.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

@@ -21,16 +21,16 @@ __global__ void adam_k(float* __restrict__ p, const float* __restrict__ g, float
 }
 }  // namespace
 
-extern "C" int cnerf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr,
-                               float beta1, float beta2, float eps, float clip, float grad_scale, void* stream) {
+extern "C" int cnerf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int step, double lr,
+                               double beta1, double beta2, double eps, float clip, float grad_scale, void* stream) {
   if (!p || !g || !m || !v || n < 0 || step < 1) return CNERF_E_ARG;
   if (n == 0) return CNERF_OK;
-  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-  const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+  const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
+  const float step_size = (float)(lr / bc1), bc2_sqrt = (float)sqrt(bc2);
   int64_t blocks = cn_div_up(n, 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(adam_k, dim3((unsigned)blocks), dim3(256), 0, cn_stream(stream), p, g, m, v, n,
-                     (float)(1.0 - (double)beta1), beta2, (float)(1.0 - (double)beta2), step_size, bc2_sqrt, eps,
+                     (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), step_size, bc2_sqrt, (float)eps,
                      clip, grad_scale);
   CN_CHECK_LAUNCH();
   return CNERF_OK;

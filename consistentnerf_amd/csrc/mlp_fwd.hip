@@ -46,14 +46,22 @@ template <int NT, bool VD, bool TRAIN>
 __global__ __launch_bounds__(64) void mlp_fwd_k(FwdArgs args_by_value) {
   // the argument block is read in place from the kernarg segment (scalar loads next to their use): taken by value, all
   // of it is fetched by the kernel prologue and stays live in SGPRs across the layer loop (31 SGPR spills at NT = 8)
+#ifdef CN_FWD_BYVAL
+  const FwdArgs& a = args_by_value;
+#else
   (void)args_by_value;
   const CN_CONST FwdArgs& a = *(const CN_CONST FwdArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+#endif
   constexpr int W = NT * 32;
   constexpr int NTH = NT / 2 > 0 ? NT / 2 : 1;   // view-branch tiles (W/2 wide)
   constexpr int MD = (NT + 1) / 2, MDV = (NTH + 1) / 2;
   __shared__ __attribute__((aligned(16))) float Tx[32 * 64];   // gamma(x)
   __shared__ __attribute__((aligned(16))) float Td[32 * 64];   // gamma(d) (32 columns used)
+#ifdef CN_FWD_BYVAL
+  const NetGeom& g = a.g;
+#else
   const CN_CONST NetGeom& g = a.g;
+#endif
   const int lane = threadIdx.x, m = lane & 31, hh = lane >> 5;
   const int64_t p0 = (int64_t)blockIdx.x * 32;
   const int64_t p = p0 + m;

@@ -61,6 +61,19 @@ def _packed(model):
     return _packed_gen(model)[0]
 
 
+def _packed_bf(model, planes):
+    """bf16-plane panels of `model` for the opt-in reduced-precision inference forward, re-packed when a parameter changed."""
+    ts = model.kernel_tensors()
+    key = (planes,) + tuple((t.data_ptr(), t._version, getattr(t, "_cnerf_epoch", 0)) for t in ts)
+    cache = model.__dict__.get("_cnerf_packed_bf")
+    if cache is None or cache[0] != key:
+        with torch.no_grad():
+            buf = ops.pack_weights_bf(model.spec(), ts, planes, None if cache is None or cache[0][0] != planes else cache[1])
+        cache = (key, buf)
+        model.__dict__["_cnerf_packed_bf"] = cache
+    return cache[1]
+
+
 def _packed_still_valid(model, gen):
     cache = model.__dict__.get("_cnerf_packed")
     return cache is not None and cache[2] - gen <= 1
@@ -236,6 +249,17 @@ def run_network(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk=1024 * 64
     B, S = inputs.shape[0], inputs.shape[1]
     dirs = viewdirs.contiguous() if (viewdirs is not None and spec.use_viewdirs) else None
     params = fn.kernel_tensors()
+    prec = getattr(fn, "inference_precision", "fp32")
+    if prec != "fp32" and not (torch.is_grad_enabled() and any(p.requires_grad for p in params)):
+        # OPT-IN reduced-precision inference (NeRF.inference_precision = "bf16" | "bf16x2" | "bf16x3"): bf16 matrix cores,
+        # fp32 accumulation; never taken when a gradient could be asked for
+        if prec not in ops.PRECISION_PLANES:
+            raise ValueError(f"inference_precision must be fp32 or one of {sorted(ops.PRECISION_PLANES)}")
+        planes = ops.PRECISION_PLANES[prec]
+        pk = _packed_bf(fn, planes)
+        if isinstance(inputs, RayPoints):
+            return ops.mlp_forward_bf(spec, pk, planes, B, S, rays=inputs.rays, z=inputs.z_vals, dirs=dirs)
+        return ops.mlp_forward_bf(spec, pk, planes, B, S, pts=inputs.reshape(-1, 3).contiguous(), dirs=dirs)
     if not torch.is_grad_enabled():
         # under torch.no_grad() a Function still sees needs_input_grad = True for the parameters: detach them, or the
         # inference pass would run the training kernel and write a 10 KB-per-point stash nobody reads
@@ -325,6 +349,8 @@ def _camera_path_ok(rays, c2w, near, far, use_viewdirs, c2w_staticcam, kwargs):
         return False
     nets = [net] + ([fine] if fine is not None else [])
     if any(bool(n.use_viewdirs) != bool(use_viewdirs) for n in nets):
+        return False
+    if any(getattr(n, "inference_precision", "fp32") != "fp32" for n in nets):   # the camera path is the exact-fp32 one
         return False
     return not (torch.is_grad_enabled() and any(p.requires_grad for n in nets for p in n.parameters()))
 

@@ -138,12 +138,18 @@ class NeRF(nn.Module):
             ts += [self.output_linear.weight, self.output_linear.bias]
         return ts
 
+    # OPT-IN: "bf16" | "bf16x2" | "bf16x3" run the INFERENCE forward (no autograd graph) on the bf16 matrix cores with the
+    # operands split into 1 / 2 / 3 bf16 planes and fp32 accumulation (csrc/mlp_fwd_bf.hip).  Training and everything
+    # under autograd always use the exact-fp32 kernels; so does this module unless the attribute is set.
+    inference_precision = "fp32"
+
     def invalidate_packed(self):
         """Forget the kernel-layout copy of the weights.  The cache key (run_nerf._packed) sees optimizer steps,
         load_state_dict() and every autograd-visible in-place edit, but NOT writes through `p.data` (manual EMA /
         re-initialisation code: `p.data.mul_()`, `p.data.copy_()`), which bump no version counter — call this after such
         an edit."""
         self.__dict__.pop("_cnerf_packed", None)
+        self.__dict__.pop("_cnerf_packed_bf", None)
 
     def forward(self, x):
         """H:107-130 on an already-embedded batch x[..., input_ch + input_ch_views] -> [..., 4 | output_ch]

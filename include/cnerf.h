@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define CNERF_ABI_VERSION 1
+#define CNERF_ABI_VERSION 2   /* 2: cnerf_adam_step takes its hyper-parameters as double; the *_pair, *_cam, *_bf entry points */
 
 #define CNERF_OK 0
 #define CNERF_E_ARG (-1)        /* null pointer / negative size / inconsistent shapes            */
@@ -275,9 +275,11 @@ int cnerf_patch_depth_loss(const float* depth_pred, const float* mono, int P, in
                            float* loss, float* d_depth, void* stream);
 
 /* ---- f-1: optimiser tail  (clip_grad_value_ V:1983, Adam R:210/780, lr decay R:784-788) --------- */
-/* In-place Adam over n contiguous floats; clip<=0 disables the value clip; step is 1-based. */
-int cnerf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr,
-                    float beta1, float beta2, float eps, float clip, float grad_scale, void* stream);
+/* In-place Adam over n contiguous floats; clip<=0 disables the value clip; step is 1-based.  The hyper-parameters are
+ * doubles, as torch.optim.Adam holds them: 1 - beta2 formed from a float-rounded 0.999 is off by 1.3e-5 (relative), which
+ * would show in exp_avg_sq. */
+int cnerf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int step, double lr,
+                    double beta1, double beta2, double eps, float clip, float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -58,6 +58,30 @@ def main():
         print(f"S={S:4d} M={M:8d}  fwd(inf) {t_inf:7.3f} ms {tf('fwd', t_inf):6.1f} TF | fwd(train) {t_tr:7.3f} ms "
               f"{tf('fwd', t_tr):6.1f} TF | dgrad {t_dg:7.3f} ms {tf('dgrad', t_dg):6.1f} TF | wgrad {t_wg:7.3f} ms "
               f"{tf('wgrad', t_wg):6.1f} TF", flush=True)
+        for planes in (1, 2, 3):
+            pk = ops.pack_weights_bf(spec, m.kernel_tensors(), planes)
+            t_bf = timeit(lambda: ops.mlp_forward_bf(spec, pk, planes, B, S, rays=rays, z=z))
+            print(f"          fwd bf16 x{planes} (inference, opt-in) {t_bf:7.3f} ms = {tf('fwd', t_bf):7.1f} TFLOP/s fp32-equivalent, "
+                  f"{t_inf / t_bf:5.2f}x the fp32 kernel", flush=True)
+        if S == 192:
+            keep = (spec, packed, d_raw, B, S, stash)
+        else:                                   # both levels are around: the paired backward (one dgrad + one wgrad grid)
+            fs, fp, fd, fB, fS, fst = keep
+            g0 = [torch.empty(s_, device=dev) for s_ in spec.tensor_shapes()]
+            g1 = [torch.empty(s_, device=dev) for s_ in spec.tensor_shapes()]
+            n0, n1 = fs.c(), spec.c()
+            ws0 = torch.empty(lib.cnerf_mlp_bwd_ws_floats(C.byref(n0), fB * fS), device=dev)
+            ws1 = torch.empty(lib.cnerf_mlp_bwd_ws_floats(C.byref(n1), M), device=dev)
+            p0, p1 = ops._ptrs(g0), ops._ptrs(g1)
+            t_dp = timeit(lambda: lib.cnerf_mlp_dgrad_pair(C.byref(n0), ops._p(fp), ops._p(fd), fB, fS, ops._p(fst), ops._p(ws0),
+                                                           C.byref(n1), ops._p(packed), ops._p(d_raw), B, S, ops._p(stash),
+                                                           ops._p(ws1), st()))
+            t_wp = timeit(lambda: lib.cnerf_mlp_wgrad_pair(C.byref(n0), fB, fS, ops._p(fst), ops._p(ws0), C.byref(p0),
+                                                           C.byref(n1), B, S, ops._p(stash), ops._p(ws1), C.byref(p1), 0, st()))
+            Mt = fB * fS + M
+            print(f"pair  M={Mt:8d}  dgrad {t_dp:7.3f} ms {2 * MAC['dgrad'] * Mt / (t_dp * 1e-3) / 1e12:6.1f} TF | wgrad {t_wp:7.3f} ms "
+                  f"{2 * MAC['wgrad'] * Mt / (t_wp * 1e-3) / 1e12:6.1f} TF", flush=True)
+            del ws0, ws1, keep
         if S == 192:
             w = torch.rand(B, 64, device=dev)
             zc = ops.coarse_z(rays, 64, None, False)
@@ -68,7 +92,9 @@ def main():
             t_cb = timeit(lambda: ops.composite_backward(raw, z, rays, None, False, g, None, None, None))
             print(f"          resample {t_rs*1e3:7.1f} us | composite fwd {t_cf*1e3:7.1f} us ({24*M/t_cf/1e6:6.1f} GB/s) | "
                   f"bwd {t_cb*1e3:7.1f} us ({40*M/t_cb/1e6:6.1f} GB/s)", flush=True)
-        del stash, ws
+        if S != 192:
+            del stash
+        del ws
 
 
 if __name__ == "__main__":

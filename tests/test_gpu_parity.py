@@ -1350,8 +1350,13 @@ def test_adam_kernel_clip_and_grad_scale(dev, clip, grad_scale):
         if clip > 0 and step == 1:
             assert (np.abs(g * grad_scale) > clip).mean() > 0.2
     # one fp32 rounding per operation on each side, in slightly different association (lerp / addcmul / addcdiv): a few ulp
-    check(m, mr, 4e-7 * float(mr.abs().max()), "exp_avg"); check(v, vr, 4e-7 * float(vr.abs().max()), "exp_avg_sq")
-    check(p, pr, 4e-7 * float(pr.abs().max()), "param")
+    # of each element (the hyper-parameters cross the C ABI as doubles: 1 - beta2 from a float-rounded 0.999 would be off by
+    # 1.3e-5 relative, which this bound catches)
+    for name, a_, b_ in (("exp_avg", m, mr), ("exp_avg_sq", v, vr), ("param", p, pr)):
+        a_, b_ = a_.cpu().double(), b_.double()
+        rel = float(((a_ - b_).abs() / b_.abs().clamp_min(1e-12 if name != "param" else 1e-3)).max())
+        print(f"  {name}: max relative |d| = {rel:.2e}")
+        assert rel <= 2e-6, (name, rel)
 
 
 @pytest.mark.parametrize("nshards", [2, 3])
@@ -1772,3 +1777,73 @@ def test_camera_path_generates_rays_in_kernel(dev, ndc, perturb, noise, white):
     finally:
         ops.PROFILE = None
     assert "render_fwd_cam" not in kinds and out[0].requires_grad
+
+
+# ------------------------------------------------------------------------------------------------
+# round 2: OPT-IN reduced-precision inference (bf16 planes) — its own tolerance tier, never the default path
+@pytest.mark.parametrize("D,W,tag", [(8, 256, "mlp_D8W256_vd"), (4, 128, "mlp_D4W128_vd")])
+def test_bf16_plane_inference_forward(dev, D, W, tag):
+    """cnerf_mlp_fwd_bf against the reference capture (fixture mlp_*: the reference's own network on the same points) and
+    the exact-fp32 kernel, per plane count.  Tiers (relative to max|raw|): bf16x3 2e-5 (fp32-like: 6 of the 9 cross terms of
+    a 3-way split), bf16x2 2e-3, bf16 1e-1.  The errors must also ORDER — each extra plane buys more than 10x — which a
+    mis-paired plane or a slip in the k permutation of the panels would break.  Ragged point count (padding lanes)."""
+    from consistentnerf_amd import ops
+    g = golden(tag)
+    model, _ = make_model(D, W, True, 4, 11, dev)
+    spec = model.spec()
+    pts, dirs = T(g["pts"], dev).reshape(-1, 3).contiguous(), T(g["dirs"], dev)
+    M = pts.shape[0]
+    dirs = dirs if dirs.shape[0] == M else dirs[:, None, :].expand(-1, M // dirs.shape[0], -1).reshape(-1, 3).contiguous()
+    ref, _ = ops.mlp_forward(spec, ops.pack_weights(spec, model.kernel_tensors()), M, 1, pts=pts, dirs=dirs)
+    cap = T(g["raw"], dev).reshape(M, 1, 4)
+    scale = max(1.0, float(cap.abs().max()))
+    check(ref, cap, 3e-5 * scale, "fp32 kernel vs capture")
+    errs = {}
+    for name, planes in (("bf16", 1), ("bf16x2", 2), ("bf16x3", 3)):
+        pk = ops.pack_weights_bf(spec, model.kernel_tensors(), planes)
+        for Mr in (M, M - 13):                      # full and ragged (padding lanes of the last 32-point tile)
+            raw = ops.mlp_forward_bf(spec, pk, planes, Mr, 1, pts=pts[:Mr].contiguous(), dirs=dirs[:Mr].contiguous())
+            assert torch.isfinite(raw).all()
+            errs[name] = max(errs.get(name, 0.0), float((raw - cap[:Mr]).abs().max()) / scale)
+        print(f"  {name}: max|d raw| / max|raw| vs the capture = {errs[name]:.3e}")
+    assert errs["bf16x3"] <= 2e-5 and errs["bf16x2"] <= 2e-3 and errs["bf16"] <= 1e-1
+    assert errs["bf16"] > 10 * errs["bf16x2"] and (errs["bf16x2"] > 10 * errs["bf16x3"] or errs["bf16x3"] < 5e-6)
+
+
+def test_bf16_plane_inference_is_opt_in_and_never_trains(dev):
+    """NeRF.inference_precision routes ONLY graph-free forwards to the bf16 kernel: the default is the exact path, a
+    forward that may need gradients stays fp32, render() under no_grad uses it for both levels (ragged chunk, rays from
+    a ray tensor), and the rendered image stays within the tier's PSNR bound of the fp32 render."""
+    from consistentnerf_amd import ops, run_nerf as R
+    coarse, fine, rays = _c2(dev, 777)
+    kw = _kwargs(coarse, fine, 64, 128, 0.0, False, 0.0, False)
+
+    def kinds_of(fn):
+        ops.PROFILE = []
+        try:
+            out = fn()
+            return out, [n for n, *_ in ops.PROFILE]
+        finally:
+            ops.PROFILE = None
+    with torch.no_grad():
+        ref, k0 = kinds_of(lambda: R.render_rays(rays, _with_depth=True, **kw))
+    assert k0.count("mlp_fwd") == 2
+    floor = {"bf16": 25.0, "bf16x2": 60.0, "bf16x3": 90.0}       # PSNR (dB) of the rendered colours vs the fp32 render
+    try:
+        for prec in ("bf16", "bf16x2", "bf16x3"):
+            coarse.inference_precision = fine.inference_precision = prec
+            with torch.no_grad():
+                out, k = kinds_of(lambda: R.render_rays(rays, _with_depth=True, **kw))
+            assert k.count("mlp_fwd_bf%d" % ops.PRECISION_PLANES[prec]) == 2 and "mlp_fwd" not in k
+            mse = float(((out["rgb_map"] - ref["rgb_map"]) ** 2).mean())
+            psnr = 99.0 if mse == 0 else -10.0 * np.log10(mse)
+            print(f"  {prec}: rendered rgb vs fp32 render {psnr:.1f} dB; max|d depth| {float((out['depth_map'] - ref['depth_map']).abs().max()):.2e}")
+            assert psnr >= floor[prec]
+            out, k = kinds_of(lambda: R.render_rays(rays, **kw))        # autograd on: the exact kernels, with a stash
+            assert k.count("mlp_fwd_train") == 2 and not any(n.startswith("mlp_fwd_bf") for n in k)
+        with pytest.raises(ValueError):
+            coarse.inference_precision = "fp8"
+            with torch.no_grad():
+                R.render_rays(rays, **kw)
+    finally:
+        coarse.inference_precision = fine.inference_precision = "fp32"
