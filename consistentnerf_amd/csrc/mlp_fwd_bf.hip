@@ -16,6 +16,8 @@
 // runs on the VALU one register pair at a time in the gaps between MFMAs (v_cvt_pk_bf16_f32 + shift/and + sub).
 // Bound: with the weights streamed per wave from L2 the kernel needs 16 B/clk/wave at NP = 2, 3 — the L2->CU limit
 // (64 B/clk/CU) — so it is weight-stream-bound before it is MFMA-bound; sharing the panels through LDS is the next step.
+#include <stdlib.h>
+
 #include "encode.hpp"
 #include "mlp_common.hpp"
 #include "raygen.hpp"
@@ -38,8 +40,8 @@ static int make_bf_geom(const NetGeom& g, int NP, BfGeom* b) {
   for (int l = 1; l < g.D; ++l) b->p_trunk[l] = panel(g.W, g.W);
   b->p_skip = g.skip >= 0 ? panel(g.in_chp, g.W) : -1;
   b->p_feat = panel(g.W, g.W);
-  b->p_views = panel(g.W, g.Wh);
-  b->p_viewsd = panel(g.dir_chp, g.Wh);
+  b->p_views = panel(g.W, g.W);            // N = W/2 real rows; every K-step is padded to NT tiles (uniform K-step size:
+  b->p_viewsd = panel(g.dir_chp, g.W);     // the LDS ring of the shared-panel kernel moves whole K-steps)
   for (int l = 0; l < g.D; ++l) b->b_trunk[l] = vec(g.W);
   b->b_feat = vec(g.W); b->b_views = vec(g.Wh); b->b_alpha = vec(1); b->b_rgb = vec(3);
   b->v_alpha = vec(g.W); b->v_rgb = vec(3 * g.Wh);
@@ -58,6 +60,7 @@ __device__ __forceinline__ unsigned bf16_rne(float x) {   // round-to-nearest-ev
 struct BfPackJob {
   const float* src;        // weight [N, ld]
   int ld, col0, N, K;      // source rows / columns used (K <= Kp)
+  int NTM;                 // 32-row tiles per K-step in memory (>= N/32)
   int Kp, kind;            // contracted width padded to 16; kind 0: k order of an LDS tile (16 s + 8 hh + e),
                            //                                kind 1: k order of C-layout registers (see the header)
   int64_t dst;             // byte offset
@@ -73,7 +76,7 @@ __global__ void pack_bf_k(BfPackArgs a) {
     return;
   }
   const BfPackJob j = a.job[blockIdx.y];
-  const int NTO = j.N / 32, NP = a.NP;
+  const int NTO = j.NTM, NP = a.NP;             // tiles per K-step in memory (rows >= N are zero)
   const int64_t n = (int64_t)(j.Kp / 16) * NTO * 512;           // (s, to, i, hh, e): all planes of one weight together
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
     const int e = (int)(idx & 7), hh = (int)((idx >> 3) & 1), i = (int)((idx >> 4) & 31);
@@ -116,7 +119,10 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
 // One register pair -> one dword of every plane (element 2q in the low half, 2q+1 in the high half).
 template <int NP, bool RELU>
 __device__ __forceinline__ void split_pair(float x0, float x1, u32x4 (&b)[NP], int q) {
-  if (RELU) { x0 = fmaxf(x0, 0.f); x1 = fmaxf(x1, 0.f); }
+  if (RELU) {   // one v_max each (fmaxf also emits a canonicalising v_max per operand: every VALU slot counts here)
+    asm("v_max_f32 %0, 0, %1" : "=v"(x0) : "v"(x0));
+    asm("v_max_f32 %0, 0, %1" : "=v"(x1) : "v"(x1));
+  }
   unsigned h = cvt_pk_bf16(x0, x1);
   b[0][q] = h;
 #pragma unroll
@@ -146,13 +152,13 @@ struct BfPanel {
   int lane;      // (m * 2 + hh) * 16: this lane's 16 bytes inside a 1 KiB piece
 };
 
-template <int NTO, int NP>
+template <int NTO, int NP, int NTM>
 __device__ __forceinline__ void a_fetch(u32x4 (&A)[NTO][NP], const BfPanel& P, int poff, int s) {
 #pragma unroll
   for (int t = 0; t < NTO; ++t)
 #pragma unroll
     for (int p = 0; p < NP; ++p)
-      A[t][p] = __builtin_amdgcn_raw_buffer_load_b128(P.rs, P.lane, poff + ((s * NTO + t) * NP + p) * 1024, 0);
+      A[t][p] = __builtin_amdgcn_raw_buffer_load_b128(P.rs, P.lane, poff + ((s * NTM + t) * NP + p) * 1024, 0);
 }
 
 // accumulators <- bias (fp32): register r of tile t is feature 32t + 8(r>>2) + 4hh + (r&3)
@@ -173,25 +179,27 @@ struct ASets { static constexpr int N = NP == 1 ? 4 : (NP == 2 ? 2 : 1); };
 
 // Q[t] += Panel . relu?(X) for the K = 32 NTI features held in C-layout registers X.  A-operand register sets: set
 // s % NSET holds K-step s and is refilled in place with K-step s + NSET behind its last use.
-template <int NTI, int NTO, int NP, bool RELU>
+template <int NTI, int NTO, int NP, bool RELU, int NTM>
 __device__ __forceinline__ void gemm_bf_reg(f32x16 (&Q)[NTO], const f32x16 (&X)[NTI], const BfPanel& P, int poff) {
   constexpr int KS = 2 * NTI, NSET = ASets<NP>::N;
   u32x4 A[NSET][NTO][NP];
 #pragma unroll
-  for (int s = 0; s < NSET && s < KS; ++s) a_fetch<NTO, NP>(A[s], P, poff, s);
+  for (int s = 0; s < NSET && s < KS; ++s) a_fetch<NTO, NP, NTM>(A[s], P, poff, s);
   u32x4 bc[NP], bn[NP];
 #pragma unroll
   for (int q = 0; q < 4; ++q) split_pair<NP, RELU>(X[0][2 * q], X[0][2 * q + 1], bc, q);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
+    // tile-major: the 1 / 3 / 6 cross terms of a tile back to back (the matrix pipe forwards the accumulator; ordering them
+    // product-major — no two consecutive MFMAs on one accumulator — measured 15 % SLOWER: more operands live, a read burst)
 #pragma unroll
     for (int t = 0; t < NTO; ++t) {
       products<NP>(Q[t], A[s % NSET][t], bc);
       if (s + NSET < KS) {
 #pragma unroll
         for (int p = 0; p < NP; ++p)
-          A[s % NSET][t][p] = __builtin_amdgcn_raw_buffer_load_b128(P.rs, P.lane, poff + (((s + NSET) * NTO + t) * NP + p) * 1024, 0);
+          A[s % NSET][t][p] = __builtin_amdgcn_raw_buffer_load_b128(P.rs, P.lane, poff + (((s + NSET) * NTM + t) * NP + p) * 1024, 0);
       }
       // the next K-step's B planes, one register pair behind each of the first four tiles' MFMAs
       if (s + 1 < KS && t < 4) {
@@ -214,7 +222,7 @@ __device__ __forceinline__ void gemm_bf_reg(f32x16 (&Q)[NTO], const f32x16 (&X)[
 
 // Q[t] += Panel . T for KS (even) K-steps of 16 channels read from the fp32 encoding tile T (channels 16 s + 8 hh + e);
 // two A-operand sets alternate so that the panel pieces of step s + 1 are in flight under the MFMAs of step s.
-template <int NTO, int NP>
+template <int NTO, int NP, int NTM>
 __device__ __forceinline__ void gemm_bf_lds(f32x16 (&Q)[NTO], const float* T, int KS, const BfPanel& P, int poff, int m, int hh) {
   u32x4 A0[NTO][NP], A1[NTO][NP];
   auto step = [&](u32x4 (&A)[NTO][NP], int s) __attribute__((always_inline)) {
@@ -228,13 +236,13 @@ __device__ __forceinline__ void gemm_bf_lds(f32x16 (&Q)[NTO], const float* T, in
 #pragma unroll
     for (int t = 0; t < NTO; ++t) products<NP>(Q[t], A[t], b);
   };
-  a_fetch<NTO, NP>(A0, P, poff, 0);
+  a_fetch<NTO, NP, NTM>(A0, P, poff, 0);
   for (int s = 0; s < KS; s += 2) {
-    a_fetch<NTO, NP>(A1, P, poff, s + 1);
+    a_fetch<NTO, NP, NTM>(A1, P, poff, s + 1);
     __builtin_amdgcn_sched_barrier(0);
     step(A0, s);
     __builtin_amdgcn_sched_barrier(0);
-    a_fetch<NTO, NP>(A0, P, poff, s + 2 < KS ? s + 2 : s);   // (the last refill re-reads step s: branch-free, unused)
+    a_fetch<NTO, NP, NTM>(A0, P, poff, s + 2 < KS ? s + 2 : s);   // (the last refill re-reads step s: branch-free, unused)
     __builtin_amdgcn_sched_barrier(0);
     step(A1, s + 1);
     __builtin_amdgcn_sched_barrier(0);
@@ -281,7 +289,7 @@ __global__ __launch_bounds__(64) void mlp_fwd_bf_k(BfArgs args_by_value) {
   f32x16 X[NT], Y[NT];
   // layer 0: gamma(x) from LDS -> Y
   bias_init<NT>(Y, P, (int)bg.b_trunk[0], hh);
-  gemm_bf_lds<NT, NP>(Y, Tx, g.in_chp / 16, P, (int)bg.p_l0, m, hh);
+  gemm_bf_lds<NT, NP, NT>(Y, Tx, g.in_chp / 16, P, (int)bg.p_l0, m, hh);
   pin<NT>(Y);
   // trunk layers l = 1..D-1 and feature_linear (l = D): Out = bias + W . relu(In) (+ the gamma(x) segment of the skip layer)
   float sig = 0.f;
@@ -305,11 +313,11 @@ __global__ __launch_bounds__(64) void mlp_fwd_bf_k(BfArgs args_by_value) {
       sig += *reinterpret_cast<const float*>(a.pk + bg.b_alpha);
     }
     // (the feature layer's input is already rectified: max(x, 0) once more is the identity — one GEMM body serves both)
-    gemm_bf_reg<NT, NT, NP, true>(Out, In, P, (int)(l < g.D ? bg.p_trunk[l] : bg.p_feat));
+    gemm_bf_reg<NT, NT, NP, true, NT>(Out, In, P, (int)(l < g.D ? bg.p_trunk[l] : bg.p_feat));
     {
       if (l == g.skip + 1) {
         pin<NT>(Out);
-        gemm_bf_lds<NT, NP>(Out, Tx, g.in_chp / 16, P, (int)bg.p_skip, m, hh);
+        gemm_bf_lds<NT, NP, NT>(Out, Tx, g.in_chp / 16, P, (int)bg.p_skip, m, hh);
       }
     }
     pin<NT>(Out);
@@ -326,9 +334,9 @@ __global__ __launch_bounds__(64) void mlp_fwd_bf_k(BfArgs args_by_value) {
   // views_linears (H:120-123) on cat([feature, gamma(d)]): Y (registers, no activation on the feature) + Td (LDS)
   f32x16 V[NTH];
   bias_init<NTH>(V, P, (int)bg.b_views, hh);
-  gemm_bf_reg<NT, NTH, NP, false>(V, Y, P, (int)bg.p_views);
+  gemm_bf_reg<NT, NTH, NP, false, NT>(V, Y, P, (int)bg.p_views);
   pin<NTH>(V);
-  gemm_bf_lds<NTH, NP>(V, Td, g.dir_chp / 16, P, (int)bg.p_viewsd, m, hh);
+  gemm_bf_lds<NTH, NP, NT>(V, Td, g.dir_chp / 16, P, (int)bg.p_viewsd, m, hh);
   // rgb_linear (H:125) on relu(V), fp32 on the VALU
   float o[3] = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -348,8 +356,295 @@ __global__ __launch_bounds__(64) void mlp_fwd_bf_k(BfArgs args_by_value) {
   if (hh == 0) buf_store(ors, m * 16, 0, f32x4{o[0] + brgb[0], o[1] + brgb[1], o[2] + brgb[2], sig});
 }
 
+// ======================================================================================================================
+// Shared-panel variant: the four waves of a workgroup (one per SIMD, 32 points each) consume the SAME weight stream, so
+// it crosses L2 -> CU once per 128 points instead of once per 32: the per-wave kernel above saturates at ~9.3 B/clk/wave
+// (37 B/clk/CU) of panel traffic whatever the plane count — it is L2-stream-bound, MFMA-busy 25 / 43 / 65 % at 1 / 2 / 3
+// planes.  Here a K-step of a panel (NT x NP pieces of 1 KiB) is moved HBM/L2 -> LDS by LDS-DMA (`buffer_load ... lds`, each
+// wave a quarter of the pieces) into a 4-slot ring two K-steps ahead of its use, published by ONE barrier per K-step, and
+// every wave reads its A operands from the ring with ds_read_b128 (64 lanes x 16 B contiguous: conflict-free).
+//   iteration s:  DMA(K-step s+2 -> slot (s+2)&3)   [that slot was read last in iteration s-2: two barriers ago]
+//                 MFMAs of K-step s from slot s&3
+//                 s_waitcnt vmcnt(own pieces of s+2 may stay in flight) ; barrier          -> K-step s+1 is published
+// Every GEMM has a multiple of 4 K-steps (the last one excepted), so each starts at slot 0 and hands the ring over to the
+// next panel (whose first two K-steps it prefetches) without draining it.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void dma1k(const i32x4& rs, unsigned lds_addr, int voff, int soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :
+               : "s"(__builtin_amdgcn_readfirstlane((int)lds_addr)), "v"(voff), "s"(rs),
+                 "s"(__builtin_amdgcn_readfirstlane(soff))
+               : "memory");
+}
+
+template <int NT, int NP>
+struct Ring {
+  static constexpr int PIECES = NT * NP;            // 1 KiB pieces per K-step
+  static constexpr int SLOT = PIECES * 1024;        // bytes per ring slot
+  static constexpr int PW = PIECES / 4;             // DMA instructions per wave and K-step
+  i32x4 rs;                                         // the packed buffer behind a buffer resource (DMA source)
+  unsigned lds0;                                    // LDS byte address of slot 0 (wave-uniform)
+  const unsigned char* ring;                        // the same, as a pointer for the ds_reads
+  int w;                                            // wave index in the workgroup (scalar)
+  int lane16;                                       // lane * 16: the DMA copies a piece lane-linearly
+  int rd16;                                         // (m * 2 + hh) * 16: this lane's A-operand bytes inside a piece
+  // this wave's quarter of K-step `s` of the panel at byte offset `poff` -> slot
+  __device__ __forceinline__ void dma(int poff, int s, int slot) const {
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+      const int i = w + 4 * j;
+      dma1k(rs, lds0 + (unsigned)(slot * SLOT + i * 1024), lane16, poff + (s * PIECES + i) * 1024);
+    }
+  }
+  __device__ __forceinline__ u32x4 a(int slot, int t, int p) const {
+    return *reinterpret_cast<const u32x4*>(ring + slot * SLOT + (t * NP + p) * 1024 + rd16);
+  }
+  template <int OUTSTANDING>
+  __device__ __forceinline__ void publish() const {   // own DMA pieces older than the newest OUTSTANDING have landed
+    static_assert(OUTSTANDING >= 0 && OUTSTANDING < 64, "vmcnt range");
+#ifdef CN_BF_SYNC
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+#else
+    __builtin_amdgcn_s_waitcnt(0x0f70 | (OUTSTANDING & 15) | ((OUTSTANDING >> 4) << 14));   // vmcnt only (gfx9 encoding)
+#endif
+    __syncthreads();
+  }
+};
+
+// Q[t] += Panel . relu?(X), panel K-steps through the ring.  On entry K-steps 0 and 1 are in flight / published (K-step 0
+// published); on exit the same holds for the NEXT panel (poff_next; -1: none follows).
+template <int NTI, int NTO, int NT, int NP, bool RELU>
+__device__ __forceinline__ void gemm_ring_reg(f32x16 (&Q)[NTO], const f32x16 (&X)[NTI], const Ring<NT, NP>& R, int poff,
+                                              int poff_next) {
+  constexpr int KS = 2 * NTI, PW = Ring<NT, NP>::PW;
+  static_assert(KS % 4 == 0, "ring slot continuity");
+  u32x4 bc[NP], bn[NP];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) split_pair<NP, RELU>(X[0][2 * q], X[0][2 * q + 1], bc, q);
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    u32x4 A[3][NP];       // A operands run two tiles ahead of the MFMAs that consume them (LDS latency)
+#pragma unroll
+    for (int p = 0; p < NP; ++p) A[0][p] = R.a(s & 3, 0, p);
+    if (NTO > 1) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) A[1][p] = R.a(s & 3, 1, p);
+    }
+#pragma unroll
+    for (int t = 0; t < NTO; ++t) {
+      if (t + 2 < NTO) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) A[(t + 2) % 3][p] = R.a(s & 3, t + 2, p);
+      }
+      products<NP>(Q[t], A[t % 3], bc);
+      if (t == 0) {       // the DMA of K-step s+2, behind the first MFMAs (in front of them it would delay the first LDS reads)
+        if (s + 2 < KS) R.dma(poff, s + 2, (s + 2) & 3);
+        else if (poff_next >= 0) R.dma(poff_next, s + 2 - KS, (s + 2) & 3);
+      }
+      if (s + 1 < KS && t < 4) {
+        const int sn = s + 1;
+        split_pair<NP, RELU>(X[sn >> 1][8 * (sn & 1) + 2 * t], X[sn >> 1][8 * (sn & 1) + 2 * t + 1], bn, t);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (NTO < 4 && s + 1 < KS) {
+#pragma unroll
+      for (int q = NTO; q < 4; ++q) {
+        const int sn = s + 1;
+        split_pair<NP, RELU>(X[sn >> 1][8 * (sn & 1) + 2 * q], X[sn >> 1][8 * (sn & 1) + 2 * q + 1], bn, q);
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) bc[p] = bn[p];
+    if (s + 2 < KS) R.template publish<PW>();
+    else if (poff_next >= 0) R.template publish<PW>();
+    else R.template publish<0>();
+  }
+}
+
+// the same with the B operand read from the fp32 encoding tile T (KS K-steps of 16 channels: 16 s + 8 hh + e)
+template <int KS, int NTO, int NT, int NP>
+__device__ __forceinline__ void gemm_ring_lds(f32x16 (&Q)[NTO], const float* T, const Ring<NT, NP>& R, int poff, int poff_next,
+                                              int m, int hh) {
+  constexpr int PW = Ring<NT, NP>::PW;
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    if (s + 2 < KS) R.dma(poff, s + 2, (s + 2) & 3);
+    else if (poff_next >= 0) R.dma(poff_next, s + 2 - KS, (s + 2) & 3);
+    const f32x4 c0 = *reinterpret_cast<const f32x4*>(T + enc_off(m, 4 * s + 2 * hh));
+    const f32x4 c1 = *reinterpret_cast<const f32x4*>(T + enc_off(m, 4 * s + 2 * hh + 1));
+    u32x4 b[NP];
+    split_pair<NP, false>(c0[0], c0[1], b, 0);
+    split_pair<NP, false>(c0[2], c0[3], b, 1);
+    split_pair<NP, false>(c1[0], c1[1], b, 2);
+    split_pair<NP, false>(c1[2], c1[3], b, 3);
+#pragma unroll
+    for (int t = 0; t < NTO; ++t) {
+      u32x4 A[NP];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) A[p] = R.a(s & 3, t, p);
+      products<NP>(Q[t], A, b);
+    }
+    if (s + 2 < KS || poff_next >= 0) R.template publish<PW>();
+    else R.template publish<0>();
+  }
+}
+
+template <int NT, int NP>
+__global__ __launch_bounds__(256) void mlp_fwd_bfs_k(BfArgs args_by_value) {
+  constexpr int W = NT * 32, NTH = NT / 2;
+  (void)args_by_value;
+  const CN_CONST BfArgs& a = *(const CN_CONST BfArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  const CN_CONST NetGeom& g = a.g;
+  const CN_CONST BfGeom& bg = a.b;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];   // [4 ring slots][4 waves x (Tx 8 KiB | Td 8 KiB)]
+  const int tid = threadIdx.x, lane = tid & 63, m = lane & 31, hh = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* Tx = reinterpret_cast<float*>(lds_raw + 4 * Ring<NT, NP>::SLOT + w * 16384);
+  float* Td = Tx + 32 * 64;
+  // a wave past the last point still moves its share of the panels and meets the barriers: it computes on clamped points
+  // and its output resource is empty
+  const int64_t p0 = ((int64_t)blockIdx.x * 4 + w) * 32;
+  const int64_t p = p0 + m;
+  const int nvalid = a.M - p0 < 32 ? (a.M - p0 > 0 ? (int)(a.M - p0) : 0) : 32;
+  const int64_t pc = p < a.M ? p : a.M - 1;
+  const int64_t ray = pc / a.S;
+  const BfPanel P{make_rsrc(a.pk, (unsigned)bg.total), (m * 2 + hh) * 16};
+  Ring<NT, NP> R;
+  {
+    const unsigned long long ba = (unsigned long long)a.pk;
+    R.rs = i32x4{__builtin_amdgcn_readfirstlane((int)(ba & 0xffffffffu)), __builtin_amdgcn_readfirstlane((int)((ba >> 32) & 0xffff)),
+                 __builtin_amdgcn_readfirstlane((int)bg.total), 0x00027000};
+  }
+  R.lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)lds_raw);
+  R.ring = lds_raw;
+  R.w = w;
+  R.lane16 = lane * 16;
+  R.rd16 = (m * 2 + hh) * 16;
+  // start the panel stream before anything else: K-steps 0 and 1 of layer 0
+  R.dma((int)bg.p_l0, 0, 0);
+  R.dma((int)bg.p_l0, 1, 1);
+
+  float x[3] = {0.f, 0.f, 0.f}, v[3] = {0.f, 0.f, 0.f};
+  if (a.pts != nullptr) {
+    x[0] = a.pts[pc * 3 + 0]; x[1] = a.pts[pc * 3 + 1]; x[2] = a.pts[pc * 3 + 2];
+  } else if (a.cam.on) {
+    float o[3], d[3];
+    cn_gen_ray(a.cam, a.cam.first + ray, o, d, v);
+    const float zz = a.z[pc];
+    x[0] = o[0] + d[0] * zz; x[1] = o[1] + d[1] * zz; x[2] = o[2] + d[2] * zz;
+  } else {
+    const float* r = a.rays + ray * a.rs;
+    const float zz = a.z[pc];
+    x[0] = r[0] + r[3] * zz; x[1] = r[1] + r[4] * zz; x[2] = r[2] + r[5] * zz;   // R:384 (no FMA contraction)
+  }
+  if (!(a.pts == nullptr && a.cam.on)) {
+    const float* dsrc = a.dirs != nullptr ? a.dirs + ray * 3 : a.rays + ray * a.rs + (a.rs - 3);
+    v[0] = dsrc[0]; v[1] = dsrc[1]; v[2] = dsrc[2];
+  }
+  encode(Tx, x, g.L, g.in_ch, g.in_chp, m, hh, nullptr);
+  encode(Td, v, g.Ld, g.dir_ch, g.dir_chp, m, hh, nullptr);
+
+  f32x16 X[NT], Y[NT];
+  bias_init<NT>(Y, P, (int)bg.b_trunk[0], hh);
+  pin<NT>(Y);                                  // (the bias loads are older than nothing the ring waits for below)
+  R.template publish<Ring<NT, NP>::PW>();      // K-step 0 of layer 0 has landed everywhere
+  gemm_ring_lds<4, NT, NT, NP>(Y, Tx, R, (int)bg.p_l0, (int)(g.D > 1 ? bg.p_trunk[1] : bg.p_feat), m, hh);
+  pin<NT>(Y);
+  float sig = 0.f;
+  auto layer = [&](f32x16 (&In)[NT], f32x16 (&Out)[NT], int l) __attribute__((always_inline)) {
+    if (l == g.D) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) In[t][r] = fmaxf(In[t][r], 0.f);
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 wq = buf_load(P.rs, hh * 16, (int)bg.v_alpha + (32 * t + 8 * q) * 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) sig = __builtin_fmaf(In[t][4 * q + j], wq[j], sig);
+        }
+      sig += __shfl_xor(sig, 32, 64);
+      sig += *reinterpret_cast<const float*>(a.pk + bg.b_alpha);
+    }
+    bias_init<NT>(Out, P, (int)(l < g.D ? bg.b_trunk[l] : bg.b_feat), hh);
+    pin<NT>(Out);      // the bias loads retire (compiler waitcnt) before the ring's own vmcnt bookkeeping resumes
+    const bool skip = l == g.skip + 1;
+    // what follows this layer's register GEMM in the stream: its own gamma(x) segment, the next layer, or the view branch
+    const int nxt = skip ? (int)bg.p_skip : (l + 1 < g.D ? (int)bg.p_trunk[l + 1] : (l + 1 == g.D ? (int)bg.p_feat : (int)bg.p_views));
+    gemm_ring_reg<NT, NT, NT, NP, true>(Out, In, R, (int)(l < g.D ? bg.p_trunk[l] : bg.p_feat), nxt);
+    if (skip) {
+      pin<NT>(Out);
+      gemm_ring_lds<4, NT, NT, NP>(Out, Tx, R, (int)bg.p_skip, (int)(l + 1 < g.D ? bg.p_trunk[l + 1] : bg.p_feat), m, hh);
+    }
+    pin<NT>(Out);
+  };
+  const int nl = g.D;
+  for (int l = 1; l <= nl; l += 2) {
+    layer(Y, X, l);
+    if (l + 1 <= nl) layer(X, Y, l + 1);
+  }
+  if (nl & 1) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) Y[t] = X[t];
+  }
+  f32x16 V[NTH];
+  bias_init<NTH>(V, P, (int)bg.b_views, hh);
+  pin<NTH>(V);
+  gemm_ring_reg<NT, NTH, NT, NP, false>(V, Y, R, (int)bg.p_views, (int)bg.p_viewsd);
+  pin<NTH>(V);
+  gemm_ring_lds<2, NTH, NT, NP>(V, Td, R, (int)bg.p_viewsd, -1, m, hh);
+  float o[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int t = 0; t < NTH; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 wq = buf_load(P.rs, hh * 16, (int)bg.v_rgb + (c * (W / 2) + 32 * t + 8 * q) * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[c] = __builtin_fmaf(fmaxf(V[t][4 * q + j], 0.f), wq[j], o[c]);
+      }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) o[c] += __shfl_xor(o[c], 32, 64);
+  const float* brgb = reinterpret_cast<const float*>(a.pk + bg.b_rgb);
+  const rsrc_t ors = make_rsrc(a.raw + (nvalid > 0 ? p0 : 0) * 4, (unsigned)(nvalid * 16));
+  if (hh == 0) buf_store(ors, m * 16, 0, f32x4{o[0] + brgb[0], o[1] + brgb[1], o[2] + brgb[2], sig});
+}
+
+template <int NT, int NP>
+int launch_bfs(const BfArgs& a, hipStream_t st) {
+  const size_t lds = (size_t)4 * Ring<NT, NP>::SLOT + 4 * 16384;
+  static bool attr_set[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return CNERF_E_NODEVICE;
+  if (!attr_set[dev]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_bfs_k<NT, NP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+      return (int)hipGetLastError();
+    attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL((mlp_fwd_bfs_k<NT, NP>), dim3((unsigned)cn_div_up(a.M, 128)), dim3(256), lds, st, a);
+  CN_CHECK_LAUNCH();
+  return CNERF_OK;
+}
+
 template <int NT>
 int launch_bf(const BfArgs& a, int NP, hipStream_t st) {
+  // shared-panel kernel by default; the per-wave one on request (CNERF_BF_PERWAVE=1: A/B measurements) or when the
+  // encodings are not the 64- / 32-channel tiles its unrolled K-steps assume
+  const char* e = getenv("CNERF_BF_PERWAVE");
+  if (!(e && e[0] == '1') && a.g.in_chp == 64 && a.g.dir_chp == 32) {
+    switch (NP) {
+      case 1: return launch_bfs<NT, 1>(a, st);
+      case 2: return launch_bfs<NT, 2>(a, st);
+      case 3: return launch_bfs<NT, 3>(a, st);
+      default: return CNERF_E_ARG;
+    }
+  }
   const unsigned grid = (unsigned)cn_div_up(a.M, 32);
   switch (NP) {
     case 1: hipLaunchKernelGGL((mlp_fwd_bf_k<NT, 1>), dim3(grid), dim3(64), 0, st, a); break;
@@ -385,7 +680,7 @@ extern "C" int cnerf_pack_weights_bf(const cnerf_net* net, const cnerf_ptrs* par
   a.njobs = a.ncopies = 0; a.NP = planes; a.out = static_cast<unsigned char*>(packed_bf);
   const int W = g.W, Wh = g.Wh, D = g.D;
   auto panel = [&](const float* src, int ld, int col0, int N, int K, int Kp, int kind, int64_t dst) {
-    a.job[a.njobs++] = BfPackJob{src, ld, col0, N, K, Kp, kind, dst};
+    a.job[a.njobs++] = BfPackJob{src, ld, col0, N, K, g.NT, Kp, kind, dst};
   };
   auto copy = [&](const float* src, int n, int64_t dst) { a.cp[a.ncopies++] = BfCopyJob{src, n, dst}; };
   auto Wt = [&](int l) { return params->p[2 * l]; };

@@ -61,8 +61,12 @@ def main():
         for planes in (1, 2, 3):
             pk = ops.pack_weights_bf(spec, m.kernel_tensors(), planes)
             t_bf = timeit(lambda: ops.mlp_forward_bf(spec, pk, planes, B, S, rays=rays, z=z))
+            os.environ["CNERF_BF_PERWAVE"] = "1"
+            t_pw = timeit(lambda: ops.mlp_forward_bf(spec, pk, planes, B, S, rays=rays, z=z))
+            del os.environ["CNERF_BF_PERWAVE"]
             print(f"          fwd bf16 x{planes} (inference, opt-in) {t_bf:7.3f} ms = {tf('fwd', t_bf):7.1f} TFLOP/s fp32-equivalent, "
-                  f"{t_inf / t_bf:5.2f}x the fp32 kernel", flush=True)
+                  f"{t_inf / t_bf:5.2f}x the fp32 kernel  (per-wave panel streaming instead of the shared LDS ring: {t_pw:7.3f} ms)",
+                  flush=True)
         if S == 192:
             keep = (spec, packed, d_raw, B, S, stash)
         else:                                   # both levels are around: the paired backward (one dgrad + one wgrad grid)
