@@ -405,6 +405,7 @@ struct Ring {
     static_assert(OUTSTANDING >= 0 && OUTSTANDING < 64, "vmcnt range");
 #ifdef CN_BF_SYNC
     __builtin_amdgcn_s_waitcnt(0x0f70);
+    (void)OUTSTANDING;
 #else
     __builtin_amdgcn_s_waitcnt(0x0f70 | (OUTSTANDING & 15) | ((OUTSTANDING >> 4) << 14));   // vmcnt only (gfx9 encoding)
 #endif
@@ -636,8 +637,11 @@ template <int NT>
 int launch_bf(const BfArgs& a, int NP, hipStream_t st) {
   // shared-panel kernel by default; the per-wave one on request (CNERF_BF_PERWAVE=1: A/B measurements) or when the
   // encodings are not the 64- / 32-channel tiles its unrolled K-steps assume
+  // (W = 128 with one plane — 4 pieces per K-step, one per wave — also takes the per-wave kernel: the shared one returned
+  //  wrong values for a varying subset of waves there on the MI355X, also with every wait at vmcnt(0); all other shapes are
+  //  bit-identical to the per-wave kernel over repeated runs, which the GPU suite checks)
   const char* e = getenv("CNERF_BF_PERWAVE");
-  if (!(e && e[0] == '1') && a.g.in_chp == 64 && a.g.dir_chp == 32) {
+  if (!(e && e[0] == '1') && a.g.in_chp == 64 && a.g.dir_chp == 32 && NT * NP >= 8) {
     switch (NP) {
       case 1: return launch_bfs<NT, 1>(a, st);
       case 2: return launch_bfs<NT, 2>(a, st);
