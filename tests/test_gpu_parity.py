@@ -1877,3 +1877,90 @@ def test_bf16_plane_inference_is_opt_in_and_never_trains(dev):
                 R.render_rays(rays, **kw)
     finally:
         coarse.inference_precision = fine.inference_precision = "fp32"
+
+
+DIST2_GPU_WORKER = r"""
+import os, sys, tempfile, numpy as np, torch
+ROOT = sys.argv[1]
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import _inputs as I
+from test_gpu_parity import _view_args
+from consistentnerf_amd import distributed as D, run_nerf_view as V
+import torch.distributed as dist
+dev = torch.device("cuda:0")                       # both ranks share the box's one GPU; the exchange goes through gloo
+rank, world, _ = D.init_from_env("gloo")
+assert world == 2 and dist.get_backend() == "gloo"
+
+def run(sharded):
+    with tempfile.TemporaryDirectory() as tmp:
+        kw, _, start, grad_vars, opt = V.create_nerf(_view_args(tmp))
+    for net, seed in ((kw["network_fn"], 51), (kw["network_fine"], 52)):
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in I.nerf_state_dict(4, 128, 10, 4, 5, True, seed=seed, gain=0.6).items()})
+    kw.update(near=2.0, far=6.0, perturb=0.0)       # deterministic sampling: the sharded and the whole batch see the same rays
+    opt.param_groups[0]["clip_value"] = 0.1
+    red = D.GradReducer(opt, [kw["network_fn"], kw["network_fine"]], mean=False) if sharded else None
+    K = I.intrinsics(100, 100, 138.0)
+    losses = []
+    for i in range(3):
+        rays = torch.from_numpy(I.ray_batch(512, seed=300 + i)).to(dev)
+        rs = np.random.RandomState(400 + i)
+        target = torch.from_numpy(rs.uniform(size=(512, 3)).astype(np.float32)).to(dev)
+        prior = torch.from_numpy(rs.uniform(2, 6, size=(512,)).astype(np.float32)).to(dev)
+        mask = torch.from_numpy((rs.uniform(size=(512,)) < 0.6).astype(np.float32)).to(dev)
+        counts = None
+        if sharded:
+            rays, target, prior, mask = D.shard_batch(rays, target, prior, mask)
+            counts = D.global_mask_counts(mask)          # all-reduced: the GLOBAL set sizes
+        rgb, disp, acc, depth, ex = V.render(100, 100, K, chunk=32768, rays=torch.stack([rays[:, 0:3], rays[:, 3:6]], 0),
+                                             retraw=True, **kw)
+        opt.zero_grad()
+        il, dl = V.hardmask_losses(rgb, target, mask, 0.2, depth, prior, 6.0, counts=counts)
+        il0, dl0 = V.hardmask_losses(ex["rgb0"], target, mask, 0.2, ex["depth0"], prior, 6.0, counts=counts)
+        loss = il + dl + il0 + dl0
+        loss.backward()
+        if sharded:
+            red.finish()
+            loss = D.allreduce_scalar_sum(loss.detach())
+        opt.step()
+        losses.append(float(loss))
+    torch.cuda.synchronize()
+    return opt.flat_param.clone(), losses
+
+p_sh, l_sh = run(True)           # 2 ranks x 256 rays, flat gradient all-reduced per network slice
+p_1, l_1 = run(False)            # the same 512-ray steps on one rank (every rank computes it: the reference trajectory)
+# replicas stay identical
+chk = p_sh.clone(); dist.broadcast(chk, 0)
+assert torch.equal(chk, p_sh), "ranks diverged"
+rel_l = max(abs(a - b) / abs(b) for a, b in zip(l_sh, l_1))
+# Adam normalises the step: a gradient element near zero whose sign differs by summation order moves a weight by ~lr, so
+# the bound on the weights is a few lr (3 steps of 5e-4), the bound on the losses is tight
+dmax = float((p_sh - p_1).abs().max())
+frac = float(((p_sh - p_1).abs() > 1e-6).float().mean())
+assert rel_l < 1e-5, (l_sh, l_1)
+assert dmax < 2e-3 and frac < 0.02, (dmax, frac)
+D.barrier()
+if rank == 0:
+    print("DIST2_GPU_OK", l_sh, l_1, dmax, frac)
+dist.destroy_process_group()
+"""
+
+
+def test_two_ranks_product_step_on_one_gpu(dev, tmp_path):
+    """The product path of the data-parallel step with WORLD SIZE 2: two processes (both on the box's one MI355X, the
+    collectives through gloo, which stages device tensors through the host) shard each 512-ray batch, all-reduce the mask
+    counts, render + backward through the HIP kernels into their FusedAdam.flat_grad, exchange it with GradReducer (one
+    all-reduce per network slice, issued from inside loss.backward()) and step.  After 3 steps the replicas are identical,
+    the summed losses equal the single-rank losses of the whole batch (1e-5), and the weights agree up to Adam's sensitivity
+    to the summation order of near-zero gradient elements."""
+    import subprocess
+    import sys
+    script = tmp_path / "dist2_gpu_worker.py"
+    script.write_text(DIST2_GPU_WORKER)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29591", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    env.pop("CNERF_FORCE_DIST", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29591", str(script), root], capture_output=True, text=True, env=env,
+                       timeout=900)
+    print(r.stdout[-1500:])
+    assert r.returncode == 0 and "DIST2_GPU_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
