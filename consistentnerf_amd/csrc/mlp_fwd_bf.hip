@@ -397,18 +397,19 @@ struct Ring {
       dma1k(rs, lds0 + (unsigned)(slot * SLOT + i * 1024), lane16, poff + (s * PIECES + i) * 1024);
     }
   }
+  // piece j (0..PW-1) of this wave's quarter: dealt out one per tile by the register-operand GEMM (a VMEM instruction
+  // holds the in-order wave until the address unit takes it: four in a row cost 16-22 % of the kernel, measured)
+  __device__ __forceinline__ void dma_piece(int poff, int s, int slot, int j) const {
+    const int i = w + 4 * j;
+    dma1k(rs, lds0 + (unsigned)(slot * SLOT + i * 1024), lane16, poff + (s * PIECES + i) * 1024);
+  }
   __device__ __forceinline__ u32x4 a(int slot, int t, int p) const {
     return *reinterpret_cast<const u32x4*>(ring + slot * SLOT + (t * NP + p) * 1024 + rd16);
   }
   template <int OUTSTANDING>
   __device__ __forceinline__ void publish() const {   // own DMA pieces older than the newest OUTSTANDING have landed
     static_assert(OUTSTANDING >= 0 && OUTSTANDING < 64, "vmcnt range");
-#ifdef CN_BF_SYNC
-    __builtin_amdgcn_s_waitcnt(0x0f70);
-    (void)OUTSTANDING;
-#else
     __builtin_amdgcn_s_waitcnt(0x0f70 | (OUTSTANDING & 15) | ((OUTSTANDING >> 4) << 14));   // vmcnt only (gfx9 encoding)
-#endif
     __syncthreads();
   }
 };
@@ -439,9 +440,11 @@ __device__ __forceinline__ void gemm_ring_reg(f32x16 (&Q)[NTO], const f32x16 (&X
         for (int p = 0; p < NP; ++p) A[(t + 2) % 3][p] = R.a(s & 3, t + 2, p);
       }
       products<NP>(Q[t], A[t % 3], bc);
-      if (t == 0) {       // the DMA of K-step s+2, behind the first MFMAs (in front of them it would delay the first LDS reads)
-        if (s + 2 < KS) R.dma(poff, s + 2, (s + 2) & 3);
-        else if (poff_next >= 0) R.dma(poff_next, s + 2 - KS, (s + 2) & 3);
+      // the DMA of K-step s+2, one piece behind each tile's MFMAs (all of them in front would delay the first LDS reads)
+#pragma unroll
+      for (int j = t; j < PW; j += NTO) {
+        if (s + 2 < KS) R.dma_piece(poff, s + 2, (s + 2) & 3, j);
+        else if (poff_next >= 0) R.dma_piece(poff_next, s + 2 - KS, (s + 2) & 3, j);
       }
       if (s + 1 < KS && t < 4) {
         const int sn = s + 1;
