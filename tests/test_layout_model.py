@@ -255,3 +255,83 @@ def test_wgrad_point_contraction():
         for j in range(4):
             acc = mfma_32x32x2(a4[:, j], b4[:, j], acc)
     assert np.allclose(acc_to_dense([acc], 1), XT @ YT.T)
+
+
+# ---- opt-in bf16-plane inference forward (csrc/mlp_fwd_bf.hip) -------------------------------------------------------------
+def bf16_rne(x):
+    """round-to-nearest-even bf16 of float32 values, returned as float32 (pack_bf_k / v_cvt_pk_bf16_f32)."""
+    u = np.asarray(x, np.float32).view(np.uint32)
+    h = ((u + 0x7fff + ((u >> 16) & 1)) >> 16).astype(np.uint32)
+    return (h << 16).view(np.float32)
+
+
+def split_planes(x, NP):
+    out, r = [], np.asarray(x, np.float32)
+    for _ in range(NP):
+        p = bf16_rne(r)
+        out.append(p)
+        r = (r - p).astype(np.float32)        # exact: what this plane left over
+    return out
+
+
+def mfma_32x32x16(a, b, c):
+    """v_mfma_f32_32x32x16_bf16: a, b [64, 8] per-lane operands (lane l: row / column l&31, k = 8 (l>>5) + e); c [64, 16]."""
+    A = np.zeros((32, 16)); B = np.zeros((16, 32))
+    for e in range(8):
+        A[I31, 8 * HH + e] = a[:, e]
+        B[8 * HH + e, I31] = b[:, e]
+    D = A @ B
+    out = c.copy()
+    for r in range(16):
+        out[:, r] += D[(r & 3) + 8 * (r >> 2) + 4 * HH, I31]
+    return out
+
+
+def test_bf16_plane_layer_chain():
+    """The layout contract of mlp_fwd_bf.hip: K-step s = (tile s>>1, half s&1) of a register-operand GEMM takes registers
+    r = 8 half + e of the previous layer's C-layout tile as the 8 bf16 of lane (m, hh), and pack_bf_k stores the weights in
+    the matching k order 32t + 16 half + 8(e>>2) + 4hh + (e&3); LDS-operand panels use k = 16s + 8hh + e.  Two chained
+    layers through the lane model with 2 planes (3 cross terms) against dense fp64 matmuls, and the error ordering of
+    1 / 2 / 3 planes."""
+    rs = np.random.RandomState(3)
+    W_, K0 = 64, 32                               # a 64-wide layer fed by a 32-channel "encoding", then 64 -> 64
+    W0 = rs.normal(size=(W_, K0)).astype(np.float32) * 0.3
+    W1 = rs.normal(size=(W_, W_)).astype(np.float32) * 0.2
+    X = rs.normal(size=(32, K0)).astype(np.float32)          # 32 points
+    ref1 = np.maximum(X.astype(np.float64) @ W0.T.astype(np.float64), 0) @ W1.T.astype(np.float64)
+    errs = {}
+    for NP in (1, 2, 3):
+        prods = [(i, s_ - i) for s_ in range(NP - 1, -1, -1) for i in range(s_ + 1)]
+        Wp0, Wp1 = split_planes(W0, NP), split_planes(W1, NP)
+        NT = W_ // 32
+        # layer 0: B operand from the "LDS tile": lane (m, hh), element e of K-step s = channel 16s + 8hh + e
+        acc = [np.zeros((64, 16)) for _ in range(NT)]
+        for s_ in range(K0 // 16):
+            ch = 16 * s_ + 8 * HH[:, None] + np.arange(8)[None, :]
+            bpl = split_planes(X[I31[:, None], ch], NP)
+            for t in range(NT):
+                apl = [Wp0[p][32 * t + I31[:, None], ch] for p in range(NP)]     # pack kind 0
+                for i, j in prods:
+                    acc[t] = mfma_32x32x16(apl[i], bpl[j], acc[t])
+        # layer 1: B operand = relu of layer 0's accumulators, 8 registers at a time
+        out = [np.zeros((64, 16)) for _ in range(NT)]
+        for s_ in range(2 * NT):
+            t_in, half = s_ >> 1, s_ & 1
+            e = np.arange(8)[None, :]
+            xs = np.maximum(acc[t_in][:, 8 * half:8 * half + 8], 0).astype(np.float32)
+            bpl = split_planes(xs, NP)
+            feat = 32 * t_in + 16 * half + 8 * (e >> 2) + 4 * HH[:, None] + (e & 3)   # pack kind 1
+            # the C layout puts exactly that feature in register 8 half + e of lane (m, hh)
+            r = 8 * half + e
+            assert np.array_equal(feat, 32 * t_in + (r & 3) + 8 * (r >> 2) + 4 * HH[:, None])
+            for t in range(NT):
+                apl = [Wp1[p][32 * t + I31[:, None], feat] for p in range(NP)]
+                for i, j in prods:
+                    out[t] = mfma_32x32x16(apl[i], bpl[j], out[t])
+        got = np.zeros((32, W_))
+        for t in range(NT):
+            for r in range(16):
+                got[I31, 32 * t + (r & 3) + 8 * (r >> 2) + 4 * HH] = out[t][:, r]
+        errs[NP] = np.abs(got - ref1).max() / np.abs(ref1).max()
+    assert errs[1] < 3e-2 and errs[2] < 2e-4 and errs[3] < 2e-6, errs
+    assert errs[1] > 20 * errs[2] > 400 * errs[3] / 20 or errs[3] < 1e-7, errs
