@@ -170,10 +170,12 @@ def run_oracle(a):
 
 
 # ------------------------------------------------------------------------------------------------ GPU side
-def hip_run(seed, steps):
+def hip_run(seed, steps, nudged=False):
     from consistentnerf_amd import run_nerf as R
     dev = torch.device("cuda:0")
     K, bank, target, test_rays, test_rgb, sds = scene(seed)
+    if nudged:
+        sds = ulp_nudge(sds, seed)
     args = argparse.Namespace(
         multires=10, i_embed=0, use_viewdirs=True, multires_views=4, N_importance=128, netdepth=8, netwidth=256,
         netdepth_fine=8, netwidth_fine=256, netchunk=1024 * 64, lrate=LRATE, basedir=tempfile.mkdtemp(), expname="p",
@@ -217,11 +219,14 @@ def run_hip(a):
     for s in seeds:
         t0 = time.perf_counter()
         hl, hp, himg = hip_run(s, steps)
+        _, hp_n, himg_n = hip_run(s, steps, nudged=True)      # the HIP path's own chaos control (cheap: seconds per run)
         ol, op, oimg = ref[f"s{s}_ref_loss"], float(ref[f"s{s}_ref_psnr"]), ref[f"s{s}_ref_img"]
         cl, cp, cimg = ref[f"s{s}_ctl_loss"], float(ref[f"s{s}_ctl_psnr"]), ref[f"s{s}_ctl_img"]
         first_div = lambda x, y, tol: int(np.argmax(np.abs(x - y) > tol * np.abs(y))) if np.any(np.abs(x - y) > tol * np.abs(y)) else steps  # noqa: E731
         rows.append({
             "seed": s, "heldout_psnr_hip_dB": hp, "heldout_psnr_oracle_dB": op, "heldout_psnr_oracle_1ulp_dB": cp,
+            "heldout_psnr_hip_1ulp_dB": hp_n, "gap_hip1ulp_minus_hip_dB": hp_n - hp,
+            "image_psnr_hip1ulp_vs_hip_dB": psnr_img(himg_n, himg),
             "gap_hip_minus_oracle_dB": hp - op, "gap_control_minus_oracle_dB": cp - op,
             "image_psnr_hip_vs_oracle_dB": psnr_img(himg, oimg), "image_psnr_control_vs_oracle_dB": psnr_img(cimg, oimg),
             "final_loss_hip": float(hl[-1]), "final_loss_oracle": float(ol[-1]), "final_loss_control": float(cl[-1]),
@@ -235,6 +240,9 @@ def run_hip(a):
         print(json.dumps(rows[-1]), flush=True)
     gap = np.array([r["gap_hip_minus_oracle_dB"] for r in rows])
     ctl = np.array([r["gap_control_minus_oracle_dB"] for r in rows])
+    hctl = np.array([r["gap_hip1ulp_minus_hip_dB"] for r in rows])
+    means = {k: float(np.mean([r[k] for r in rows])) for k in ("heldout_psnr_hip_dB", "heldout_psnr_hip_1ulp_dB",
+                                                               "heldout_psnr_oracle_dB", "heldout_psnr_oracle_1ulp_dB")}
     n = len(rows)
     sd = lambda x: float(np.std(x, ddof=1)) if n > 1 else None  # noqa: E731
     summary = {
@@ -244,6 +252,7 @@ def run_hip(a):
         "gap_mean_dB": float(gap.mean()), "gap_std_dB": sd(gap), "gap_sem_dB": (sd(gap) / np.sqrt(n)) if n > 1 else None,
         "control_mean_dB": float(ctl.mean()), "control_std_dB": sd(ctl), "control_rms_dB": float(np.sqrt(np.mean(ctl ** 2))),
         "abs_gap_mean_dB": float(np.abs(gap).mean()), "abs_control_mean_dB": float(np.abs(ctl).mean()),
+        "hip_control_rms_dB": float(np.sqrt(np.mean(hctl ** 2))), "mean_heldout_psnr_dB": means,
         "parity": bool(abs(gap.mean()) <= np.sqrt(np.mean(ctl ** 2))),
         "criterion": "|mean gap| <= rms of the control gap (the 1-sigma chaos spread about 0)",
         "runs": rows,
