@@ -159,7 +159,7 @@ def run_oracle(a):
     avail = sorted(os.sched_getaffinity(0))
     jobs = []
     for k, (s, n) in enumerate((s, n) for s in a.seeds for n in (False, True)):
-        cores = set(avail[(k * a.cores_per_worker) % len(avail):][:a.cores_per_worker]) if a.cores_per_worker else None
+        cores = set(avail[(a.core_offset + k * a.cores_per_worker) % len(avail):][:a.cores_per_worker]) if a.cores_per_worker else None
         jobs.append((s, n, milestones, a.threads, cores, partdir))
     print(f"{len(jobs)} jobs, {a.workers} workers x {a.threads} threads, {a.cores_per_worker} cores each of {len(avail)} usable; "
           f"milestones {milestones}", flush=True)
@@ -271,6 +271,7 @@ def main():
     o.add_argument("--workers", type=int, default=5)
     o.add_argument("--threads", type=int, default=1, help="ATen threads per worker")
     o.add_argument("--cores-per-worker", type=int, default=0, help="pin worker k to its own block of this many cores (0: no pinning)")
+    o.add_argument("--core-offset", type=int, default=0, help="first core of worker 0 (a second invocation beside a running one)")
     o.add_argument("--milestones", type=int, nargs="*", default=[300, 450], help="also evaluate + save at these step counts")
     mg = sub.add_parser("merge", help="assemble <out> from the milestone files of an interrupted oracle run")
     mg.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_psnr_oracle.npz"))
