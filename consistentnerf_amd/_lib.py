@@ -96,6 +96,8 @@ SIGNATURES = {
     "cnerf_loss_ws_floats": (_i64, []),
     "cnerf_masked_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
     "cnerf_patch_depth_loss": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp, _vp]),
+    "cnerf_adam_hyper": (_i, [_i, C.c_double, C.c_double, C.c_double, C.c_double, _f, _f, _vp]),
+    "cnerf_adam_step_dev": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "cnerf_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _i, C.c_double, C.c_double, C.c_double, C.c_double, _f, _f, _vp]),
 }
 

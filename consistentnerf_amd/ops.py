@@ -498,3 +498,20 @@ def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float, 
     _lib.check(_lib.load().cnerf_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), int(step), float(lr), float(beta1),
                                            float(beta2), float(eps), float(clip), float(grad_scale), _stream()),
                "cnerf_adam_step")
+
+
+def adam_hyper(out_host: Tensor, step: int, lr: float, beta1=0.9, beta2=0.999, eps=1e-8, clip: float = 0.0,
+               grad_scale: float = 1.0):
+    """cnerf_adam_hyper: the 8 scalars of step `step` into a (pinned) HOST float tensor."""
+    if out_host.is_cuda or out_host.dtype != torch.float32 or out_host.numel() < 8 or not out_host.is_contiguous():
+        raise CnerfError("adam_hyper: need a contiguous fp32 host tensor of 8 floats")
+    _lib.check(_lib.load().cnerf_adam_hyper(int(step), float(lr), float(beta1), float(beta2), float(eps), float(clip),
+                                            float(grad_scale), C.c_void_p(out_host.data_ptr())), "cnerf_adam_hyper")
+
+
+def adam_step_dev(p: Tensor, g: Tensor, m: Tensor, v: Tensor, hyp_dev: Tensor):
+    for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v"), (hyp_dev, "hyp")):
+        if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32):
+            raise CnerfError(f"adam_step_dev: {n} must be a contiguous fp32 GPU tensor")
+    _lib.check(_lib.load().cnerf_adam_step_dev(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(hyp_dev), _stream()),
+               "cnerf_adam_step_dev")

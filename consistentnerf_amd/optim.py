@@ -25,6 +25,7 @@ class FusedAdam:
             raise ops.CnerfError("FusedAdam needs GPU parameters (no CPU path)")
         self.param_groups = [dict(params=self.params, lr=lr, betas=betas, eps=eps, clip_value=clip_value)]
         self._step = 0
+        self._hyp_host = self._hyp_dev = None
         sizes = [p.numel() for p in self.params]
         self._offsets = [0]
         for n in sizes:
@@ -59,11 +60,34 @@ class FusedAdam:
 
     def step(self, grad_scale: float = 1.0):
         g = self.param_groups[0]
-        self._step += 1
-        ops.adam_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self._step, g['lr'],
-                      g['betas'][0], g['betas'][1], g['eps'], g.get('clip_value', 0.0), grad_scale)
+        if self._hyp_host is not None:
+            # graph-capturable form (graph.GraphedStep): the scalars of the step live in device memory, refreshed from a
+            # pinned host buffer by a copy that is part of the captured graph; `advance()` rewrites the host buffer
+            if not torch.cuda.is_current_stream_capturing():
+                self.advance(grad_scale)
+            self._hyp_dev.copy_(self._hyp_host, non_blocking=True)
+            ops.adam_step_dev(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self._hyp_dev)
+        else:
+            self._step += 1
+            ops.adam_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self._step, g['lr'],
+                          g['betas'][0], g['betas'][1], g['eps'], g.get('clip_value', 0.0), grad_scale)
         for p in self.params:   # the kernel wrote behind autograd's back: invalidate packed-weight caches
             p._cnerf_epoch = getattr(p, "_cnerf_epoch", 0) + 1
+
+    def make_capturable(self):
+        """Switch to the device-scalar Adam kernel so that step() can sit inside a captured hipGraph."""
+        if self._hyp_host is None:
+            self._hyp_host = torch.zeros(8, dtype=torch.float32).pin_memory()
+            self._hyp_dev = torch.zeros(8, device=self.flat_param.device, dtype=torch.float32)
+        return self
+
+    def advance(self, grad_scale: float = 1.0):
+        """Host half of a capturable step: count it and write its scalars (incl. the current param_groups lr) to the pinned
+        buffer the captured copy reads.  GraphedStep calls this before every replay."""
+        g = self.param_groups[0]
+        self._step += 1
+        ops.adam_hyper(self._hyp_host, self._step, g['lr'], g['betas'][0], g['betas'][1], g['eps'], g.get('clip_value', 0.0),
+                       grad_scale)
 
     def state_dict(self):
         state = {}

@@ -224,6 +224,9 @@ def pytest_uniform(shape, device):
     return torch.from_numpy(np.random.rand(*shape).astype(np.float32)).to(device)
 
 
+_DET_U = {}
+
+
 def sample_u(B, N_samples, det, pytest, device):
     """u for sample_pdf (H:214-229)."""
     if pytest:
@@ -231,8 +234,11 @@ def sample_u(B, N_samples, det, pytest, device):
             u = np.broadcast_to(np.linspace(0., 1., N_samples), (B, N_samples)).astype(np.float32)
             return torch.from_numpy(u[:1].copy()).to(device)   # identical rows: broadcast in the kernel
         return pytest_uniform((B, N_samples), device)
-    if det:
-        return torch.linspace(0., 1., steps=N_samples).to(device)[None]
+    if det:   # evaluated on the CPU like the reference's constant, cached per device (no H2D copy per chunk; graph-capturable)
+        key = (N_samples, str(device))
+        if key not in _DET_U:
+            _DET_U[key] = torch.linspace(0., 1., steps=N_samples).to(device)[None]
+        return _DET_U[key]
     return torch.rand(B, N_samples, device=device)
 
 

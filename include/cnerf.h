@@ -281,6 +281,13 @@ int cnerf_patch_depth_loss(const float* depth_pred, const float* mono, int P, in
 int cnerf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int step, double lr,
                     double beta1, double beta2, double eps, float clip, float grad_scale, void* stream);
 
+/* The same step with every scalar in DEVICE memory (hyp8_dev: 8 floats as cnerf_adam_hyper writes them on the host): nothing
+ * of the step is baked into the launch, so a captured hipGraph of the whole training step can be replayed while the host
+ * rewrites the pinned source of hyp8 between replays (graph.py). */
+int cnerf_adam_hyper(int step, double lr, double beta1, double beta2, double eps, float clip, float grad_scale,
+                     float* hyp8_host);
+int cnerf_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyp8_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

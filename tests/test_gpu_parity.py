@@ -1964,3 +1964,48 @@ def test_two_ranks_product_step_on_one_gpu(dev, tmp_path):
                        timeout=900)
     print(r.stdout[-1500:])
     assert r.returncode == 0 and "DIST2_GPU_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_graphed_step_equals_eager_steps(dev):
+    """graph.GraphedStep: the whole training step (render of both levels, fused losses, the merged backward, FusedAdam with its
+    scalars in device memory, weight packing) recorded once as a hipGraph and replayed — bit-identical to the same steps run
+    eagerly, with the batch and the decayed lr changing from step to step."""
+    import copy
+    from consistentnerf_amd import run_nerf as R
+    from consistentnerf_amd.graph import GraphedStep
+    from consistentnerf_amd.optim import FusedAdam
+
+    def build():
+        coarse, _ = make_model(4, 128, True, 5, 93, dev)
+        fine, _ = make_model(4, 128, True, 5, 94, dev)
+        kw = _kwargs(coarse, fine, 16, 16, 0.0, False, 0.0, False)
+        opt = FusedAdam(list(coarse.parameters()) + list(fine.parameters()), lr=5e-4, clip_value=0.1)
+
+        def step_fn(rays, tgt):
+            out = R.render_rays(rays, **kw)
+            opt.zero_grad()
+            loss = R.img2mse(out["rgb_map"], tgt) + R.img2mse(out["rgb0"], tgt)
+            loss.backward()
+            opt.step()
+            return loss
+        return opt, step_fn
+    batches = [(T(I.ray_batch(96, seed=40 + i), dev), torch.rand(96, 3, device=dev)) for i in range(6)]
+    lrs = [5e-4 * (0.1 ** (i / 3.0)) for i in range(6)]
+    # eager: 3 "warm-up" steps on batch 0 (what GraphedStep does before recording), then the six steps
+    opt_e, step_e = build()
+    opt_e.make_capturable()
+    for _ in range(3):
+        step_e(*batches[0])
+    le = []
+    for (rays, tgt), lr in zip(batches, lrs):
+        opt_e.param_groups[0]["lr"] = lr
+        le.append(step_e(rays, tgt).item())
+    opt_g, step_g = build()
+    gs = GraphedStep(step_g, opt_g, batches[0], warmup=3)
+    lg = []
+    for (rays, tgt), lr in zip(batches, lrs):
+        opt_g.param_groups[0]["lr"] = lr
+        lg.append(gs(rays, tgt).item())
+    assert le == lg, (le, lg)
+    assert torch.equal(opt_e.flat_param, opt_g.flat_param)
+    assert opt_e._step == opt_g._step == 9
