@@ -319,8 +319,17 @@ def main():
     import torch.distributed as dist
     from consistentnerf_amd import distributed as D, ops
     from consistentnerf_amd import run_nerf as R
-    rank, world, local = D.init_from_env("nccl" if (a.gpus > 1 or os.environ.get("CNERF_FORCE_DIST") == "1") else None)
+    # backend: RCCL ("nccl") for a real multi-GPU run.  CNERF_DIST_BACKEND=gloo lets the N>1 code path of this script (sharded
+    # steps, GradReducer, barrier, max-over-ranks) be exercised on a box with fewer GPUs than ranks — the ranks then share
+    # devices (rank % device_count) and the numbers mean nothing as a scaling measurement; the JSON's dist.backend says so.
+    backend = os.environ.get("CNERF_DIST_BACKEND", "nccl")
+    ngpu = torch.cuda.device_count()
+    if backend == "nccl" and int(os.environ.get("LOCAL_RANK", "0")) >= max(ngpu, 1):
+        raise SystemExit(f"LOCAL_RANK {os.environ.get('LOCAL_RANK')} but only {ngpu} GPU(s) visible: one rank per GPU over RCCL")
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(ngpu, 1))
+    rank, world, local = D.init_from_env(backend if (a.gpus > 1 or os.environ.get("CNERF_FORCE_DIST") == "1") else None)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    local = local % max(ngpu, 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if dist.is_initialized():   # build the RCCL communicator now (seconds), not inside the first step

@@ -26,7 +26,7 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
-            torch.cuda.set_device(local)
+            torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
