@@ -205,6 +205,25 @@ def hip_run(seed, steps, nudged=False):
                            **kw_test)
     img = img.cpu()
     mse = torch.mean((img - test_rgb) ** 2)
+    # the SAME trained model rendered through the opt-in reduced-precision inference forward (csrc/mlp_fwd_bf.hip): held-out
+    # PSNR against the ground truth and image PSNR against the fp32 render — the gate for that mode
+    reduced = {}
+    nets = [kw_test["network_fn"], kw_test["network_fine"]]
+    try:
+        for prec in ("bf16x3", "bf16x2", "bf16"):
+            for m_ in nets:
+                m_.inference_precision = prec
+            with torch.no_grad():
+                im, *_ = R.render(H, W, K, chunk=32768, rays=torch.stack([test_rays[:, 0:3], test_rays[:, 3:6]]).to(dev),
+                                  **kw_test)
+            im = im.cpu()
+            d2 = float(torch.mean((im - img) ** 2))
+            reduced[prec] = {"heldout_psnr_dB": (-10. * torch.log10(torch.mean((im - test_rgb) ** 2))).item(),
+                             "image_psnr_vs_fp32_render_dB": None if d2 == 0 else -10. * np.log10(d2)}
+    finally:
+        for m_ in nets:
+            m_.inference_precision = "fp32"
+    hip_run.reduced = reduced
     return torch.stack(losses).cpu().numpy(), (-10. * torch.log10(mse)).item(), img.numpy()
 
 
@@ -219,6 +238,7 @@ def run_hip(a):
     for s in seeds:
         t0 = time.perf_counter()
         hl, hp, himg = hip_run(s, steps)
+        reduced = hip_run.reduced
         _, hp_n, himg_n = hip_run(s, steps, nudged=True)      # the HIP path's own chaos control (cheap: seconds per run)
         ol, op, oimg = ref[f"s{s}_ref_loss"], float(ref[f"s{s}_ref_psnr"]), ref[f"s{s}_ref_img"]
         cl, cp, cimg = ref[f"s{s}_ctl_loss"], float(ref[f"s{s}_ctl_psnr"]), ref[f"s{s}_ctl_img"]
@@ -236,6 +256,7 @@ def run_hip(a):
             "mean_rel_loss_diff_hip": float(np.mean(np.abs(hl - ol) / ol)),
             "mean_rel_loss_diff_control": float(np.mean(np.abs(cl - ol) / ol)),
             "hip_seconds": time.perf_counter() - t0,
+            "hip_model_rendered_with_opt_in_precision": reduced,
         })
         print(json.dumps(rows[-1]), flush=True)
     gap = np.array([r["gap_hip_minus_oracle_dB"] for r in rows])
@@ -253,6 +274,11 @@ def run_hip(a):
         "control_mean_dB": float(ctl.mean()), "control_std_dB": sd(ctl), "control_rms_dB": float(np.sqrt(np.mean(ctl ** 2))),
         "abs_gap_mean_dB": float(np.abs(gap).mean()), "abs_control_mean_dB": float(np.abs(ctl).mean()),
         "hip_control_rms_dB": float(np.sqrt(np.mean(hctl ** 2))), "mean_heldout_psnr_dB": means,
+        "opt_in_precision_on_the_hip_trained_models": {
+            prec: {"mean_heldout_psnr_dB": float(np.mean([r["hip_model_rendered_with_opt_in_precision"][prec]["heldout_psnr_dB"] for r in rows])),
+                   "max_abs_heldout_psnr_change_vs_fp32_dB": float(np.max([abs(r["hip_model_rendered_with_opt_in_precision"][prec]["heldout_psnr_dB"] - r["heldout_psnr_hip_dB"]) for r in rows])),
+                   "min_image_psnr_vs_fp32_render_dB": float(np.min([r["hip_model_rendered_with_opt_in_precision"][prec]["image_psnr_vs_fp32_render_dB"] or 200.0 for r in rows]))}
+            for prec in ("bf16x3", "bf16x2", "bf16")},
         "parity": bool(abs(gap.mean()) <= np.sqrt(np.mean(ctl ** 2))),
         "criterion": "|mean gap| <= rms of the control gap (the 1-sigma chaos spread about 0)",
         "runs": rows,
