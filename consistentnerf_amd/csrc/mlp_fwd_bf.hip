@@ -110,10 +110,14 @@ struct BfArgs {
 
 #define CN_CONST __attribute__((address_space(4)))
 
+// v_cvt_pk_bf16_f32 (RNE).  Through the compiler, NOT inline asm: a VALU write needs two wait states before an MFMA reads
+// the register on gfx950, and the hazard recognizer only inserts them (s_nop 1) for instructions it knows to be VALU.  As
+// asm the conversion could sit one instruction in front of the MFMA that consumes it: that made the shared-panel kernel
+// wrong at W = 128 / one plane (tile 0 of every encoding GEMM).  scripts/isa_hazards.py checks the ISA for this pattern.
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
-  unsigned r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
 }
 
 // One register pair -> one dword of every plane (element 2q in the low half, 2q+1 in the high half).
@@ -369,9 +373,6 @@ __global__ __launch_bounds__(64) void mlp_fwd_bf_k(BfArgs args_by_value) {
 // Every GEMM has a multiple of 4 K-steps (the last one excepted), so each starts at slot 0 and hands the ring over to the
 // next panel (whose first two K-steps it prefetches) without draining it.
 typedef int i32x4 __attribute__((ext_vector_type(4)));
-#ifndef CN_BF_MIN_PIECES
-#define CN_BF_MIN_PIECES 8
-#endif
 
 __device__ __forceinline__ void dma1k(const i32x4& rs, unsigned lds_addr, int voff, int soff) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
@@ -412,8 +413,12 @@ struct Ring {
   template <int OUTSTANDING>
   __device__ __forceinline__ void publish() const {   // own DMA pieces older than the newest OUTSTANDING have landed
     static_assert(OUTSTANDING >= 0 && OUTSTANDING < 64, "vmcnt range");
+    // nothing is scheduled across the publish: the ring's only writer is the DMA asm, which the machine scheduler does not
+    // see as a store to the LDS the next K-step's ds_reads load from
+    __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_waitcnt(0x0f70 | (OUTSTANDING & 15) | ((OUTSTANDING >> 4) << 14));   // vmcnt only (gfx9 encoding)
     __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
   }
 };
 
@@ -643,12 +648,8 @@ template <int NT>
 int launch_bf(const BfArgs& a, int NP, hipStream_t st) {
   // shared-panel kernel by default; the per-wave one on request (CNERF_BF_PERWAVE=1: A/B measurements) or when the
   // encodings are not the 64- / 32-channel tiles its unrolled K-steps assume
-  // (W = 128 with one plane — 4 pieces per K-step, one per wave — also takes the per-wave kernel: the shared one returns
-  //  wrong values for most waves there on the MI355X; not a publish race (the same with every wait at vmcnt(0), with 256
-  //  idle cycles before each barrier, and with one workgroup per CU) and not understood.  All other shapes are bit-identical
-  //  to the per-wave kernel over repeated launches, which the GPU suite checks.  -DCN_BF_MIN_PIECES=4 re-enables it.)
   const char* e = getenv("CNERF_BF_PERWAVE");
-  if (!(e && e[0] == '1') && a.g.in_chp == 64 && a.g.dir_chp == 32 && NT * NP >= CN_BF_MIN_PIECES) {
+  if (!(e && e[0] == '1') && a.g.in_chp == 64 && a.g.dir_chp == 32) {
     switch (NP) {
       case 1: return launch_bfs<NT, 1>(a, st);
       case 2: return launch_bfs<NT, 2>(a, st);

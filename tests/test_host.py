@@ -257,3 +257,39 @@ def test_header_is_plain_c_and_the_c_example_links(tmp_path):
                         str(hdr_only), "-o", str(tmp_path / "h")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     assert subprocess.run([str(tmp_path / "h")]).returncode == 0
+
+
+def test_no_inline_asm_valu_next_to_mfma(tmp_path):
+    """The hazard recognizer cannot see a VALU instruction inside an asm statement, so it does not insert the wait states
+    gfx950 needs between such a write and an MFMA reading it (nor between an MFMA and such a read).  scripts/isa_hazards.py
+    scans the device ISA of every MFMA kernel for both patterns; a synthetic positive control proves it can find them."""
+    root = os.path.join(os.path.dirname(__file__), "..")
+    sys.path.insert(0, os.path.join(root, "scripts"))
+    import isa_hazards
+    ctl = tmp_path / "ctl.s"
+    ctl.write_text("probe_k:\n"
+                   "\t;;#ASMSTART\n\tv_cvt_pk_bf16_f32 v5, v12, v13\n\t;;#ASMEND\n"
+                   "\tds_read_b128 v[10:13], v133 offset:5120\n"
+                   "\tv_mfma_f32_32x32x16_bf16 a[0:15], v[6:9], v[2:5], a[0:15]\n"
+                   "\t;;#ASMSTART\n\tv_pk_mul_f32 v[20:21], a[0:1], v[30:31]\n\t;;#ASMEND\n"
+                   ".Lfunc_end0:\n")
+    found = isa_hazards.check(str(ctl))
+    assert len(found) == 2 and "2 required" in found[0] and "11 required" in found[1], found
+    ok = tmp_path / "ok.s"
+    ok.write_text("probe_k:\n"
+                  "\t;;#ASMSTART\n\tv_cvt_pk_bf16_f32 v5, v12, v13\n\t;;#ASMEND\n"
+                  "\ts_nop 1\n"
+                  "\tv_mfma_f32_32x32x16_bf16 a[0:15], v[6:9], v[2:5], a[0:15]\n"
+                  ".Lfunc_end0:\n")
+    assert isa_hazards.check(str(ok)) == []
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    files = "mlp_fwd mlp_bwd wgrad mlp_fwd_bf"
+    r = subprocess.run(["bash", os.path.join(root, "scripts", "isa_stats.sh"), str(tmp_path)],
+                       env=dict(os.environ, FILES=files), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    found = []
+    for f in files.split():
+        found += isa_hazards.check(str(tmp_path / f"{f}.s"))
+    assert not found, "\n".join(found[:10])
