@@ -107,21 +107,28 @@ __global__ __launch_bounds__(64) void mlp_dgrad_k(BwdArgs args_by_value) {
     pin<NT>(X);
     CN_T(2)
     // dZ_{D-1} = relu'(h_{D-1}) * (feature_linear^T . dF + alpha_linear^T . dsigma)
-    a_prefetch3<NT>(A, AP, (int)g.t_feat, W, W / 8 - 1);
+    // (only the first A set before the sigma-head quads: all three next to X, the quads and their products do not fit the
+    //  arch-VGPR half of the register file; sets 1 and 2 are needed 32 and 64 MFMAs into the GEMM)
+    a_load<NT>(A[0], AP, (int)g.t_feat, W, 0);
     load_bits<MD>(srs, smo, tm_col(g.s_mask + g.s_mb[g.D - 1]), bits);
     {
-      f32x4 wq[NT][4];
+      // the weight quads land in Y's own registers and are scaled in place (all loads in flight before the first use: one
+      // exposed L2 round trip; a separate staging array would be 128 more live registers next to X, Y and A)
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) wq[t][q] = buf_load(AP.rs, hh * 16, (int)(g.v_alpha + 32 * t + 8 * q) * 4);
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 wq = buf_load(AP.rs, hh * 16, (int)(g.v_alpha + 32 * t + 8 * q) * 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) Y[t][4 * q + j] = wq[j];
+        }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) Y[t][4 * q + j] = wq[t][q][j] * dc[3];
+        for (int r = 0; r < 16; ++r) Y[t][r] *= dc[3];
+      a_load<NT>(A[1], AP, (int)g.t_feat, W, 1);
+      a_load<NT>(A[2], AP, (int)g.t_feat, W, 2);
     }
     CN_T(4)
     gemm_reg3<NT, NT, false, false>(Y, X, A, AP, (int)g.t_feat, W, hh, TileStores<NT, NT>{X, grs, gvo, tm_col(g.g_feat)});

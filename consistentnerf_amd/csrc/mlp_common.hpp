@@ -53,6 +53,11 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* base, unsigned bytes) {
 __device__ __forceinline__ f32x4 buf_load(rsrc_t r, int voff, int soff) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
+// one float at a wave-uniform index of a buffer (biases of the VALU heads): through the resource, not the raw pointer — a
+// global load keeps the 64-bit base in a VGPR pair for the whole kernel
+__device__ __forceinline__ float buf_load1(rsrc_t r, int index) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, 0, index * 4, 0));
+}
 __device__ __forceinline__ void buf_store(rsrc_t r, int voff, int soff, const f32x4& v) {
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
 }
@@ -89,6 +94,16 @@ __device__ __forceinline__ void load_bits(rsrc_t r, int voff, int soff, unsigned
 
 // ---- A operand -----------------------------------------------------------------------------------------------------
 // The packed weight blob behind ONE buffer resource + this lane's byte offset inside a 32-row x 8-k tile piece.
+// x[lane] + x[lane ^ 32] in every lane, without a lane index: v_permlane32_swap exchanges the upper half of one register
+// with the lower half of the other, so swapping x with itself leaves (lo, lo) and (hi, hi) — their sum is lo + hi in all 64
+// lanes, the same two addends as x + __shfl_xor(x, 32) (which costs the lane id in a long-lived register + a ds_bpermute).
+__device__ __forceinline__ float half_sum(float x) {
+  typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+  const unsigned u = __builtin_bit_cast(unsigned, x);
+  const u32x2_t r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);   // (not __builtin_bit_cast: on a vector ELEMENT it reads element 0)
+}
+
 struct APanel {
   rsrc_t rs;
   int lane;     // ((lane & 31) * 8 + 4 * (lane >> 5)) * 4

@@ -141,8 +141,8 @@ __global__ __launch_bounds__(64) void mlp_fwd_k(FwdArgs args_by_value) {
             for (int j = 0; j < 4; ++j) sig = __builtin_fmaf(In[t0 + t][4 * q + j], wq[t][q][j], sig);
         __builtin_amdgcn_sched_barrier(0);
       }
-      sig += __shfl_xor(sig, 32, 64);
-      sig += a.packed[g.b_alpha];
+      sig = half_sum(sig);
+      sig += buf_load1(AP.rs, (int)g.b_alpha);
     }
     CN_T(3)
     if (TRAIN)
@@ -195,10 +195,10 @@ __global__ __launch_bounds__(64) void mlp_fwd_k(FwdArgs args_by_value) {
             for (int j = 0; j < 4; ++j) o[c] = __builtin_fmaf(X[t][4 * q + j], wv[j], o[c]);
           }
 #pragma unroll
-    for (int c = 0; c < 8; ++c) o[c] += __shfl_xor(o[c], 32, 64);
+    for (int c = 0; c < 8; ++c) o[c] = half_sum(o[c]);
     if (hh == 0)
       for (int c = 0; c < g.out_ch; ++c)
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o[c] + a.packed[g.b_out + c]), ors,
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o[c] + buf_load1(AP.rs, (int)g.b_out + c)), ors,
                                               (m * g.out_ch + c) * 4, 0, 0);
     CN_T(4)
     CN_TEND
@@ -246,10 +246,10 @@ __global__ __launch_bounds__(64) void mlp_fwd_k(FwdArgs args_by_value) {
             for (int j = 0; j < 4; ++j) o[c] = __builtin_fmaf(V[t][4 * q + j], wq[c][t][q][j], o[c]);
     }
 #pragma unroll
-    for (int c = 0; c < 3; ++c) o[c] += __shfl_xor(o[c], 32, 64);
+    for (int c = 0; c < 3; ++c) o[c] = half_sum(o[c]);
     if (hh == 0)
-      buf_store(ors, m * 16, 0, f32x4{o[0] + a.packed[g.b_rgb + 0], o[1] + a.packed[g.b_rgb + 1],
-                                      o[2] + a.packed[g.b_rgb + 2], sig});
+      buf_store(ors, m * 16, 0, f32x4{o[0] + buf_load1(AP.rs, (int)g.b_rgb + 0), o[1] + buf_load1(AP.rs, (int)g.b_rgb + 1),
+                                      o[2] + buf_load1(AP.rs, (int)g.b_rgb + 2), sig});
     CN_T(4)
     CN_TEND
   }

@@ -28,4 +28,26 @@ for f in sys.argv[2:]:
         nm = len(re.findall(r"\bv_mfma", b)); ns = len(re.findall(r"\bscratch_", b))
         dem = name
         print(f"{dem[:58]:58s} {m[0]:4d} {m[1]:4d} {m[2]:4d} {m[3]:6d} {m[4]:6d} {m[5]:8d} {nm:5d} {ns:6d}")
+# where the remaining spill traffic sits: scratch instructions (VGPR spills) and lane moves (SGPR spills) by the number of
+# MFMAs issued before them
+print()
+for f in sys.argv[2:]:
+    s = open(f"{out}/{f}.s").read()
+    for name in re.findall(r"\.name:\s+(\S+)", s):
+        body = re.search(rf"^{re.escape(name)}:(.*?)^\.Lfunc_end", s, re.S | re.M)
+        if not body:
+            continue
+        n, sites = 0, {}
+        for line in body.group(1).split("\n"):
+            t = line.strip().split()
+            if not t:
+                continue
+            if t[0].startswith("v_mfma"):
+                n += 1
+            elif t[0].startswith("scratch_") or t[0] in ("v_readlane_b32", "v_writelane_b32"):
+                sites[(n, t[0])] = sites.get((n, t[0]), 0) + 1
+        if sites:
+            print(f"{name} ({n} MFMAs)")
+            for (k, ins), c in sorted(sites.items()):
+                print(f"   mfma# {k:5d}  {c:3d} x {ins}")
 PY
