@@ -19,7 +19,9 @@ import torch
 class GraphedStep:
     def __init__(self, step_fn: Callable[..., torch.Tensor], optimizer, example_inputs: Sequence[torch.Tensor], warmup: int = 3):
         """step_fn(*inputs) -> loss runs ONE full step (render, loss, zero_grad, backward, optimizer.step()) on tensors of
-        the shapes of `example_inputs`; it must not read host-side state that changes between steps."""
+        the shapes of `example_inputs`; it must not read host-side state that changes between steps.  The `warmup` runs
+        before the recording are REAL steps on `example_inputs` (they move the weights and Adam's state, like `warmup`
+        ordinary training steps on that batch); the recording itself executes nothing."""
         self.opt = optimizer.make_capturable()
         self.static_in = [t.clone() for t in example_inputs]
         side = torch.cuda.Stream()
