@@ -301,8 +301,9 @@ def pmc_traffic(kernel, points):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=10)
+    # defaults: a timed region of ~5 s (200 x 26 ms), long enough for a coarse (seconds) GPU-busy sampler to see it
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the C5 / C3 legs that follow the timed C2 region at N=1")
     ap.add_argument("--graph", action="store_true",
