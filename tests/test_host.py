@@ -293,3 +293,18 @@ def test_no_inline_asm_valu_next_to_mfma(tmp_path):
     for f in files.split():
         found += isa_hazards.check(str(tmp_path / f"{f}.s"))
     assert not found, "\n".join(found[:10])
+    # register-file facts DESIGN.md quotes (same toolchain as the build): the D=8/W=256 dgrad and inference forward keep
+    # everything in registers, wgrad has no scratch, nothing exceeds the 512-register budget of one wave per SIMD
+    meta = {}
+    for f in ("mlp_fwd", "mlp_bwd", "wgrad"):
+        txt = (tmp_path / f"{f}.s").read_text()
+        for blk in re.findall(r"- \.agpr_count:.*?\.wavefront_size", txt, re.S):
+            name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+            meta[name] = {k: int(re.search(rf"\.{k}:\s+(\d+)", blk).group(1))
+                          for k in ("vgpr_count", "vgpr_spill_count", "sgpr_spill_count", "private_segment_fixed_size")}
+    pick = lambda frag: next(v for k, v in meta.items() if frag in k)
+    assert pick("mlp_dgrad_kILi8ELb1E")["vgpr_spill_count"] == 0 and pick("mlp_dgrad_kILi8ELb1E")["private_segment_fixed_size"] == 0
+    assert pick("mlp_fwd_kILi8ELb1ELb0E")["vgpr_spill_count"] == 0
+    assert pick("wgrad_kENS")["private_segment_fixed_size"] == 0 and pick("wgrad_kENS")["vgpr_spill_count"] == 0
+    assert all(v["vgpr_count"] <= 512 for v in meta.values())
+    assert pick("mlp_fwd_kILi8ELb1ELb1E")["sgpr_spill_count"] == 0 and pick("mlp_fwd_kILi8ELb1ELb1E")["vgpr_spill_count"] <= 8
