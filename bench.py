@@ -1,28 +1,45 @@
 #!/usr/bin/env python3
 """bench.py — training ray-samples/sec of the MI355X NeRF hot path (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--scaling weak|strong] [--rays-per-gpu R] [--graph] [--pmc]
   (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
 
 One "step" = one full optimisation step of BASELINE config C2 on synthetic DTU-like data, per GPU:
-4096 rays -> coarse 64 samples -> fine 64+128 samples (D=8/W=256 MLPs with view directions, stratified
+R rays -> coarse 64 samples -> fine 64+128 samples (D=8/W=256 MLPs with view directions, stratified
 jitter, hierarchical resampling) -> mse(rgb)+mse(rgb0) -> backward (dgrad+wgrad of both nets) ->
-[N>1: one RCCL all-reduce of the flat fp32 gradient] -> Adam + lr decay.  1 048 576 ray-samples per GPU per
-step (64 + 192 network evaluations per ray); weak scaling (every rank renders its own 4096-ray
-slice of the global batch).  Inputs (ray bank, targets, weights) are resident in HBM before the timed region.
+[N>1: one RCCL all-reduce of the flat fp32 gradient, 1/N folded into the Adam kernel] -> Adam + lr decay.
+256 ray-samples per ray (64 + 192 network evaluations).  Inputs (ray bank, targets, weights) are
+resident in HBM before the timed region.
+
+  --scaling weak   (default) R = 4096 rays per GPU, global batch 4096*N: BASELINE configs[1] at N=1.
+  --scaling strong the 4096-ray C2 batch sharded N ways, R = 4096/N rays per GPU — BASELINE configs[3] (C4) as SURVEY §8(e)
+                   defines it: same global batch as 1 GPU.
+  --rays-per-gpu R times exactly that per-GPU shard (e.g. `--gpus 1 --rays-per-gpu 512` = the per-GPU work of the 8-way C4
+                   shard on one GPU); `config.workload` names it.
+  --graph          replay the step as captured hipGraphs (consistentnerf_amd/graph.py): one graph at N=1; at N>1 two graphs
+                   around the eager gradient exchange (--graph-collective split, default) or the RCCL all-reduce recorded
+                   inside one graph (--graph-collective capture).
+  --pmc            re-runs this command twice under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes,
+                   kernel-trace only) and fills roofline.traffic from THOSE runs instead of the committed lookup.
 
 Extra objects on the JSON line:
   roofline     — dominant kernel of the step, algorithmic FLOPs per launch / its average duration measured
                  with HIP events on the launch stream inside the timed region; peak = fp32 MFMA 157.3 TFLOP/s.
   cpu_baseline — the CPU oracle ("port" of the reference step: stock ATen, fp32) timed on this host's cores on
                  a bounded sample (rank 0, N=1 only).
-  dist         — what the gradient exchange did: ranks RCCL saw, message count / bytes per step, and the part of the
+  dist         — what the gradient exchange did: ranks RCCL saw, backend, message count / bytes per step, and the part of the
                  exchange the step waited for (HIP events on the launch stream).  Present whenever a process group
                  exists (N>1, or CNERF_FORCE_DIST=1 on one GPU).
-  extra        — (N=1, after the timed C2 region, not part of `value`) BASELINE configs[4] and configs[2] under the same
-                 clock: c5 = one 756x1008 NDC frame through render() (perturb=0, chunk 32768) incl. the D2H of the frame;
-                 c3 = 20 training steps with hard masks + masked rgb/depth losses on both levels + the monocular patch
-                 term + clip 0.1 + Adam.  --no-extra skips them.
+  extra        — (after the timed region, not part of `value`)
+                 N=1: c4_shard = the 512-ray per-GPU step of the 8-way strong-scaling shard, eager and graphed, with its
+                 per-kernel table; c5 = BASELINE configs[4]: render_path over 4 poses of the 60-pose LLFF spiral, 756x1008 NDC
+                 frames (perturb=0, chunk 32768) incl. the D2H of every frame; c3 = configs[2]: 20 training steps with hard masks
+                 + masked rgb/depth losses on both levels + the monocular patch term + clip 0.1 + Adam; hbm_kernels = the
+                 HBM-bound kernels of the path (compositing fwd/bwd, resampling, losses, Adam, weight packing) against the 8 TB/s
+                 roof at the C2 batch and at the C5 chunk.
+                 N>1 (weak run): c4_strong = the same process group timing the 4096-ray batch sharded N ways, eager and
+                 graphed (split), under a watchdog that prints the line without this leg if it does not finish.
+                 --no-extra skips them.
 """
 import argparse
 import json
@@ -68,103 +85,154 @@ def build_ray_bank(device, seed=0):
     return K, rays, target
 
 
+def physical_cores():
+    """(physical cores this process may run on, usable logical cpus): distinct (package, core id) pairs of the cpus in the
+    affinity mask, from /proc/cpuinfo; falls back to the logical count."""
+    try:
+        avail = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = list(range(os.cpu_count() or 1))
+    try:
+        cores, cur = {}, {}
+        for line in open("/proc/cpuinfo"):
+            if ":" in line:
+                k, v = [x.strip() for x in line.split(":", 1)]
+                cur[k] = v
+            elif cur:
+                if "processor" in cur:
+                    cores[int(cur["processor"])] = (cur.get("physical id", "0"), cur.get("core id", cur["processor"]))
+                cur = {}
+        if cur and "processor" in cur:
+            cores[int(cur["processor"])] = (cur.get("physical id", "0"), cur.get("core id", cur["processor"]))
+        phys = len({cores[c] for c in avail if c in cores})
+        return (phys or len(avail)), len(avail)
+    except OSError:
+        return len(avail), len(avail)
+
+
 def cpu_baseline(seconds_budget=25.0):
-    """The CPU oracle's training step (same workload shape, B=256 rays) on this host's cores."""
+    """The CPU oracle's training step (the C2 shapes: 64+192 samples, D=8/W=256, fwd+bwd+Adam) on this host's cores.
+    Headline figure: B = 1024 rays on min(physical cores, 32) threads — ATen's intra-op parallelism stops
+    scaling on 256x256 GEMMs well before 32 threads; a second figure at threads = ALL physical cores (count printed) is
+    measured on a bounded probe and, when it is not slower, on the full batch; a single-thread figure on 64 rays."""
     import _inputs as I
     from oracle import nerf_oracle as O
-    # threads: the cores this process may run on, capped at 32 (ATen's intra-op parallelism stops scaling —
-    # and with hundreds of threads on 256x256 GEMMs it collapses — well before that)
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    ncores = max(1, min(avail, 32))
-    torch.set_num_threads(ncores)
-    Bc = 256
+    phys, avail = physical_cores()
+    ncores = max(1, min(phys, 32))
     sd = [O.as_tensors(I.nerf_state_dict(8, 256, 10, 4, 5, True, seed=s), True) for s in (21, 22)]
     net, cfg = O.NetCfg(8, 256, output_ch=5), O.RenderCfg(NC, NF, 1.0)
-    rays = torch.from_numpy(I.ray_batch(Bc, seed=3, near=NEAR, far=FAR))
-    target = torch.rand(Bc, 3)
+    rays_all = torch.from_numpy(I.ray_batch(1024, seed=3, near=NEAR, far=FAR))
+    target_all = torch.rand(1024, 3)
     params = [p for d in sd for p in d.values()]
     m = [torch.zeros_like(p) for p in params]
     v = [torch.zeros_like(p) for p in params]
+    count = [0]
 
-    def step(i):
-        out = O.render_rays(rays, sd[0], sd[1], net, cfg, torch.rand(Bc, NC), torch.rand(Bc, NF))
-        loss = O.mse(out["rgb_map"], target) + O.mse(out["rgb0"], target)
+    def step(Bc):
+        count[0] += 1
+        out = O.render_rays(rays_all[:Bc], sd[0], sd[1], net, cfg, torch.rand(Bc, NC), torch.rand(Bc, NF))
+        loss = O.mse(out["rgb_map"], target_all[:Bc]) + O.mse(out["rgb0"], target_all[:Bc])
         grads = torch.autograd.grad(loss, params, allow_unused=True)
         with torch.no_grad():
             for p, g, mm, vv in zip(params, grads, m, v):
                 if g is not None:
-                    O.adam_step(p, g, mm, vv, i + 1, 5e-4)
-    tw = time.perf_counter()
-    step(0)
-    tw = time.perf_counter() - tw
-    t0, n = time.perf_counter(), 0
-    while n < 1 or (time.perf_counter() - t0 + tw < seconds_budget and n < 20):
-        step(n + 1)
-        n += 1
-    dt = (time.perf_counter() - t0) / n
-    # single-thread figure (SURVEY §8d asks for both): one warm + one timed step of 64 rays
-    torch.set_num_threads(1)
-    Bc1 = 64
-    rays1, target1 = rays[:Bc1], target[:Bc1]
+                    O.adam_step(p, g, mm, vv, count[0], 5e-4)
 
-    def step1(i):
-        out = O.render_rays(rays1, sd[0], sd[1], net, cfg, torch.rand(Bc1, NC), torch.rand(Bc1, NF))
-        loss = O.mse(out["rgb_map"], target1) + O.mse(out["rgb0"], target1)
-        grads = torch.autograd.grad(loss, params, allow_unused=True)
-        with torch.no_grad():
-            for p, g, mm, vv in zip(params, grads, m, v):
-                if g is not None:
-                    O.adam_step(p, g, mm, vv, n + 2 + i, 5e-4)
-    step1(0)
-    t1 = time.perf_counter()
-    step1(1)
-    dt1 = time.perf_counter() - t1
-    # all usable cores (SURVEY 8d asks for the figure even where it is slower: the 32-thread cap above is then evidence, not
-    # assertion): ATen's intra-op parallelism collapses on these GEMM sizes with hundreds of threads, so the probe is ONE step
-    # of the 64-ray batch (a 256-ray step takes over a minute on 256 threads)
-    all_val = None
-    if avail > ncores:
-        torch.set_num_threads(avail)
-        ta = time.perf_counter()
-        step1(2)
-        ta = time.perf_counter() - ta
-        all_val = Bc1 * (NC + NC + NF) / ta
+    def timed(Bc, threads, budget, max_steps=20):
+        torch.set_num_threads(threads)
+        t0 = time.perf_counter()
+        step(Bc)                               # warm-up (also the bound on what the timed steps will cost)
+        tw = time.perf_counter() - t0
+        if tw > budget:                        # one step already blew the budget: report it rather than spend more
+            return Bc * (NC + NC + NF) / tw, 1, tw
+        t0, n = time.perf_counter(), 0
+        while n < 1 or (time.perf_counter() - t0 + tw < budget and n < max_steps):
+            step(Bc)
+            n += 1
+        dt = (time.perf_counter() - t0) / n
+        return Bc * (NC + NC + NF) / dt, n, dt
+
+    # 256-ray probe decides whether the 1024-ray batch fits the budget (3.4 s/step expected at 32 threads)
+    v256, _, dt256 = timed(256, ncores, 6.0, max_steps=2)
+    Bc = 1024 if 4 * dt256 * 3 < seconds_budget else 256
+    val, n, dt = timed(Bc, ncores, seconds_budget - 8.0)
+    # all physical cores: a 32-ray probe first (on hundreds of threads a step can collapse to minutes)
+    phys_val = phys_sample = None
+    if phys > ncores:
+        pv, _, pdt = timed(32, phys, 0.0)
+        phys_val, phys_sample = pv, f"one 32-ray step, {pdt:.2f} s"
+        if pv > 0.5 * val:
+            pv2, pn, pdt2 = timed(256, phys, 8.0, max_steps=3)
+            phys_val, phys_sample = pv2, f"{pn} steps of 256 rays, {pdt2:.2f} s/step"
+    v1, _, dt1 = timed(64, 1, 0.0)
     torch.set_num_threads(ncores)
-    return {"value": Bc * (NC + NC + NF) / dt, "unit": "ray-samples/s", "cores": ncores, "kind": "port",
-            "single_thread_value": Bc1 * (NC + NC + NF) / dt1, "all_cores_value": all_val, "all_cores": avail,
+    best, cores = (val, ncores) if (phys_val is None or val >= phys_val) else (phys_val, phys)
+    return {"value": best, "unit": "ray-samples/s", "cores": cores, "kind": "port",
+            "threads_main": ncores, "value_main": val, "physical_cores": phys, "value_physical_cores": phys_val,
+            "sample_physical_cores": phys_sample, "single_thread_value": v1, "logical_cpus_usable": avail,
             "sample": f"{n} training steps of {Bc} rays (same C2 shapes: 64+192 samples, D=8/W=256, fwd+bwd+Adam), "
-                      f"{dt:.2f} s/step, torch {torch.__version__} CPU fp32, {ncores} threads of {avail} usable / "
-                      f"{os.cpu_count()} logical cpus"}
+                      f"{dt:.2f} s/step on {ncores} threads, torch {torch.__version__} CPU fp32; host has {phys} physical cores "
+                      f"({avail} usable logical cpus of {os.cpu_count()}); `value` = the better of the {ncores}-thread and the "
+                      f"{phys}-thread figure"}
 
 
-def c5_leg(dev):
-    """BASELINE configs[4]: one full-res LLFF frame (756x1008, NDC, 64 + 128 samples, D=8/W=256, perturb=0, chunk 32768)
-    through render(c2w=...) incl. the frame's D2H (render_path does it per frame, R:158)."""
+def llff_rig(n_views=6, seed=17):
+    """A seeded forward-facing rig of `n_views` cameras in the raw LLFF poses_bounds layout [N, 17] (load_llff.py:64-66)."""
+    rs = np.random.RandomState(seed)
+    arr = np.zeros((n_views, 17))
+    for k in range(n_views):
+        a, b = rs.uniform(-0.15, 0.15, 2)
+        Rm = np.array([[1, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]]) @ \
+            np.array([[np.cos(b), 0, np.sin(b)], [0, 1, 0], [-np.sin(b), 0, np.cos(b)]])
+        t = rs.uniform(-1.5, 1.5, 3) * [1, 0.6, 0.2]
+        arr[k, :15] = np.concatenate([Rm[:, [1, 0, 2]] * [1, -1, 1], t[:, None], np.array([[3024.], [4032.], [3260.]])], 1).reshape(-1)
+        arr[k, 15:] = [rs.uniform(8, 12), rs.uniform(60, 110)]
+    return arr
+
+
+def c5_leg(dev, n_frames=4):
+    """BASELINE configs[4]: LLFF 6-view full-res `render_path` (R:140-178) — `n_frames` poses of the 60-pose spiral
+    (load_llff.py:178-202) of a 6-view rig, 756x1008 NDC frames, 64 + 128 samples, D=8/W=256, perturb=0, chunk 32768, every
+    frame handed to the host as the reference does (R:157-159)."""
+    import contextlib
     import tempfile
-    import _inputs as I
-    from consistentnerf_amd import run_nerf as R
-    H, W, focal = 756, 1008, 815.0
+    from consistentnerf_amd import io_formats as F, run_nerf as R
+    H, W = 756, 1008
+    poses, bds, render_poses, i_test = F.llff_poses(llff_rig(6), (H, W), factor=4, n_render=60)
+    focal = float(poses[0, 2, 4])                                   # 3260 / 4 = 815
+    K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]], dtype=np.float32)
     a = make_args(tempfile.mkdtemp())
     a.dataset_type, a.no_ndc, a.raw_noise_std = "llff", False, 1.0
     torch.manual_seed(0)
     _, kw_test, *_ = R.create_nerf(a)
     kw_test.update(near=0.0, far=1.0)
-    K = I.intrinsics(H, W, focal)
-    poses = [torch.from_numpy(I.camera_pose(5.0 * i, 0.0, 4.0)) for i in range(2)]
-    with torch.no_grad():
-        R.render(H // 4, W // 4, K, chunk=32768, c2w=poses[0], **kw_test)      # warm-up (1/16 of a frame)
+    sel = [int(round(k * 60 / n_frames)) for k in range(n_frames)]   # spread over the spiral
+    rp = torch.from_numpy(render_poses[sel]).to(dev)
+    with torch.no_grad(), contextlib.redirect_stdout(sys.stderr):
+        R.render(H // 4, W // 4, K, chunk=32768, c2w=rp[0], **kw_test)      # warm-up (1/16 of a frame)
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        # per-frame host time: render_path prints it (R:147-149); measured here around single-pose calls of the same function
+        frame_s = []
+        t_all = time.perf_counter()
+        rgbs, disps = [], []
+        for k in range(n_frames):
+            t0 = time.perf_counter()
+            r_, d_ = R.render_path(rp[k:k + 1], (H, W, focal), K, 32768, kw_test)
+            frame_s.append(time.perf_counter() - t0)
+            rgbs.append(r_[0]); disps.append(d_[0])
+        dt_all = time.perf_counter() - t_all
+        # all frames in ONE render_path call, and through the sharded driver (world 1 here: in-kernel rays of the row block,
+        # D2H of frame i under the render of frame i+1)
         t0 = time.perf_counter()
-        e0.record()
-        rgb, disp, acc, extras = R.render(H, W, K, chunk=32768, c2w=poses[1], **kw_test)
-        e1.record()
-        rgb_host = rgb.cpu().numpy()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        rgbs2, _ = R.render_path(rp, (H, W, focal), K, 32768, kw_test)
+        dt_path = time.perf_counter() - t0
+        from consistentnerf_amd import distributed as D
+        t0 = time.perf_counter()
+        rgbs3, _ = D.render_path_sharded(rp, (H, W, focal), K, 32768, kw_test)
+        dt_sharded = time.perf_counter() - t0
+    rgb_host = np.stack(rgbs, 0)
+    same = bool(np.array_equal(rgb_host, rgbs2) and np.array_equal(rgb_host, rgbs3))
+    dt = float(np.median(frame_s))
     n = H * W * (NC + NC + NF)
     tf = n * 2 * MAC_FWD / dt / 1e12
     # the same frame through the OPT-IN reduced-precision inference forward (bf16 matrix cores, 1 / 2 / 3 bf16 planes per
@@ -177,14 +245,14 @@ def c5_leg(dev):
             for m in nets:
                 m.inference_precision = prec
             with torch.no_grad():
-                R.render(H // 4, W // 4, K, chunk=32768, c2w=poses[0], **kw_test)
+                R.render(H // 4, W // 4, K, chunk=32768, c2w=rp[0], **kw_test)
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                rgb_r, *_ = R.render(H, W, K, chunk=32768, c2w=poses[1], **kw_test)
+                rgb_r, *_ = R.render(H, W, K, chunk=32768, c2w=rp[1], **kw_test)
                 rgb_r_host = rgb_r.cpu().numpy()
                 torch.cuda.synchronize()
                 dtr = time.perf_counter() - t1
-            mse = float(np.mean((rgb_r_host.astype(np.float64) - rgb_host.astype(np.float64)) ** 2))
+            mse = float(np.mean((rgb_r_host.astype(np.float64) - rgb_host[1].astype(np.float64)) ** 2))
             reduced[prec] = {"frame_s": dtr, "speedup_vs_fp32": dt / dtr, "ray_samples_per_s": n / dtr,
                              "image_psnr_vs_fp32_render_dB": (None if mse == 0 else -10.0 * np.log10(mse)),
                              "dtype": {"bf16": "bf16 x bf16 -> f32", "bf16x2": "2 bf16 planes per operand, 3 cross terms -> f32",
@@ -192,12 +260,126 @@ def c5_leg(dev):
     finally:
         for m in nets:
             m.inference_precision = "fp32"
-    return {"frame_s": dt, "gpu_frame_s": e0.elapsed_time(e1) * 1e-3, "rays": H * W, "ray_samples_per_s": n / dt,
+    return {"frame_s": dt, "frames": n_frames, "frame_s_each": [round(x, 4) for x in frame_s], "spiral_pose_indices": sel,
+            "render_path_s": dt_path, "render_path_sharded_s": dt_sharded, "identical_frames_across_drivers": same,
+            "rays": H * W, "ray_samples_per_s": n / dt, "ray_samples_per_s_render_path": n * n_frames / dt_path,
             "opt_in_reduced_precision": reduced,
-            "frame": f"{H}x{W} NDC, chunk 32768, perturb 0, 64+128 samples, D=8 W=256 (random init), D2H of the frame included",
+            "frame": f"{H}x{W} NDC, chunk 32768, perturb 0, 64+128 samples, D=8 W=256 (random init), spiral poses of a 6-view LLFF "
+                     f"rig, D2H of every frame included",
             "finite": bool(np.isfinite(rgb_host).all()),
             "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4), "basis": "whole frame, 2*593408 FLOP per ray-sample"}}
+                         "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4), "basis": "median frame, 2*593408 FLOP per ray-sample"}}
+
+
+HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+
+
+def hbm_kernels(dev, reps=20):
+    """The HBM-bound kernels of the path, each timed alone with HIP events (`reps` back-to-back launches after a warm-up) on
+    synthetic inputs of the C2 batch (4096 rays) and of the C5 chunk (32768 rays): algorithmic bytes (SURVEY §8d per-unit
+    figures x units) / average launch time against the 8 TB/s roof."""
+    from consistentnerf_amd import ops
+    from consistentnerf_amd.run_nerf_helpers import NeRF
+    rows = []
+
+    def timeit(fn):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    def add(kernel, size, nbytes, ms, basis):
+        gbps = nbytes / (ms * 1e-3) / 1e9
+        rows.append({"kernel": kernel, "at": size, "bytes_algorithmic": int(nbytes), "avg_ms": round(ms, 5), "GBps": round(gbps, 1),
+                     "frac_of_8TBps": round(gbps / HBM_PEAK_GBPS, 4), "basis": basis})
+
+    g = torch.Generator(device="cpu").manual_seed(5)
+    for B, tag in ((4096, "C2 batch, 4096 rays"), (32768, "C5 chunk, 32768 rays")):
+        rays = torch.randn(B, 11, generator=g).to(dev)
+        rays[:, 6], rays[:, 7] = NEAR, FAR
+        for S in (NC, NC + NF):
+            raw = torch.randn(B, S, 4, generator=g).to(dev)
+            z = torch.sort(torch.rand(B, S, generator=g) * (FAR - NEAR) + NEAR, -1)[0].to(dev)
+            ms = timeit(lambda: ops.composite_forward(raw, z, rays, None, False))
+            add("composite_fwd_k", f"{tag}, S={S}", B * S * 24 + B * (44 + 28), ms, "24 B per ray-sample (raw 16 + z 4 in, weights 4 out) + 72 B per ray")
+            gr, gd = torch.randn(B, 3, generator=g).to(dev), torch.randn(B, generator=g).to(dev)
+            ms = timeit(lambda: ops.composite_backward(raw, z, rays, None, False, gr, None, None, gd))
+            add("composite_bwd_k", f"{tag}, S={S}", B * S * 36 + B * (44 + 16), ms, "36 B per ray-sample (raw 16 + z 4 in, d_raw 16 out) + 60 B per ray")
+        zc = torch.sort(torch.rand(B, NC, generator=g) * (FAR - NEAR) + NEAR, -1)[0].to(dev)
+        w = (torch.rand(B, NC, generator=g) ** 8).to(dev)
+        u = torch.rand(B, NF, generator=g).to(dev)
+        ms = timeit(lambda: ops.resample(zc, w, u))
+        add("resample_k", tag, B * 4 * (NC + NC + NF + NC + NF + 1), ms, "per ray: z 64 + weights 64 + u 128 floats in, z_fine 192 + z_std out = 1796 B")
+        x, y = torch.rand(B, 3, generator=g).to(dev), torch.rand(B, 3, generator=g).to(dev)
+        ms = timeit(lambda: ops.mse(x, y))
+        add("mse_k", tag, B * 3 * 12, ms, "12 B per element (x, y in, d_x out); one workgroup, fixed order")
+        d, pr, mk = torch.rand(B, generator=g).to(dev), torch.rand(B, generator=g).to(dev), (torch.rand(B, generator=g) < 0.6).float().to(dev)
+        ms = timeit(lambda: ops.masked_loss(x, y, d, pr, mk, FAR, 0.2))
+        add("masked_loss_k", tag, B * (24 + 12 + 12 + 4), ms, "52 B per ray (rgb, target, depth, prior, mask in; d_rgb, d_depth out)")
+    m = NeRF(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True).to(dev)
+    nparam = sum(p.numel() for p in m.kernel_tensors())
+    n2 = 2 * nparam
+    p_, g_, m_, v_ = (torch.rand(n2, device=dev) for _ in range(4))
+    ms = timeit(lambda: ops.adam_step(p_, g_, m_, v_, 3, 5e-4))
+    add("adam_k", f"{n2} parameters (coarse + fine)", n2 * 28, ms, "28 B per parameter (p, m, v read + written, g read)")
+    spec = m.spec()
+    packed = ops.pack_weights(spec, m.kernel_tensors())
+    ms = timeit(lambda: ops.pack_weights(spec, m.kernel_tensors(), packed))
+    add("pack_weights (per network)", f"{nparam} parameters -> {packed.numel()} packed floats", 4 * (nparam + packed.numel()), ms,
+        "parameters read once, forward + transposed panels written")
+    return {"peak_GBps": HBM_PEAK_GBPS, "reps": reps, "note": "each kernel alone, HIP events over back-to-back launches; these are "
+            "0.3 % of a C2 step (latency-bound at 4096 rays) — the table says how far from the HBM roof they sit at both sizes",
+            "kernels": rows}
+
+
+def pmc_rerun(per_rank, dom_kernel):
+    """--pmc: this benchmark re-run under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (one counter per pass, kernel
+    trace only — MI355X_MICROARCH.md's HBM recipe; counters cannot be sampled from inside the measuring process), a few steps
+    each; -> per-launch HBM bytes of the dominant kernel = 2 x FETCH_SIZE (gfx950: 16-byte-per-lane streaming reads are tallied
+    at half) + WRITE_SIZE, both in KB units."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    pat = {"mlp_wgrad": "wgrad_k", "mlp_dgrad": "mlp_dgrad_k", "mlp_fwd_train": "mlp_fwd_k", "mlp_fwd": "mlp_fwd_k"}[dom_kernel]
+    if shutil.which("rocprofv3") is None:
+        return {"traffic": None, "source": "rocprofv3 not on PATH"}
+    res, launches = {}, {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="cnerf_pmc_")
+        cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
+               sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "2", "--no-extra", "--no-cpu-baseline",
+               "--rays-per-gpu", str(per_rank)]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd="/tmp")
+        except subprocess.TimeoutExpired:
+            return {"traffic": None, "source": f"rocprofv3 --pmc {ctr} timed out"}
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            return {"traffic": None, "source": f"rocprofv3 --pmc {ctr} rc={r.returncode}: {r.stderr[-300:]}"}
+        vals = {}
+        for f in files:
+            for row in csv.DictReader(open(f)):
+                if pat in row["Kernel_Name"] and "reduce" not in row["Kernel_Name"] and row["Counter_Name"] == ctr:
+                    vals.setdefault(row["Dispatch_Id"], 0.0)
+                    vals[row["Dispatch_Id"]] += float(row["Counter_Value"])
+        if not vals:
+            return {"traffic": None, "source": f"no {pat} dispatch in the {ctr} pass"}
+        v = sorted(vals.values())
+        big = [x for x in v if x >= 0.5 * v[-1]]          # the largest launch size of that kernel (fine / merged level)
+        res[ctr], launches[ctr] = sum(big) / len(big) * 1024.0, len(big)
+        shutil.rmtree(d, ignore_errors=True)
+    return {"traffic": int(2 * res["FETCH_SIZE"] + res["WRITE_SIZE"]), "FETCH_SIZE_bytes_x2": int(2 * res["FETCH_SIZE"]),
+            "WRITE_SIZE_bytes": int(res["WRITE_SIZE"]), "launches_averaged": launches,
+            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of THIS command (3 steps each), per launch of the "
+                      "dominant kernel: 2*FETCH_SIZE + WRITE_SIZE"}
 
 
 def c3_leg(dev, steps=20):
@@ -298,17 +480,165 @@ def pmc_traffic(kernel, points):
     return None
 
 
+def per_kernel_table(prof, elapsed_ms):
+    """HIP-event records of ops._timed -> rows (kernel, points, launches, avg_ms, TFLOP/s, share of the timed region)."""
+    kern = {}
+    for nme, units, e0, e1 in prof:
+        k = kern.setdefault((nme, units), [0.0, 0])
+        k[0] += e0.elapsed_time(e1)
+        k[1] += 1
+    flops = {"mlp_fwd_train": 2 * MAC_FWD, "mlp_fwd": 2 * MAC_FWD, "mlp_dgrad": 2 * MAC_DGRAD, "mlp_wgrad": 2 * MAC_WGRAD}
+    table = []
+    for (nme, units), (ms, n) in kern.items():
+        if nme not in flops:
+            continue
+        avg_ms = ms / n
+        tf = flops[nme] * units / (avg_ms * 1e-3) / 1e12
+        table.append({"kernel": nme, "points": units, "launches": n, "avg_ms": round(avg_ms, 4), "tflops": round(tf, 2),
+                      "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4), "share_of_step": round(ms / elapsed_ms, 4)})
+    table.sort(key=lambda r: -r["avg_ms"] * r["launches"])
+    return table
+
+
+class Workload:
+    """The C2 training step on this rank's shard: model, optimizer, ray bank, exchange."""
+
+    def __init__(self, dev, rank, world, seed=1234):
+        import tempfile
+        import torch.distributed as dist
+        from consistentnerf_amd import distributed as D, run_nerf as R
+        self.R, self.D, self.dev, self.rank, self.world = R, D, dev, rank, world
+        torch.manual_seed(seed)                       # identical init on every rank (replicated weights)
+        with tempfile.TemporaryDirectory() as tmp:
+            self.kw, _, _, self.grad_vars, self.opt = R.create_nerf(make_args(tmp))
+        self.kw.update(near=NEAR, far=FAR)
+        self.K, self.bank, self.targets = build_ray_bank(dev)
+        torch.manual_seed(99 + rank)                  # per-rank jitter streams (RegNeRF/train.py:364-365 precedent)
+        # the step's gradient exchange: per-network slices of the flat fp32 gradient, all-reduced (RCCL) as _MlpFn.backward
+        # reports them final, the 1/world folded into the Adam kernel; a no-op without a process group
+        self.reducer = D.GradReducer(self.opt, [self.kw['network_fn'], self.kw['network_fine']], mean=True,
+                                     timing=dist.is_initialized(), fold_scale=True)
+
+    def fwd_bwd(self, rays, tgt):
+        R = self.R
+        rays_od = torch.stack([rays[:, 0:3], rays[:, 3:6]], 0)
+        rgb, disp, acc, extras = R.render(H_IMG, W_IMG, self.K, chunk=32768, rays=rays_od, retraw=True, **self.kw)
+        self.opt.zero_grad()
+        loss = R.img2mse(rgb, tgt) + R.img2mse(extras['rgb0'], tgt)
+        loss.backward()
+        return loss
+
+    def body(self, rays, tgt):
+        loss = self.fwd_bwd(rays, tgt)
+        self.reducer.finish()
+        self.opt.step(grad_scale=self.reducer.grad_scale)
+        return loss
+
+    def batch(self, i, per_rank):
+        """rank's contiguous slice of global batch i (every rank holds the identical, identically shuffled bank)"""
+        gstep = per_rank * self.world
+        lo = (i * gstep + self.rank * per_rank) % (self.bank.shape[0] - per_rank)
+        return self.bank[lo:lo + per_rank], self.targets[lo:lo + per_rank]
+
+    def graphed(self, per_rank, collective):
+        from consistentnerf_amd.graph import GraphedStep
+        ex = (self.bank[0:per_rank], self.targets[0:per_rank])
+        if self.world == 1 and not self.reducer_active():
+            return GraphedStep(self.body, self.opt, ex, warmup=3)
+        return GraphedStep(self.fwd_bwd, self.opt, ex, warmup=3, reducer=self.reducer, collective=collective)
+
+    def reducer_active(self):
+        import torch.distributed as dist
+        return dist.is_initialized()
+
+    def run(self, per_rank, steps, warmup, i0=0, graphed=None, profile=True):
+        """`warmup` untimed + `steps` timed steps bracketed by barrier + synchronize; -> (elapsed s (max over ranks), last
+        loss tensor, per-kernel HIP-event records)."""
+        from consistentnerf_amd import ops
+        import torch.distributed as dist
+
+        def step(i):
+            rays, tgt = self.batch(i, per_rank)
+            loss = graphed(rays, tgt) if graphed is not None else self.body(rays, tgt)
+            lr = 5e-4 * (0.1 ** (i / (250 * 1000)))
+            for pg in self.opt.param_groups:
+                pg['lr'] = lr
+            return loss
+        for i in range(warmup):
+            step(i0 + i)
+        torch.cuda.synchronize()
+        self.D.barrier()
+        torch.cuda.synchronize()
+        ops.PROFILE = [] if (profile and graphed is None) else None
+        self.reducer.exposed.clear()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            loss = step(i0 + warmup + i)
+        torch.cuda.synchronize()
+        self.D.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        prof, ops.PROFILE = (ops.PROFILE or []), None
+        if self.world > 1:
+            t = torch.tensor([elapsed], device=self.dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = t.item()
+        return elapsed, loss, prof
+
+    def host_enqueue_ms(self, per_rank, n=20):
+        """Host time to ENQUEUE one eager step (launch-side cost: ~100 ctypes / ATen launches + autograd), measured with the
+        GPU drained before and after so that the host never waits on it inside."""
+        ts = []
+        for i in range(n):
+            rays, tgt = self.batch(i, per_rank)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            self.body(rays, tgt)
+            ts.append(time.perf_counter() - t0)
+        torch.cuda.synchronize()
+        ts.sort()
+        return 1e3 * ts[len(ts) // 2]
+
+
+def shard_leg(wl, per_rank, steps, warmup, collective="split", i0=100000):
+    """The `per_rank`-ray step of a strong-scaling shard on this process group: eager and graphed, per-kernel table."""
+    ms = {}
+    el, loss, prof = wl.run(per_rank, steps, warmup, i0=i0)
+    ms["eager"] = el / steps * 1e3
+    table = per_kernel_table(prof, el * 1e3)
+    host = wl.host_enqueue_ms(per_rank)
+    g = wl.graphed(per_rank, collective)
+    el_g, loss_g, _ = wl.run(per_rank, steps, warmup, i0=i0 + steps + warmup, graphed=g)
+    ms["graph"] = el_g / steps * 1e3
+    n = per_rank * (NC + NC + NF) * wl.world
+    mfma_ms = sum(r["avg_ms"] * r["launches"] for r in table) / steps
+    ideal_ms = n / wl.world * 2 * (MAC_FWD + MAC_DGRAD + MAC_WGRAD) / (PEAK_FP32_MFMA_TFLOPS * 1e12) * 1e3
+    return {"rays_per_gpu": per_rank, "global_batch": per_rank * wl.world, "steps": steps, "warmup": warmup,
+            "ms_per_step_eager": round(ms["eager"], 4), "ms_per_step_graph": round(ms["graph"], 4),
+            "graph_collective": collective if wl.reducer_active() else None,
+            "ray_samples_per_s_eager": n / (ms["eager"] * 1e-3), "ray_samples_per_s_graph": n / (ms["graph"] * 1e-3),
+            "host_enqueue_ms_per_eager_step": round(host, 3),
+            "mfma_kernels_ms_per_step": round(mfma_ms, 4), "step_ms_at_mfma_peak": round(ideal_ms, 4),
+            "frac_of_peak_graph": round(ideal_ms / ms["graph"], 4), "frac_of_peak_eager": round(ideal_ms / ms["eager"], 4),
+            "final_loss": float(loss_g.item()), "kernels": table}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     # defaults: a timed region of ~5 s (200 x 26 ms), long enough for a coarse (seconds) GPU-busy sampler to see it
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: 4096 rays per GPU (global batch 4096 N); strong: the 4096-ray batch sharded N ways (C4)")
+    ap.add_argument("--rays-per-gpu", type=int, default=0, help="override the per-GPU shard (e.g. 512 = the 8-way C4 shard)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the C5 / C3 legs that follow the timed C2 region at N=1")
+    ap.add_argument("--no-extra", action="store_true", help="skip the legs that follow the timed region")
     ap.add_argument("--graph", action="store_true",
-                    help="(N=1) replay the step as ONE captured hipGraph (consistentnerf_amd/graph.py); the per-kernel table then "
-                         "comes from a separate eager pass of the same steps, and the JSON says so")
+                    help="replay the step as captured hipGraph(s) (consistentnerf_amd/graph.py); the per-kernel table then comes "
+                         "from a separate eager pass of the same steps, and the JSON says so")
+    ap.add_argument("--graph-collective", choices=("split", "capture"), default="split")
+    ap.add_argument("--pmc", action="store_true", help="fill roofline.traffic from rocprofv3 --pmc passes of THIS command")
     a = ap.parse_args()
 
     # stdout carries exactly ONE line, the JSON: everything else that writes to fd 1 — the reference-style prints of
@@ -319,7 +649,6 @@ def main():
 
     import torch.distributed as dist
     from consistentnerf_amd import distributed as D, ops
-    from consistentnerf_amd import run_nerf as R
     # backend: RCCL ("nccl") for a real multi-GPU run.  CNERF_DIST_BACKEND=gloo lets the N>1 code path of this script (sharded
     # steps, GradReducer, barrier, max-over-ranks) be exercised on a box with fewer GPUs than ranks — the ranks then share
     # devices (rank % device_count) and the numbers mean nothing as a scaling measurement; the JSON's dist.backend says so.
@@ -339,129 +668,117 @@ def main():
         torch.cuda.synchronize()
     ok, name, cus, _ = ops.device_info(local)
 
-    import tempfile
-    torch.manual_seed(1234)                       # identical init on every rank (replicated weights)
-    with tempfile.TemporaryDirectory() as tmp:
-        kw_train, _, start, grad_vars, optimizer = R.create_nerf(make_args(tmp))
-    kw_train.update(near=NEAR, far=FAR)
-    K, bank, targets = build_ray_bank(dev)
-    nbank = bank.shape[0]
-    torch.manual_seed(99 + rank)                  # per-rank jitter streams (RegNeRF/train.py:364-365 precedent)
-    gstep = B_PER_GPU * world
-    # the step's gradient exchange: per-network slices of the flat fp32 gradient, all-reduced (RCCL) as _MlpFn.backward
-    # reports them final; a no-op without a process group
-    reducer = D.GradReducer(optimizer, [kw_train['network_fn'], kw_train['network_fine']], mean=True,
-                            timing=dist.is_initialized())
-
-    def body(rays, tgt):
-        rays_od = torch.stack([rays[:, 0:3], rays[:, 3:6]], 0)
-        rgb, disp, acc, extras = R.render(H_IMG, W_IMG, K, chunk=32768, rays=rays_od, retraw=True, **kw_train)
-        optimizer.zero_grad()
-        loss = R.img2mse(rgb, tgt) + R.img2mse(extras['rgb0'], tgt)
-        loss.backward()
-        reducer.finish()
-        optimizer.step()
-        return loss
-
-    graphed = None
-    if a.graph:
-        assert world == 1, "--graph is a single-GPU option"
-        from consistentnerf_amd.graph import GraphedStep
-        graphed = GraphedStep(body, optimizer, (bank[0:B_PER_GPU], targets[0:B_PER_GPU]), warmup=3)
-
-    def step(i, eager=False):
-        lo = (i * gstep + rank * B_PER_GPU) % (nbank - B_PER_GPU)
-        rays, tgt = bank[lo:lo + B_PER_GPU], targets[lo:lo + B_PER_GPU]
-        loss = graphed(rays, tgt) if (graphed is not None and not eager) else body(rays, tgt)
-        lr = 5e-4 * (0.1 ** (i / (250 * 1000)))
-        for pg in optimizer.param_groups:
-            pg['lr'] = lr
-        return loss
-
-    for i in range(a.warmup):
-        step(i)
-    torch.cuda.synchronize()
-    D.barrier()
-    torch.cuda.synchronize()
-    ops.PROFILE = []
-    reducer.exposed.clear()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        loss = step(a.warmup + i)
-    torch.cuda.synchronize()
-    D.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    prof, ops.PROFILE = ops.PROFILE, None
+    if a.rays_per_gpu > 0:
+        per_rank = a.rays_per_gpu
+    elif a.scaling == "strong":
+        if B_PER_GPU % world:
+            raise SystemExit(f"--scaling strong shards the {B_PER_GPU}-ray batch evenly: {world} ranks do not divide it")
+        per_rank = B_PER_GPU // world
+    else:
+        per_rank = B_PER_GPU
+    wl = Workload(dev, rank, world)
+    graphed = wl.graphed(per_rank, a.graph_collective) if a.graph else None
+    elapsed, loss, prof = wl.run(per_rank, a.steps, a.warmup, graphed=graphed)
     if graphed is not None:      # a replayed graph carries no events: the per-kernel table from an eager pass of the same steps
-        ops.PROFILE = []
-        for i in range(a.steps):
-            step(a.warmup + a.steps + i, eager=True)
-        torch.cuda.synchronize()
-        prof, ops.PROFILE = ops.PROFILE, None
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+        el_e, _, prof = wl.run(per_rank, a.steps, 0, i0=a.warmup + a.steps)
+        table = per_kernel_table(prof, el_e * 1e3)
+    else:
+        table = per_kernel_table(prof, elapsed * 1e3)
     final_loss = loss.item()
-
-    # live per-kernel timing (HIP events on the launch stream, inside the timed region)
-    kern = {}
-    for nme, units, e0, e1 in prof:
-        k = kern.setdefault((nme, units), [0.0, 0])
-        k[0] += e0.elapsed_time(e1)
-        k[1] += 1
-    flops = {"mlp_fwd_train": 2 * MAC_FWD, "mlp_fwd": 2 * MAC_FWD, "mlp_dgrad": 2 * MAC_DGRAD, "mlp_wgrad": 2 * MAC_WGRAD}
-    table = []
-    for (nme, units), (ms, n) in kern.items():
-        avg_ms = ms / n
-        table.append({"kernel": nme, "points": units, "launches": n, "avg_ms": round(avg_ms, 4),
-                      "tflops": round(flops[nme] * units / (avg_ms * 1e-3) / 1e12, 2),
-                      "share_of_step": round(ms / (elapsed * 1e3), 4)})
-    table.sort(key=lambda r: -r["avg_ms"] * r["launches"])
     dom = table[0]
+    traffic, traffic_source = pmc_traffic(dom["kernel"], dom["points"]), (
+        "static lookup: committed rocprofv3 PMC passes of this kernel at this launch size (profiles/*_pmc*/pass2+pass3 "
+        "summaries, 2*FETCH_SIZE + WRITE_SIZE); NOT sampled in this run")
+    pmc_live = None
+    if a.pmc and rank == 0 and world == 1:
+        pmc_live = pmc_rerun(per_rank, dom["kernel"])
+        if pmc_live and pmc_live.get("traffic") is not None:
+            traffic, traffic_source = pmc_live["traffic"], pmc_live["source"]
     roofline = {"bound": "mfma", "kernel": f'{dom["kernel"]} (M={dom["points"]} points)', "achieved": dom["tflops"],
                 "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(dom["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4),
-                "traffic": pmc_traffic(dom["kernel"], dom["points"]),
-                "traffic_source": "static lookup: committed rocprofv3 PMC passes of this kernel at this launch size "
-                                  "(profiles/*_pmc*/pass2+pass3 summaries, 2*FETCH_SIZE + WRITE_SIZE); NOT sampled in this run",
-                "avg_launch_ms": dom["avg_ms"], "kernels": table}
+                "traffic": traffic, "traffic_source": traffic_source, "avg_launch_ms": dom["avg_ms"], "kernels": table}
+    if pmc_live:
+        roofline["pmc"] = pmc_live
     if graphed is not None:
         roofline["kernels_measured"] = "separate eager pass of the same steps after the timed (graph-replayed) region"
     dist_info = None
     if dist.is_initialized():
-        ex = reducer.exposed_ms()
-        dist_info = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
-                     "messages_per_step": len(reducer.slices), "message_bytes": [4 * (hi - lo) for lo, hi in reducer.slices.values()],
-                     "bytes_per_step": reducer.bytes_per_step,
+        ex = wl.reducer.exposed_ms()
+        be = dist.get_backend()
+        dist_info = {"rccl_ranks": dist.get_world_size() if be == "nccl" else 0, "ranks": dist.get_world_size(), "backend": be,
+                     "messages_per_step": len(wl.reducer.slices),
+                     "message_bytes": [4 * (hi - lo) for lo, hi in wl.reducer.slices.values()],
+                     "bytes_per_step": wl.reducer.bytes_per_step, "one_over_world": "folded into the Adam kernel (grad_scale)",
                      "allreduce_exposed_ms": round(sum(ex) / max(len(ex), 1), 4), "allreduce_exposed_ms_max": round(max(ex), 4) if ex else None,
                      "measured": "HIP events on the launch stream: last slice issued -> launch stream released (this rank)"}
 
+    out = None
     if rank == 0:
-        samples_per_step = B_PER_GPU * (NC + NC + NF) * world
+        samples_per_step = per_rank * (NC + NC + NF) * world
+        exch = ""
+        if world > 1:
+            exch = (", RCCL all-reduce of the flat fp32 grad" if dist.get_backend() == "nccl"
+                    else f", {dist.get_backend()} all-reduce of the flat fp32 grad (NOT RCCL: ranks share devices, no scaling claim)")
+        cfgname = "BASELINE configs[1]" if (world == 1 and per_rank == B_PER_GPU) else (
+            "BASELINE configs[3] (C4: the 4096-ray C2 batch sharded)" if per_rank * world == B_PER_GPU else
+            ("BASELINE configs[3] shapes, weak scaling" if per_rank == B_PER_GPU else "a per-GPU shard of BASELINE configs[3]"))
         out = {
             "metric": "train_ray_samples_per_sec", "value": samples_per_step * a.steps / elapsed,
             "unit": "ray-samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if (a.scaling == "strong" and a.rays_per_gpu <= 0) else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic", "hip_graph": graphed is not None,
-            "config": {"workload": "DTU scan8 3-view (synthetic 512x640 ray bank), 4096 rays/GPU/step, coarse 64 + "
-                                   "fine 64+128 samples, D=8 W=256 viewdirs MLPs (random init), perturb=1, "
-                                   "mse(rgb)+mse(rgb0), backward, Adam; BASELINE configs[1] (configs[3] when N>1)",
-                       "rays_per_gpu": B_PER_GPU, "ray_samples_per_ray": NC + NC + NF, "device": name, "cus": cus,
-                       "parallelism": f"ray-shard dp{world}" + (", RCCL all-reduce of the flat fp32 grad" if world > 1 else ""),
-                       "final_loss": final_loss},
+            "config": {"workload": f"DTU scan8 3-view (synthetic 512x640 ray bank), {per_rank} rays/GPU/step (global batch "
+                                   f"{per_rank * world}), coarse 64 + fine 64+128 samples, D=8 W=256 viewdirs MLPs (random init), "
+                                   f"perturb=1, mse(rgb)+mse(rgb0), backward, Adam; {cfgname}",
+                       "rays_per_gpu": per_rank, "global_batch": per_rank * world, "ray_samples_per_ray": NC + NC + NF,
+                       "device": name, "cus": cus, "parallelism": f"ray-shard dp{world}" + exch, "final_loss": final_loss},
             "roofline": roofline,
         }
         if dist_info is not None:
             out["dist"] = dist_info
+
+    def emit():
+        if rank == 0:
+            sys.stdout.flush()
+            os.write(json_fd, (json.dumps(out) + "\n").encode())
+
+    if not a.no_extra and world > 1 and per_rank == B_PER_GPU and B_PER_GPU % world == 0:
+        # the same process group on the strong-scaling shard of C4.  A watchdog prints the line without this leg and ends
+        # the process if the leg has not finished (a collective that never completes cannot be interrupted from Python).
+        import threading
+        done = threading.Event()
+
+        def watchdog():
+            if not done.wait(float(os.environ.get("CNERF_BENCH_LEG_TIMEOUT", "120"))):
+                if rank == 0:
+                    out.setdefault("extra", {})["c4_strong"] = {"error": "leg did not finish within the watchdog's limit"}
+                    emit()
+                os._exit(0)
+        threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            leg = shard_leg(wl, B_PER_GPU // world, min(a.steps, 100), 10, collective=a.graph_collective)
+        except Exception as e:  # noqa: BLE001 — the main line must survive a failure of the side leg
+            leg = {"error": f"{type(e).__name__}: {e}"}
+        done.set()
+        if rank == 0:
+            out["extra"] = {"note": "same process group, after the timed region; not part of `value`", "c4_strong": leg}
+    if rank == 0:
         if world == 1 and not a.no_extra:
-            del kw_train, optimizer, grad_vars, bank, targets, reducer
+            extra = {"note": "same process, after the timed C2 region; not part of `value`"}
+            if per_rank == B_PER_GPU:
+                extra["c4_shard"] = shard_leg(wl, B_PER_GPU // 8, 200, 20)
+                extra["c4_shard"]["what"] = ("the 512-ray per-GPU step of the 8-way strong-scaling shard of the 4096-ray C2 batch, "
+                                             "on this one GPU (no exchange: world 1)")
+            del wl, graphed
             torch.cuda.empty_cache()
-            out["extra"] = {"note": "same process, after the timed C2 region; not part of `value`", "c5": c5_leg(dev), "c3": c3_leg(dev)}
+            extra["c5"] = c5_leg(dev)
+            extra["c3"] = c3_leg(dev)
+            extra["hbm_kernels"] = hbm_kernels(dev)
+            out["extra"] = extra
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        emit()
     os.close(json_fd)
     if dist.is_initialized():
         dist.destroy_process_group()

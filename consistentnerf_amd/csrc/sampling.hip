@@ -45,20 +45,47 @@ struct PdfLds {
   float bins[WAVES][MAX_NB];
 };
 
+// torch.sum(x, -1) of one row of n fp32 values WITH THE ASSOCIATION OF ATen's CPU KERNEL (aten/src/ATen/native/cpu/
+// SumKernel.cpp, fp32 accumulators): the contiguous inner reduction runs on 8-float vectors — `row_sum` keeps 4 vector
+// accumulators (vector i of a group of four goes to accumulator i & 3, groups in order; leftover vectors to accumulator 0;
+// then acc0 += acc1, acc2, acc3), the n % 8 tail is summed sequentially from zero, and the 8 lanes of the vector sum are added
+// to it in lane order; rows shorter than one vector take the same `row_sum` on scalars.  (Rows of >= 512 elements would add
+// ATen's cascade levels; MAX_NB rules them out.)  This is the pdf normaliser of sample_pdf (H:213): one fp32 ulp of it
+// decides on which side of 1.0 the last CDF entry lands, i.e. the index of every sample at a CDF tie — the u = 1.0 sample of
+// each ray on the deterministic test-time path.  Verified against torch.sum on the 8192 rows of the bulk fixture (0 differing
+// bits) and, end to end, on its 2 x 524 288 indices (tests/golden/sample_pdf_bulk.npz).  Wave-uniform result.
+template <typename AFn>
+__device__ __forceinline__ float aten_row_sum(int n, int lane, AFn a) {
+  const int V = n >= 8 ? 8 : 1;
+  const int nv = n / V, size_ilp = nv >> 2;
+  float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+  if (lane < V) {
+    for (int i = 0; i < size_ilp; ++i) {
+      p0 += a((4 * i + 0) * V + lane);
+      p1 += a((4 * i + 1) * V + lane);
+      p2 += a((4 * i + 2) * V + lane);
+      p3 += a((4 * i + 3) * V + lane);
+    }
+    for (int i = 4 * size_ilp; i < nv; ++i) p0 += a(i * V + lane);
+    p0 += p1;
+    p0 += p2;
+    p0 += p3;
+  }
+  float acc = 0.f;
+  for (int k = nv * V; k < n; ++k) acc += a(k);
+  for (int l = 0; l < V; ++l) acc += __shfl(p0, l, 64);
+  return acc;
+}
+
 // Builds cdf[0..Nb-1] and bins[0..Nb-1] for one ray in LDS.  w(j), j<Nb-1, is the raw weight;
-// pdf = (w+1e-5)/sum, cdf = [0, cumsum(pdf)] with the running sum carried in fp64 and each entry
-// rounded to fp32 (what the CPU reference's cumsum produces).
+// pdf = (w+1e-5)/sum with the sum associated as torch.sum does on the CPU (aten_row_sum), cdf = [0, cumsum(pdf)] with the
+// running sum carried in fp64 and each entry rounded to fp32 (what the CPU reference's cumsum produces).
 template <typename WFn, typename BFn>
 __device__ __forceinline__ void build_cdf(float* cdf, float* bins, int Nb, int lane, WFn w, BFn bin) {
   const int nw = Nb - 1;
   // per-lane contiguous chunk so the scan is lane-local + one wave scan
   const int C = (nw + 63) >> 6;
-  double tot = 0.0;
-  for (int j = 0; j < C; ++j) {
-    int k = lane * C + j;
-    if (k < nw) tot += (double)(w(k) + 1e-5f);
-  }
-  const float sum = (float)wave_sum(tot);
+  const float sum = aten_row_sum(nw, lane, [&](int k) { return w(k) + 1e-5f; });
   double run = 0.0;
   for (int j = 0; j < C; ++j) {
     int k = lane * C + j;

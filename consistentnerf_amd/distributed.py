@@ -99,8 +99,13 @@ class GradReducer:
     issued (all gradient compute queued) to the moment the launch stream may proceed — the part of the exchange the step
     actually waits for."""
 
-    def __init__(self, optimizer, modules, mean: bool = True, timing: bool = False):
-        self.opt, self.mean, self.timing = optimizer, mean, timing
+    def __init__(self, optimizer, modules, mean: bool = True, timing: bool = False, fold_scale: bool = False):
+        """fold_scale=True: finish() leaves the SUM in the flat gradient and the caller hands `grad_scale` (1/world when
+        `mean`) to FusedAdam.step(grad_scale=...), where the multiply is free inside the Adam kernel (before its clip — the
+        order of RegNeRF/train.py:246-274); the default applies it here with one more pass over the buffer, which is what a
+        caller clipping the .grad views with torch's own clip_grad_value_ between finish() and step() needs."""
+        self.opt, self.mean, self.timing, self.fold_scale = optimizer, mean, timing, fold_scale
+        self.hold = False           # True: network_ready() is ignored and finish() issues every slice (graph.GraphedStep, split)
         self.modules = [m for m in modules if m is not None]
         self.slices = {}
         for m in self.modules:
@@ -121,10 +126,21 @@ class GradReducer:
             self._ev.record(torch.cuda.current_stream())
         self._works.append(dist.all_reduce(self.opt.flat_grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
 
+    @property
+    def grad_scale(self) -> float:
+        """what FusedAdam.step(grad_scale=) has to apply after finish() (1.0 unless fold_scale and mean and world > 1)"""
+        return 1.0 / world() if (self.fold_scale and self.mean and world() > 1) else 1.0
+
     def network_ready(self, m):
         """called by _MlpFn.backward when network `m` has no backward node pending in this step"""
-        if id(m) in self.slices and id(m) not in self._done:
+        if not self.hold and id(m) in self.slices and id(m) not in self._done:
             self._issue(m)
+
+    def reset(self):
+        """forget the bookkeeping of a backward pass whose exchange is not going to be finished (a recorded, not executed one)"""
+        for m in self.modules:
+            m._cnerf_pending = 0
+        self._works, self._done, self._ev = [], set(), None
 
     def finish(self):
         for m in self.modules:
@@ -137,7 +153,7 @@ class GradReducer:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record(torch.cuda.current_stream())
             self.exposed.append((self._ev, e1))
-        if self.mean and world() > 1:
+        if self.mean and world() > 1 and not self.fold_scale:
             self.opt.flat_grad.mul_(1.0 / world())
         self._works, self._done, self._ev = [], set(), None
 
@@ -197,34 +213,136 @@ def gather_rows(block: torch.Tensor, H: int) -> torch.Tensor:
     return torch.cat(keep, 0)
 
 
-def render_image_sharded(H, W, K, chunk, c2w, render_kwargs, render_fn=None, get_rays_fn=None):
-    """One frame of `render_path` (R:156) with its rows split over the ranks: each rank renders its row block through
-    the unchanged `render(rays=...)` (so viewdirs / NDC are derived exactly as for the full frame), then the blocks
-    are all-gathered.  Returns (rgb [H,W,3], disp [H,W]) on every rank — rays are independent, so the frame equals the
-    single-GPU one bit for bit."""
+def _pad_rows(t: torch.Tensor, n: int) -> torch.Tensor:
+    """[m, ...] -> [n, ...] by repeating the last row (edge padding of the OUTPUT block: same frame as padding the rays the
+    way RegNeRF/internal/models.py:311-322 does, without rendering the padding)."""
+    if t.shape[0] == n:
+        return t
+    if t.shape[0] == 0:       # a rank without rows (H < world): its block is all padding
+        return t.new_zeros((n,) + tuple(t.shape[1:]))
+    return torch.cat([t, t[-1:].expand(n - t.shape[0], *t.shape[1:])], 0)
+
+
+def gather_blocks_to_root(block: torch.Tensor, out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """ONE gather of the equal-sized per-rank blocks to rank 0 -> [world, *block.shape] there (written into `out` when given),
+    None elsewhere.  RCCL gathers device buffers directly; gloo (the one-GPU tests) is staged through the host."""
+    w = world()
+    if w == 1:
+        if out is None:
+            return block[None]
+        out[0].copy_(block)
+        return out
+    block = block.contiguous()
+    if dist.get_backend() == "gloo" and block.is_cuda:
+        hb = block.cpu()
+        parts = [torch.empty_like(hb) for _ in range(w)] if rank() == 0 else None
+        dist.gather(hb, parts, dst=0)
+        if rank() != 0:
+            return None
+        full = torch.stack(parts, 0).to(block.device)
+        if out is None:
+            return full
+        out.copy_(full)
+        return out
+    if rank() == 0:
+        if out is None:
+            out = torch.empty((w,) + tuple(block.shape), device=block.device, dtype=block.dtype)
+        dist.gather(block, [out[r] for r in range(w)], dst=0)
+        return out
+    dist.gather(block, None, dst=0)
+    return None
+
+
+def _render_block(H, W, K, chunk, c2w, lo, hi, render_kwargs, render_fn, get_rays_fn, want_acc):
+    """This rank's rows [lo, hi) of one frame -> packed [(hi-lo)*W, 4|5] = rgb | disp (| acc).  The stock query renders them
+    through the in-kernel camera path (`run_nerf.render_pixels`: rays generated inside the kernels from `cam.first = lo*W`, no
+    [H*W, 11] ray tensor on any rank); anything else (custom network_query_fn, per-ray near/far, DEBUG) takes the ray tensor of
+    the block through the unchanged render(rays=...)."""
+    from . import run_nerf
+    if hi <= lo:
+        p = next(render_kwargs["network_fn"].parameters()) if "network_fn" in render_kwargs else torch.zeros(())
+        return p.new_zeros((0, 5 if want_acc else 4))
+    if render_fn is None and run_nerf.camera_path_ok(c2w, render_kwargs):
+        o = run_nerf.render_pixels(H, W, K, chunk, c2w, lo * W, (hi - lo) * W, **render_kwargs)
+        cols = [o["rgb_map"], o["disp_map"][:, None]] + ([o["acc_map"][:, None]] if want_acc else [])
+        return torch.cat(cols, 1)
     if render_fn is None or get_rays_fn is None:
-        from . import run_nerf, run_nerf_helpers
+        from . import run_nerf_helpers
         render_fn = render_fn or run_nerf.render
         get_rays_fn = get_rays_fn or run_nerf_helpers.get_rays
-    lo, hi, idx = row_block(H)
     rays_o, rays_d = get_rays_fn(H, W, K, c2w)
-    idx = idx.to(rays_o.device)
-    rays = torch.stack([rays_o[idx], rays_d[idx]], 0)            # [2, rows, W, 3]
+    rays = torch.stack([rays_o[lo:hi], rays_d[lo:hi]], 0)            # [2, rows, W, 3]
     out = render_fn(H, W, K, chunk=chunk, rays=rays, **render_kwargs)
-    rgb, disp = out[0], out[1]
-    return gather_rows(rgb, H), gather_rows(disp, H)
+    cols = [out[0].reshape(-1, 3), out[1].reshape(-1, 1)] + ([out[2].reshape(-1, 1)] if want_acc else [])
+    return torch.cat(cols, 1)
 
 
-def render_path_sharded(render_poses, hwf, K, chunk, render_kwargs, render_factor=0, render_fn=None, get_rays_fn=None):
-    """`render_path` (R:140-178) over all ranks -> (rgbs [N,H,W,3], disps [N,H,W]) numpy on every rank."""
+def render_image_sharded(H, W, K, chunk, c2w, render_kwargs, render_fn=None, get_rays_fn=None, want_acc=False, out=None):
+    """One frame of `render_path` (R:156) with its rows split over the ranks: every rank renders ITS rows only, the packed
+    blocks (rgb | disp [| acc], the short ones edge-padded to ceil(H/world) rows so the gather is rectangular) go to rank 0
+    in ONE gather.  Returns the frame [H, W, 4|5] on rank 0 (a view of `out` [world, rows*W, 4|5] when given), None on the
+    other ranks — render_path only ever needs the frame on one host (R:157-159).  Rays are independent, so the frame equals
+    the single-GPU one bit for bit."""
+    lo, hi = shard_bounds(H)
+    rows = -(-H // world())
+    blk = _render_block(H, W, K, chunk, c2w, lo, hi, render_kwargs, render_fn, get_rays_fn, want_acc)
+    full = gather_blocks_to_root(_pad_rows(blk, rows * W), out)
+    if full is None:
+        return None
+    if world() == 1:
+        return full[0].view(H, W, -1)
+    keep = [full[r, :(shard_bounds(H, r)[1] - shard_bounds(H, r)[0]) * W] for r in range(world())]
+    return torch.cat(keep, 0).view(H, W, -1)
+
+
+def render_path_sharded(render_poses, hwf, K, chunk, render_kwargs, render_factor=0, render_fn=None, get_rays_fn=None,
+                        want_acc=False, frame_times=None):
+    """`render_path` (R:140-178; V:252-294 with want_acc) over all ranks -> (rgbs [N,H,W,3], disps [N,H,W][, accs]) numpy on
+    rank 0, None elsewhere.  Frame i's device-to-host copy runs on its own stream into one of two pinned buffers while frame
+    i+1 renders; `frame_times` (a list) receives rank 0's host time per frame."""
+    import time
     import numpy as np
     H, W, focal = hwf
     if render_factor != 0:
         H, W, focal = H // render_factor, W // render_factor, focal / render_factor
-    rgbs, disps = [], []
-    for c2w in render_poses:
+    nch = 5 if want_acc else 4
+    root = rank() == 0
+    cuda = torch.cuda.is_available()
+    frames, pending = [], []
+    copy_stream = torch.cuda.Stream() if (cuda and root) else None
+    host = [None, None]
+
+    def drain(k):
+        ev, buf = pending.pop(k)
+        ev.synchronize()
+        frames.append(np.array(buf.numpy(), copy=True))
+
+    for i, c2w in enumerate(render_poses):
+        t0 = time.perf_counter()
         with torch.no_grad():
-            rgb, disp = render_image_sharded(H, W, K, chunk, c2w[:3, :4], render_kwargs, render_fn, get_rays_fn)
-        rgbs.append(rgb.cpu().numpy())
-        disps.append(disp.cpu().numpy())
-    return np.stack(rgbs, 0), np.stack(disps, 0)
+            frame = render_image_sharded(H, W, K, chunk, c2w[:3, :4], render_kwargs, render_fn, get_rays_fn, want_acc)
+        if root:
+            if copy_stream is None or not frame.is_cuda:
+                frames.append(frame.cpu().numpy())
+            else:
+                if len(pending) == 2:       # both pinned buffers busy: the older copy finished a frame ago
+                    drain(0)
+                j = i & 1
+                if host[j] is None:
+                    host[j] = torch.empty((H, W, nch), dtype=torch.float32).pin_memory()
+                copy_stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(copy_stream):
+                    host[j].copy_(frame, non_blocking=True)
+                    frame.record_stream(copy_stream)
+                    ev = torch.cuda.Event()
+                    ev.record(copy_stream)
+                pending.append((ev, host[j]))
+        if frame_times is not None:
+            frame_times.append(time.perf_counter() - t0)
+    while pending:
+        drain(0)
+    if not root:
+        return None
+    full = np.stack(frames, 0)
+    out = (np.ascontiguousarray(full[..., :3]), np.ascontiguousarray(full[..., 3]))
+    return out + ((np.ascontiguousarray(full[..., 4]),) if want_acc else ())

@@ -1,44 +1,92 @@
-"""The training step as ONE captured hipGraph (HIP graphs instead of a tracing compiler: the step's ~25 launches — two fused
-MLP forwards, compositing, resampling, loss, the merged backward, Adam, weight packing and the handful of ATen glue kernels —
-are recorded once and replayed with a single launch).  What changes from step to step stays outside the recording:
+"""The training step as captured hipGraphs (HIP graphs instead of a tracing compiler: the step's ~25 launches — two fused MLP
+forwards, compositing, resampling, loss, the merged backward, Adam, weight packing and the handful of ATen glue kernels — are
+recorded once and replayed with a single launch).  What changes from step to step stays outside the recording:
 
   * the batch: `GraphedStep.__call__` copies the caller's tensors into static input buffers;
-  * Adam's scalars (step count, bias corrections, the decayed lr of R:784-788): `FusedAdam.make_capturable()` moves them to
-    device memory, the recording holds the 32-byte copy from a pinned host buffer, `FusedAdam.advance()` rewrites that buffer
-    before every replay;
+  * Adam's scalars (step count, bias corrections, the decayed lr of R:784-788, the 1/world of a summed gradient):
+    `FusedAdam.make_capturable()` moves them to device memory; `FusedAdam.advance()` uploads the step's 32 bytes from a ring of
+    pinned blocks, stream-ordered ahead of every replay (the upload is NOT part of the recording: a recorded copy would read
+    whatever the host has written by the time the GPU gets there);
   * randomness: torch's CUDA generator is graph-safe (philox offsets are advanced per replay).
 
-Everything inside is exactly the eager step (same kernels, same order).  The gain is launch latency only — the four MFMA
-kernels are 98.9 % of the step — so this is an option, not a requirement: `GraphedStep(...)` raises if the capture fails and
-the caller keeps stepping eagerly."""
-from typing import Callable, Sequence
+Data-parallel steps (a `distributed.GradReducer` is passed): the gradient exchange sits between the backward and Adam.
+  collective="split"   (default) two graphs around it: [render, loss, backward] -> eager all-reduce of the flat gradient on the
+                       collective's own stream -> [Adam].  The host enqueues all three back to back (it is milliseconds ahead of
+                       the GPU), so the GPU sees no bubble; works with any backend (RCCL, or gloo in the one-GPU tests).
+  collective="capture" the RCCL all-reduce is recorded INSIDE one graph (fork to RCCL's stream and join back are capturable);
+                       one launch per step.  RCCL only.
+
+Everything inside is exactly the eager step (same kernels, same order).  The gain is launch latency only — at 4096 rays per GPU
+the four MFMA kernels are 98.9 % of the step; at the 512 rays per GPU of the 8-way strong-scaling shard (C4) the ~100 host
+launches of an eager step are no longer hidden, and the graph is what keeps the step on the kernels' time."""
+from typing import Callable, Optional, Sequence
 
 import torch
 
 
 class GraphedStep:
-    def __init__(self, step_fn: Callable[..., torch.Tensor], optimizer, example_inputs: Sequence[torch.Tensor], warmup: int = 3):
-        """step_fn(*inputs) -> loss runs ONE full step (render, loss, zero_grad, backward, optimizer.step()) on tensors of
-        the shapes of `example_inputs`; it must not read host-side state that changes between steps.  The `warmup` runs
-        before the recording are REAL steps on `example_inputs` (they move the weights and Adam's state, like `warmup`
-        ordinary training steps on that batch); the recording itself executes nothing."""
+    def __init__(self, step_fn: Callable[..., torch.Tensor], optimizer, example_inputs: Sequence[torch.Tensor], warmup: int = 3,
+                 reducer=None, collective: str = "split"):
+        """Without `reducer`: step_fn(*inputs) -> loss runs ONE full step (render, loss, zero_grad, backward, optimizer.step()).
+        With `reducer` (a distributed.GradReducer built with fold_scale=True): step_fn stops after loss.backward(); the exchange
+        (`reducer.finish()`) and `optimizer.step(grad_scale=reducer.grad_scale)` are appended here.  step_fn must not read
+        host-side state that changes between steps.  The `warmup` runs before the recording are REAL steps on `example_inputs`
+        (they move the weights and Adam's state, like `warmup` ordinary training steps on that batch); the recording itself
+        executes nothing."""
+        if collective not in ("split", "capture"):
+            raise ValueError("collective must be 'split' or 'capture'")
         self.opt = optimizer.make_capturable()
+        self.reducer, self.collective = reducer, collective
         self.static_in = [t.clone() for t in example_inputs]
+        self.tail_graph = None
+
+        def tail():
+            reducer.finish()
+            optimizer.step(grad_scale=reducer.grad_scale)
+
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):             # warm-up on a side stream (allocator pools, lazy initialisations)
             for _ in range(warmup):
                 step_fn(*self.static_in)
+                if reducer is not None:
+                    tail()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        # the weight re-pack must be part of the recording: a pack cached from a render just before (possible with warmup=0)
+        # would leave every replay's forward on the weights as they were at capture time
+        self.opt.bump_epoch()
+        timing = getattr(reducer, "timing", False)
+        if reducer is not None:
+            reducer.timing = False                # (timed events cannot be recorded into a graph)
+            reducer.hold = collective == "split"  # split: nothing leaves from inside the (recorded) backward
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):        # (recorded, not executed: the step counter does not move here)
-            self.static_loss = step_fn(*self.static_in)
+        try:
+            with torch.cuda.graph(self.graph):    # (recorded, not executed: the step counter does not move here)
+                self.static_loss = step_fn(*self.static_in)
+                if reducer is not None and collective == "capture":
+                    tail()
+            if reducer is not None and collective == "split":
+                reducer.reset()                   # the recorded backward counted its nodes; nothing was issued
+                self.tail_graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.tail_graph, pool=self.graph.pool()):
+                    optimizer.step(grad_scale=reducer.grad_scale)
+        finally:
+            if reducer is not None:
+                reducer.timing = timing
+        if reducer is not None and collective == "capture":
+            reducer.reset()
         torch.cuda.synchronize()
 
     def __call__(self, *inputs: torch.Tensor) -> torch.Tensor:
         for dst, src in zip(self.static_in, inputs):
             dst.copy_(src)
-        self.opt.advance()
+        self.opt.advance(1.0 if self.reducer is None else self.reducer.grad_scale)
         self.graph.replay()
+        if self.tail_graph is not None:
+            self.reducer.finish()                 # eager: every slice of the flat gradient, on the collective's stream
+            self.tail_graph.replay()
+        # the recorded Python ran once: tell the packed-weight caches that the weights moved (an eval render between graphed
+        # steps must re-pack, not reuse the kernel-layout copy of an earlier evaluation)
+        self.opt.bump_epoch()
         return self.static_loss

@@ -25,7 +25,7 @@ class FusedAdam:
             raise ops.CnerfError("FusedAdam needs GPU parameters (no CPU path)")
         self.param_groups = [dict(params=self.params, lr=lr, betas=betas, eps=eps, clip_value=clip_value)]
         self._step = 0
-        self._hyp_host = self._hyp_dev = None
+        self._hyp_ring = self._hyp_ev = self._hyp_dev = None
         sizes = [p.numel() for p in self.params]
         self._offsets = [0]
         for n in sizes:
@@ -59,35 +59,54 @@ class FusedAdam:
                 p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
 
     def step(self, grad_scale: float = 1.0):
+        """One Adam step over the flat buffers.  `grad_scale` multiplies the gradient inside the kernel BEFORE the clip (the
+        1/world of a summed data-parallel gradient rides here for free: distributed.GradReducer(fold_scale=True))."""
         g = self.param_groups[0]
-        if self._hyp_host is not None:
-            # graph-capturable form (graph.GraphedStep): the scalars of the step live in device memory, refreshed from a
-            # pinned host buffer by a copy that is part of the captured graph; `advance()` rewrites the host buffer
+        if self._hyp_ring is not None:
+            # graph-capturable form (graph.GraphedStep): the scalars of the step live in device memory.  Eagerly, advance()
+            # uploads them (stream-ordered, from a ring of pinned buffers) right before the kernel; under capture only the
+            # kernel is recorded and GraphedStep calls advance() before every replay.
             if not torch.cuda.is_current_stream_capturing():
                 self.advance(grad_scale)
-            self._hyp_dev.copy_(self._hyp_host, non_blocking=True)
             ops.adam_step_dev(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self._hyp_dev)
         else:
             self._step += 1
             ops.adam_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self._step, g['lr'],
                           g['betas'][0], g['betas'][1], g['eps'], g.get('clip_value', 0.0), grad_scale)
-        for p in self.params:   # the kernel wrote behind autograd's back: invalidate packed-weight caches
+        self.bump_epoch()
+
+    def bump_epoch(self):
+        """The kernel wrote the weights behind autograd's back: invalidate the packed-weight caches keyed on the parameters
+        (run_nerf._packed_gen).  GraphedStep calls this after every replay (the recorded Python of step() ran only once)."""
+        for p in self.params:
             p._cnerf_epoch = getattr(p, "_cnerf_epoch", 0) + 1
+
+    RING = 4    # pinned scalar blocks in flight: the host may run this many steps ahead of the GPU before advance() waits
 
     def make_capturable(self):
         """Switch to the device-scalar Adam kernel so that step() can sit inside a captured hipGraph."""
-        if self._hyp_host is None:
-            self._hyp_host = torch.zeros(8, dtype=torch.float32).pin_memory()
+        if self._hyp_ring is None:
+            self._hyp_ring = [torch.zeros(8, dtype=torch.float32).pin_memory() for _ in range(self.RING)]
+            self._hyp_ev = [None] * self.RING
             self._hyp_dev = torch.zeros(8, device=self.flat_param.device, dtype=torch.float32)
         return self
 
     def advance(self, grad_scale: float = 1.0):
-        """Host half of a capturable step: count it and write its scalars (incl. the current param_groups lr) to the pinned
-        buffer the captured copy reads.  GraphedStep calls this before every replay."""
+        """Host half of a capturable step: count it, write its scalars (incl. the current param_groups lr) to the next pinned
+        block of the ring and enqueue the 32-byte upload on the CURRENT stream, i.e. ahead of the step's kernels (eager) or of
+        the graph replay that follows (GraphedStep).  A block is only rewritten once the upload that last read it has
+        completed (event), so a host running several steps ahead of the GPU can never hand step N the scalars of step N+k."""
         g = self.param_groups[0]
         self._step += 1
-        ops.adam_hyper(self._hyp_host, self._step, g['lr'], g['betas'][0], g['betas'][1], g['eps'], g.get('clip_value', 0.0),
+        i = self._step % self.RING
+        if self._hyp_ev[i] is not None:
+            self._hyp_ev[i].synchronize()
+        ops.adam_hyper(self._hyp_ring[i], self._step, g['lr'], g['betas'][0], g['betas'][1], g['eps'], g.get('clip_value', 0.0),
                        grad_scale)
+        self._hyp_dev.copy_(self._hyp_ring[i], non_blocking=True)
+        ev = self._hyp_ev[i] or torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self._hyp_ev[i] = ev
 
     def state_dict(self):
         state = {}

@@ -79,14 +79,63 @@ def _packed_still_valid(model, gen):
     return cache is not None and cache[2] - gen <= 1
 
 
+def _probe_engine_query():
+    """The direct-accumulate route and the merged coarse+fine backward ask the autograd engine, from inside a backward node,
+    whether another node is going to run in the same pass: `torch._C._will_engine_execute_node` — a PRIVATE symbol.  This
+    probe runs once at import, on the CPU: the symbol must exist, answer True for a leaf's AccumulateGrad node under
+    .backward(), and refuse (RuntimeError) or answer False under torch.autograd.grad().  Anything else -> (None, reason) and
+    the module selects the plain route explicitly: per-tensor gradients handed back to autograd, one backward per level."""
+    fn = getattr(torch._C, "_will_engine_execute_node", None)
+    if fn is None:
+        return None, "torch._C._will_engine_execute_node does not exist in this torch"
+    seen = []
+
+    class _Probe(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w):
+            ctx.w = w
+            return x * 1.0
+
+        @staticmethod
+        def backward(ctx, g):
+            with torch.enable_grad():
+                acc = ctx.w.view_as(ctx.w).grad_fn.next_functions[0][0]
+            try:
+                seen.append(bool(fn(acc)))
+            except RuntimeError:
+                seen.append("refused")
+            return g, None
+
+    try:
+        w = torch.ones(2, requires_grad=True)
+        _Probe.apply(w * 2.0, w).sum().backward()
+        torch.autograd.grad(_Probe.apply(w * 2.0, w).sum(), [w])
+    except Exception as e:   # noqa: BLE001 — any failure of the probe selects the plain route
+        return None, f"probing torch._C._will_engine_execute_node raised {type(e).__name__}: {e}"
+    if len(seen) != 2 or seen[0] is not True or seen[1] not in (False, "refused"):
+        return None, f"torch._C._will_engine_execute_node answered {seen} (expected [True, False | refused])"
+    return fn, None
+
+
+_ENGINE_QUERY, _ENGINE_QUERY_WHY = _probe_engine_query()
+if _ENGINE_QUERY is None:
+    import warnings
+    warnings.warn("consistentnerf_amd: " + _ENGINE_QUERY_WHY + " — training falls back to the plain autograd route "
+                  "(per-tensor gradients returned to autograd, coarse and fine backward launched separately); results are "
+                  "identical, the step is ~2 % slower", RuntimeWarning)
+
+
 def _engine_accumulates(p):
     """True when the running backward pass will ACCUMULATE into p.grad (loss.backward(), also with inputs=[...]); False
     under torch.autograd.grad(), where the engine captures the gradient of a leaf instead (it refuses the query for a
-    leaf's AccumulateGrad node in that mode — that refusal is the signal)."""
+    leaf's AccumulateGrad node in that mode — that refusal is the signal), and False when the engine query is unusable in
+    this torch (_probe_engine_query)."""
+    if _ENGINE_QUERY is None:
+        return False
     with torch.enable_grad():
         acc = p.view_as(p).grad_fn.next_functions[0][0]
     try:
-        return bool(torch._C._will_engine_execute_node(acc))
+        return bool(_ENGINE_QUERY(acc))
     except RuntimeError:
         return False
 
@@ -109,7 +158,7 @@ class _LevelPair:
 
 def _link_levels(raw_coarse, raw_fine):
     nc, nf = raw_coarse.grad_fn, raw_fine.grad_fn
-    if not MERGE_BWD or nc is None or nf is None:
+    if not MERGE_BWD or _ENGINE_QUERY is None or nc is None or nf is None:
         return
     if getattr(nc, "stash", None) is None or getattr(nf, "stash", None) is None or nc.model is nf.model:
         return
@@ -171,7 +220,7 @@ class _MlpFn(torch.autograd.Function):
             c = pair.coarse()
             # park only when the coarse node is certain to run in this very pass, on the direct route as well
             if (c is not None and c.stash is not None and _direct_ok(c.needs_input_grad[8:], c.params)
-                    and torch._C._will_engine_execute_node(c)):
+                    and _ENGINE_QUERY(c)):
                 pair.parked = (ctx.spec, ctx.packed, g_raw.contiguous(), ctx.B, ctx.S, ctx.stash, [p.grad for p in params],
                                ctx.model)
                 ctx.stash = ctx.packed = ctx.params = ctx.model = None
@@ -345,7 +394,7 @@ def _camera_path_ok(rays, c2w, near, far, use_viewdirs, c2w_staticcam, kwargs):
         return False
     if fine is not None and not isinstance(fine, NeRF):
         return False
-    if kwargs.get("verbose") and DEBUG:
+    if DEBUG:            # the ray-tensor path carries render_rays' NaN / Inf report (R:417-419)
         return False
     nets = [net] + ([fine] if fine is not None else [])
     if any(bool(n.use_viewdirs) != bool(use_viewdirs) for n in nets):
@@ -355,18 +404,44 @@ def _camera_path_ok(rays, c2w, near, far, use_viewdirs, c2w_staticcam, kwargs):
     return not (torch.is_grad_enabled() and any(p.requires_grad for n in nets for p in n.parameters()))
 
 
-def _render_camera(H, W, K, chunk, c2w, ndc, near, far, use_viewdirs, with_depth, kwargs):
-    """batchify_rays (R:55-67) + render_rays (R:311-421) over the image of one camera, rays generated in-kernel: one C
-    call per chunk, the same random streams in the same order as the ray-tensor path (bit-identical results)."""
+def camera_path_ok(c2w, render_kwargs):
+    """True when render(c2w=..., **render_kwargs) would take the in-kernel camera path (distributed.render_image_sharded asks
+    before calling render_pixels)."""
+    kw = dict(render_kwargs)
+    near, far = kw.pop("near", 0.), kw.pop("far", 1.)
+    return _camera_path_ok(None, c2w, near, far, kw.pop("use_viewdirs", False), kw.pop("c2w_staticcam", None), kw)
+
+
+def render_pixels(H, W, K, chunk, c2w, first, count, ndc=True, near=0., far=1., use_viewdirs=False, with_depth=False, **kwargs):
+    """The pixels [first, first + count) (row-major) of the image render(H, W, K, c2w=c2w, ...) would produce, as flat
+    per-ray maps {rgb_map [count, 3], disp_map [count], acc_map [count], ...}: the row block of one rank of a sharded frame
+    (distributed.render_image_sharded).  Inference only, stock network_query_fn only (camera_path_ok); the rays are generated
+    inside the kernels, and every pixel equals the one of the full-frame render bit for bit (rays are independent; chunk
+    boundaries do not matter, R:79-80) as long as no per-call random stream is involved (perturb = 0, raw_noise_std = 0)."""
+    if isinstance(c2w, torch.Tensor):
+        c2w = c2w[:3, :4]
+    if not _camera_path_ok(None, c2w, near, far, use_viewdirs, None, kwargs):
+        raise ops.CnerfError("render_pixels needs the in-kernel camera path (stock network_query_fn, scalar near / far, "
+                             "no autograd graph)")
+    return _render_camera(H, W, K, chunk, c2w, ndc, near, far, use_viewdirs, with_depth, kwargs, int(first), int(count))
+
+
+def _render_camera(H, W, K, chunk, c2w, ndc, near, far, use_viewdirs, with_depth, kwargs, first0=0, count=None):
+    """batchify_rays (R:55-67) + render_rays (R:311-421) over the image of one camera (or its pixels [first0, first0 +
+    count)), rays generated in-kernel: one C call per chunk, the same random streams in the same order as the ray-tensor
+    path (bit-identical results)."""
     net, fine = kwargs["network_fn"], kwargs.get("network_fine")
     Nc, Nf = kwargs["N_samples"], kwargs.get("N_importance", 0)
     perturb, pytest = kwargs.get("perturb", 0.), kwargs.get("pytest", False)
     std, dev = kwargs.get("raw_noise_std", 0.), next(net.parameters()).device
     coef = ndc_coefficients(H, W, K[0][0]) if ndc else (0., 0.)
     two_nets = fine is not None and Nf > 0
+    if isinstance(c2w, torch.Tensor):     # ONE device-to-host copy of the 12 pose floats per frame, not one per chunk
+        c2w = c2w.detach().cpu().numpy()
     all_ret = {}
-    for first in range(0, H * W, chunk):
-        B = min(chunk, H * W - first)
+    end = H * W if count is None else min(H * W, first0 + count)
+    for first in range(first0, end, chunk):
+        B = min(chunk, end - first)
         t_rand = None
         if perturb > 0.:
             t_rand = pytest_uniform((B, Nc), dev) if pytest else torch.rand(B, Nc, device=dev)

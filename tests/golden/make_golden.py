@@ -186,6 +186,54 @@ def fx_sample_pdf():
         save(f"sample_pdf_{tag}", samples=samples, cdf=cdf, u=u, inds=inds, margin=margin.float())
 
 
+def fx_sample_pdf_bulk():
+    """Bulk index parity at the C2 batch size (SURVEY hard part 3): the reference's OWN render_rays (R:311-421) on 4096 rays,
+    64 coarse + 128 fine samples, D=8/W=256 networks — its coarse pass produces the weights, its own call
+    `sample_pdf(z_vals_mid, weights[...,1:-1], N_importance, det=(perturb==0.), pytest=True)` (R:395-396) is intercepted together
+    with the `torch.searchsorted` inside it (H:232): inputs (bins, weights), u, cdf, inds.  Both the test-time path (perturb = 0:
+    u = linspace, incl. the u = 1.0 tie) and the training path (perturb = 1: pytest random stream).  Stored compactly: weights
+    fp32 (the MLP-produced input, not reproducible bit for bit elsewhere), bins fp32, inds as uint8, the per-sample margin
+    min_k |u - cdf_k| as a packed bit mask of `margin > 1e-5` (the test recomputes the values from the oracle's fp64 CDF)."""
+    coarse = make_model(H, 8, 256, True, 5, seed=21)
+    fine = make_model(H, 8, 256, True, 5, seed=22)
+    B = 4096
+    rays = I.ray_batch(B, seed=5, near=2.125, far=4.67)
+    cap = {}
+    real_ss, real_sp = torch.searchsorted, R.sample_pdf
+
+    def spy_ss(cdf, u, right=False, **kw):
+        inds = real_ss(cdf, u, right=right, **kw)
+        cap.update(cdf=cdf.clone(), u=u.clone(), inds=inds.clone())
+        return inds
+
+    def spy_sp(bins, weights, N_samples, det=False, pytest=False):
+        cap.update(bins=bins.clone(), weights=weights.clone(), det=det)
+        out = real_sp(bins, weights, N_samples, det=det, pytest=pytest)
+        cap.update(samples=out.clone())
+        return out
+    out = {}
+    for tag, perturb in (("det", 0.0), ("rand", 1.0)):
+        kw = _render_kwargs(R, coarse, fine, 64, 128, perturb, False, 0.0)
+        torch.searchsorted, R.sample_pdf = spy_ss, spy_sp
+        try:
+            with torch.no_grad():
+                R.render_rays(T(rays), pytest=True, **kw)
+        finally:
+            torch.searchsorted, R.sample_pdf = real_ss, real_sp
+        assert cap["det"] == (perturb == 0.0) and cap["bins"].shape == (B, 63) and cap["weights"].shape == (B, 62)
+        cdf, u, inds = cap["cdf"], cap["u"], cap["inds"]
+        assert int(inds.max()) <= 63 and int(inds.min()) >= 0
+        margin = (u[..., None].double() - cdf[:, None, :].double()).abs().min(-1).values
+        out[f"{tag}_bins"], out[f"{tag}_weights"] = cap["bins"], cap["weights"]
+        out[f"{tag}_inds"] = inds.numpy().astype(np.uint8)
+        out[f"{tag}_safe"] = np.packbits((margin > 1e-5).numpy())
+        out[f"{tag}_samples_sum"] = cap["samples"].double().sum(-1).float()
+        out[f"{tag}_n_safe"] = np.array(int((margin > 1e-5).sum()))
+        print(f"    {tag}: {int((margin <= 1e-5).sum())} of {margin.numel()} samples within 1e-5 of a CDF entry; "
+              f"{int((inds == 63).sum())} with inds == 63")
+    save("sample_pdf_bulk", **out)
+
+
 def _render_kwargs(Rmod, coarse, fine, Nc, Nf, perturb, white, noise, lindisp=False):
     embed_fn, _ = H.get_embedder(10, 0)
     embeddirs_fn, _ = H.get_embedder(4, 0)
@@ -870,7 +918,7 @@ def fx_ssloss_primary():
     save("ssloss_primary", **out)
 
 
-ALL = dict(train_v=fx_train_v, ssloss_primary=fx_ssloss_primary, ssloss=fx_ssloss, poses=fx_poses, patch=fx_patch, formats=fx_formats, raybank=fx_raybank, embed=fx_embed, mlp=fx_mlp, raw2outputs=fx_raw2outputs, sample_pdf=fx_sample_pdf,
+ALL = dict(train_v=fx_train_v, ssloss_primary=fx_ssloss_primary, ssloss=fx_ssloss, poses=fx_poses, patch=fx_patch, formats=fx_formats, raybank=fx_raybank, embed=fx_embed, mlp=fx_mlp, raw2outputs=fx_raw2outputs, sample_pdf=fx_sample_pdf, sample_pdf_bulk=fx_sample_pdf_bulk,
            render_rays=fx_render_rays, render_full=fx_render_full, warp=fx_warp, hardmask=fx_hardmask,
            losses=fx_losses, train=fx_train, pairs=fx_pairs)
 

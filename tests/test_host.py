@@ -198,13 +198,25 @@ def render_fn(H_, W_, K_, chunk, rays, **kw):   # any per-ray function stands in
     return [torch.sin(o * 1.7 + d * 3.1), (d * o).sum(-1)]
 def get_rays_fn(H_, W_, K_, c2w):
     return O.get_rays(H_, W_, K_, c2w)
-rgbs, disps = D.render_path_sharded(poses, (H, W, 9.0), K, 64, {}, render_fn=render_fn, get_rays_fn=get_rays_fn)
-assert calls == [(4, W, 3)] * 2, calls          # both ranks render ceil(7/2) = 4 rows per frame
-for i, c2w in enumerate(poses):
-    o, d = O.get_rays(H, W, K, c2w[:3, :4])
-    ref = render_fn(H, W, K, 64, torch.stack([o, d], 0))
-    assert np.array_equal(rgbs[i], ref[0].numpy()) and np.array_equal(disps[i], ref[1].numpy())
-assert rgbs.shape == (2, H, W, 3) and disps.shape == (2, H, W)
+ft = []
+res = D.render_path_sharded(poses, (H, W, 9.0), K, 64, {}, render_fn=render_fn, get_rays_fn=get_rays_fn, frame_times=ft)
+lo, hi = D.shard_bounds(H)
+assert calls == [(hi - lo, W, 3)] * 2, calls      # every rank renders ITS rows only (4 and 3 of 7); padding is output-side
+assert len(ft) == 2
+if rank == 0:
+    rgbs, disps = res
+    for i, c2w in enumerate(poses):
+        o, d = O.get_rays(H, W, K, c2w[:3, :4])
+        ref = render_fn(H, W, K, 64, torch.stack([o, d], 0))
+        assert np.array_equal(rgbs[i], ref[0].numpy()) and np.array_equal(disps[i], ref[1].numpy())
+    assert rgbs.shape == (2, H, W, 3) and disps.shape == (2, H, W)
+else:
+    assert res is None                             # render_path needs the frames on ONE host (R:157-159)
+# a frame with fewer rows than ranks: the rank without rows contributes an all-padding block
+res1 = D.render_path_sharded(poses[:1], (1, W, 9.0), I.intrinsics(1, W, 9.0), 64, {}, render_fn=render_fn, get_rays_fn=get_rays_fn)
+if rank == 0:
+    o, d = O.get_rays(1, W, I.intrinsics(1, W, 9.0), poses[0][:3, :4])
+    assert np.array_equal(res1[0][0], render_fn(1, W, None, 64, torch.stack([o, d], 0))[0].numpy())
 D.barrier()
 if rank == 0: print("RENDER_OK", world)
 dist.destroy_process_group()
@@ -212,7 +224,8 @@ dist.destroy_process_group()
 
 
 def test_two_rank_gloo_sharded_render_path(tmp_path):
-    """render_path rows sharded over 2 ranks (gloo): edge-padded blocks, one all-gather per output, frame == unsharded."""
+    """render_path rows sharded over 2 ranks (gloo): each rank renders its own rows, ONE gather of the packed (edge-padded)
+    blocks to rank 0 per frame, frame == unsharded."""
     script = tmp_path / "render_worker.py"
     script.write_text(RENDER_WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", OMP_NUM_THREADS="2")
@@ -308,3 +321,43 @@ def test_no_inline_asm_valu_next_to_mfma(tmp_path):
     assert pick("wgrad_kENS")["private_segment_fixed_size"] == 0 and pick("wgrad_kENS")["vgpr_spill_count"] == 0
     assert all(v["vgpr_count"] <= 512 for v in meta.values())
     assert pick("mlp_fwd_kILi8ELb1ELb1E")["sgpr_spill_count"] == 0 and pick("mlp_fwd_kILi8ELb1ELb1E")["vgpr_spill_count"] <= 8
+
+
+def test_engine_query_probe_selects_the_plain_route_without_the_private_symbol(monkeypatch):
+    """run_nerf's direct-accumulate route and merged coarse+fine backward depend on torch._C._will_engine_execute_node (private).
+    The import-time probe must accept this torch's symbol, reject a missing one and one that answers differently, and with the
+    query unusable the routing helpers must select the plain autograd route (no direct accumulation, no level pairing)."""
+    import torch
+    import consistentnerf_amd.run_nerf as R
+    fn, why = R._probe_engine_query()
+    assert fn is not None and why is None and R._ENGINE_QUERY is not None
+    real = torch._C._will_engine_execute_node
+    monkeypatch.delattr(torch._C, "_will_engine_execute_node")
+    fn, why = R._probe_engine_query()
+    assert fn is None and "does not exist" in why
+    monkeypatch.setattr(torch._C, "_will_engine_execute_node", lambda node: True, raising=False)   # never refuses
+    fn, why = R._probe_engine_query()
+    assert fn is None and "answered" in why
+    monkeypatch.setattr(torch._C, "_will_engine_execute_node", lambda node: 1 / 0, raising=False)    # raises something else
+    fn, why = R._probe_engine_query()
+    assert fn is None and "ZeroDivisionError" in why
+    monkeypatch.setattr(torch._C, "_will_engine_execute_node", real, raising=False)
+    assert R._probe_engine_query()[0] is not None
+    # routing with the query switched off
+    monkeypatch.setattr(R, "_ENGINE_QUERY", None)
+    p = torch.nn.Parameter(torch.ones(3))
+    assert R._engine_accumulates(p) is False
+
+    class N:     # stand-ins for two _MlpFn nodes with distinct models
+        def __init__(self):
+            self.stash, self.model = object(), object()
+
+    class Raw:
+        def __init__(self):
+            self.grad_fn = N()
+    a, b = Raw(), Raw()
+    R._link_levels(a, b)
+    assert not hasattr(a.grad_fn, "pair") and not hasattr(b.grad_fn, "pair")
+    monkeypatch.setattr(R, "_ENGINE_QUERY", real)
+    R._link_levels(a, b)
+    assert a.grad_fn.pair is b.grad_fn.pair

@@ -98,6 +98,34 @@ def test_sample_pdf(tag):
         eq(O.pytest_uniform((256, 128)), g["u"], "u stream")
 
 
+def _bulk_u(tag, B=4096, Nf=128):
+    """the u of the reference's call: linspace(0, 1, Nf) broadcast (det, H:224-226) or its pytest stream (H:227-229)"""
+    if tag == "det":
+        return torch.from_numpy(np.broadcast_to(np.linspace(0., 1., Nf), (B, Nf)).astype(np.float32).copy())
+    return O.pytest_uniform((B, Nf))
+
+
+@pytest.mark.parametrize("tag", ["det", "rand"])
+def test_sample_pdf_bulk(tag):
+    """C2-size capture (4096 x 128) of the reference's own sample_pdf call inside render_rays, weights produced by its D=8/W=256
+    coarse pass: the oracle reproduces every index (bit-exact target) and the per-row sample sums."""
+    g = golden("sample_pdf_bulk")
+    bins, weights = T(g[tag + "_bins"]), T(g[tag + "_weights"])
+    samples, inds = O.sample_pdf(bins, weights, _bulk_u(tag))
+    safe = np.unpackbits(g[tag + "_safe"])[:inds.numel()].reshape(inds.shape).astype(bool)
+    assert int(safe.sum()) == int(g[tag + "_n_safe"])
+    mism = inds.numpy() != g[tag + "_inds"].astype(np.int64)
+    assert not (mism & safe).any(), "oracle indices differ from the reference away from CDF ties"
+    assert mism.sum() == 0, f"{mism.sum()} index mismatches at ties (same ATen build: none expected)"
+    close(samples.double().sum(-1).float(), g[tag + "_samples_sum"], rtol=1e-6, atol=1e-5)
+    # the coarse depths behind `bins` are a deterministic elementwise function of the rays: the fixture's bins must be the
+    # midpoints of the oracle's coarse_z on the same rays
+    rays = T(I.ray_batch(4096, seed=5, near=2.125, far=4.67))
+    t_rand = O.pytest_uniform((4096, 64)) if tag == "rand" else None
+    z = O.coarse_z(rays[:, 6:7], rays[:, 7:8], 64, False, t_rand)
+    eq(0.5 * (z[:, 1:] + z[:, :-1]), g[tag + "_bins"], "bins")
+
+
 RR = [("C1", 4, 128, 64, 0, 1.0, True, 0.0, False, 64), ("C1_noise", 4, 128, 64, 0, 1.0, True, 1.0, False, 32),
       ("C2", 8, 256, 64, 128, 1.0, False, 0.0, False, 64), ("C2_det", 8, 256, 64, 128, 0.0, False, 0.0, False, 16),
       ("small_lindisp", 4, 128, 32, 32, 1.0, False, 0.0, True, 32)]
