@@ -21,7 +21,9 @@
 // GEMMs are launched largest-first over many small point ranges so the tail of the grid is short (measured makespan =
 // the packing bound at M = 786 432); split partials are reduced in a fixed order by a second kernel (bit-reproducible
 // run to run).
+#include <math.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "mlp_common.hpp"
 
@@ -47,6 +49,8 @@ struct WgJob {
   int ld, col0;       // its row stride and first column
   int bias_tensor;    // -1: none
   int gk, an, ak;     // wave grid: wave w -> (wn, wk) = (w / gk, w % gk) owns an x ak tiles of 32x32
+  int nsplit, chunk;  // this GEMM's point ranges: `nsplit` workgroups of `chunk` points (multiple of 32) each
+  int first;          // linear block id of its first range (the grid is 1-D, jobs back to back, longest workgroups first)
 };
 
 // One network's operands.  A launch carries up to two (the coarse and the fine network of a training step, whose
@@ -58,14 +62,13 @@ struct WgNet {
   const float* G;
   float* partials;
   int64_t Mp, pstride;               // pstride = floats per split slice
-  int64_t chunk;                     // points per split (multiple of 32)
   int s_rows, g_rows;
-  int nsplit;                        // point ranges of this network (blocks with blockIdx.x >= nsplit have no work)
 };
 
 struct WgArgs {
   WgJob job[MAX_WG_JOBS];
   WgNet net[2];
+  int nj;
 };
 
 // The kernel argument block is read IN PLACE through the constant address space (scalar loads from the kernarg
@@ -101,15 +104,15 @@ __device__ __forceinline__ i32x4 dma_rsrc(const float* base, unsigned bytes) {
 // Body for a compile-time per-wave tile block AN x AK (<= 4 x 4); BS: this wave also sums the X columns (bias).
 template <int AN, int AK, bool BS>
 __device__ __forceinline__ void wgrad_body(WgNetC& a, WgJobC& jb, float* lds) {
-  const int split = blockIdx.x;
+  const int split = __builtin_amdgcn_readfirstlane((int)blockIdx.x - jb.first);
   const int tid = threadIdx.x, lane = tid & 63, i31 = lane & 31, hh = lane >> 5;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform on the scalar unit: addresses stay SALU
   const int wn = wv / jb.gk, wk = wv - wn * jb.gk;
   // (the by-value argument struct is indexed dynamically, so it lives in scratch: anything the slab loop needs is
   // pulled into SGPRs here — a scratch_load inside the loop would also drain vmcnt, i.e. wait for the DMA in flight)
   const int g_rows4 = __builtin_amdgcn_readfirstlane(a.g_rows * 4), s_rows4 = __builtin_amdgcn_readfirstlane(a.s_rows * 4);
-  const int64_t m_begin = (int64_t)split * a.chunk;
-  const int64_t m_end = m_begin + a.chunk < a.Mp ? m_begin + a.chunk : a.Mp;
+  const int64_t m_begin = (int64_t)split * jb.chunk;
+  const int64_t m_end = m_begin + jb.chunk < a.Mp ? m_begin + jb.chunk : a.Mp;
   const int nslab = __builtin_amdgcn_readfirstlane(m_end > m_begin ? (int)((m_end - m_begin) / TM) : 0);
   const int ntn = (jb.N + 31) >> 5, ntk = (jb.K + 31) >> 5;
   const int tn0 = __builtin_amdgcn_readfirstlane(wn * AN), tk0 = __builtin_amdgcn_readfirstlane(wk * AK);   // first n / k tile of this wave
@@ -323,9 +326,12 @@ __global__ __launch_bounds__(64 * NWAVES) void wgrad_k(WgArgs a_by_value) {
   extern __shared__ __attribute__((aligned(16))) float lds[];   // [2 buffers][X slab | Y slab]
   (void)a_by_value;   // (the first and only explicit kernel argument: offset 0 of the kernarg segment)
   WgArgsC& args = *(WgArgsC*)__builtin_amdgcn_kernarg_segment_ptr();
-  WgJobC& jb = args.job[blockIdx.y];
+  // 1-D grid, jobs back to back: the job of this block = the last one whose first block id is <= blockIdx.x (scalar loads
+  // from the kernarg segment, <= 28 entries)
+  int ji = 0;
+  for (int i = 1; i < args.nj; ++i) ji = (int)blockIdx.x >= args.job[i].first ? i : ji;
+  WgJobC& jb = args.job[ji];
   WgNetC& a = args.net[jb.net];
-  if ((int)blockIdx.x >= a.nsplit) return;   // block-uniform: the grid's x extent is the larger network's range count
   switch (jb.an * 8 + jb.ak) {     // block-uniform
     case 4 * 8 + 4: wgrad_disp<4, 4>(a, jb, lds); break;
     case 4 * 8 + 2: wgrad_disp<4, 2>(a, jb, lds); break;
@@ -411,16 +417,14 @@ int64_t cn_param_floats(const NetGeom& g) {
 }
 
 int cn_wgrad_nsplit(int64_t Mp) {
-  // many small point ranges (>= 64 slabs of 32 points each) so that the ~15 GEMMs x nsplit workgroups of
-  // unequal size pack well onto 256 CUs; capped to bound the partial-gradient buffer (nsplit x 4.8 MB)
-  int64_t s = Mp / 4096;
+  // CAPACITY of the partial-gradient buffer in slices (each cn_param_floats(g) ~ 2.4 MB at D=8/W=256): the most point ranges
+  // any GEMM of this network may be cut into — ranges of >= 16 slabs (512 points), at most 128 of them, and <= 65536 points
+  // per range (a range's rows stay within 32-bit byte offsets).  How many each GEMM actually gets is planned per launch
+  // (plan_ranges); the buffer is sized for the cap.
+  int64_t s = Mp / 512;
   if (s < 1) s = 1;
   if (s > 128) s = 128;
-  if (s * 65536 < Mp) s = (Mp + 65535) / 65536;   // <= 65536 points per range: a range's rows stay within 32-bit byte offsets
-  if (const char* e = getenv("CNERF_WGRAD_NSPLIT")) {   // tuning knob (scripts/kbench.py); both callers see the same value
-    const int v = atoi(e);
-    if (v >= 1 && v <= 256 && (int64_t)v * 65536 >= Mp) s = v;
-  }
+  if (s * 65536 < Mp) s = (Mp + 65535) / 65536;
   return (int)s;
 }
 
@@ -428,7 +432,7 @@ namespace {
 
 // Appends one network's GEMMs to the job table / reduction table.  Returns false when a shape is outside the envelope.
 bool add_net_jobs(const NetGeom& g, int netidx, const float* stash, const float* G, int64_t Mp, float* partials,
-                  int nsplit, const cnerf_ptrs* grads, WgArgs& a, int& nj, RedArgs& r, int& nr) {
+                  const cnerf_ptrs* grads, WgArgs& a, int& nj, RedArgs& r, int& nr) {
   cnerf_net net{g.D, g.W, g.L, g.Ld, g.viewdirs, g.out_ch, g.skip};
   WgNet& wn = a.net[netidx];
   const int nt = cnerf_num_tensors(&net);
@@ -441,7 +445,7 @@ bool add_net_jobs(const NetGeom& g, int netidx, const float* stash, const float*
     r.numel[r0 + i] = rr * cc;
     r.grad[r0 + i] = grads->p[i];
     r.part[r0 + i] = partials + off;
-    r.nsplit[r0 + i] = nsplit;
+    r.nsplit[r0 + i] = 0;
     r.touched[r0 + i] = 0;
     off += cn_round_up(rr * cc, 4);
   }
@@ -464,7 +468,7 @@ bool add_net_jobs(const NetGeom& g, int netidx, const float* stash, const float*
     }
     if (best_gk == 0 || best_an == 3 || best_ak == 3 || ntn > 8 || ntk > 8 || nj >= MAX_WG_JOBS) { ok = false; return; }
     a.job[nj++] = WgJob{netidx, xcol, ycol, N, K, n_lo, tensor, ld, col0, bias_tensor, best_gk ? best_gk : 2, best_an,
-                        best_ak};
+                        best_ak, 1, 0, 0};
     r.touched[r0 + tensor] = 1;
     if (bias_tensor >= 0) r.touched[r0 + bias_tensor] = 1;
   };
@@ -487,55 +491,162 @@ bool add_net_jobs(const NetGeom& g, int netidx, const float* stash, const float*
     add(g.g_out, g.s_h[D - 1], g.out_ch, W, base + 2, W, 0, base + 3);
   }
   wn.stash = stash; wn.G = G; wn.partials = partials; wn.Mp = Mp; wn.pstride = pstride;
-  wn.s_rows = g.s_rows; wn.g_rows = g.g_rows; wn.nsplit = nsplit;
-  wn.chunk = cn_round_up(cn_div_up(Mp, nsplit), TM);
-  // a split's operand rows sit behind one buffer resource each: 32-bit byte offsets
-  if (wn.chunk * (int64_t)(g.s_rows > g.g_rows ? g.s_rows : g.g_rows) * 4 >= (int64_t)0x7fffffff) ok = false;
+  wn.s_rows = g.s_rows; wn.g_rows = g.g_rows;
   return ok;
+}
+
+// CNERF_WGRAD_NSPLIT="a" or "a,b": tuning knob (scripts/kbench_pair.py) — every GEMM of network 0 (and 1) gets exactly a (b) ranges
+void forced_counts(int* f) {
+  f[0] = f[1] = 0;
+  if (const char* e = getenv("CNERF_WGRAD_NSPLIT")) {
+    f[0] = f[1] = atoi(e);
+    if (const char* c = strchr(e, ',')) f[1] = atoi(c + 1);
+  }
+}
+
+// ---- how many point ranges each GEMM gets -------------------------------------------------------------------------------
+// A workgroup occupies a whole CU (160 KiB of LDS) for (its range's slabs) x (its GEMM's time per slab: 1024 cycles per 32x32
+// tile of the busiest wave + ~560 of barrier — measured 17000-17220 / 8830-8920 / 4705-4860 / 2563-2582 / 1540-1680 cycles
+// for 16 / 8 / 4 / 2 / 1 tiles, scripts/wgrad_trace.py); blocks go to the 8 XCDs round-robin in grid order (block i runs on
+// XCC i % 8, measured), each XCD hands its blocks to its first free CU; the launch is over when the last one finishes.
+// Rounds 1-2 cut every GEMM of a network into Mp / 4096 ranges: right at 4096 rays (128 + 64 ranges, 10 rounds), ruinous at the
+// 512 rays per GPU of the 8-way strong-scaling shard (24 + 8 ranges: the 256 long workgroups are exactly ONE round at 0.95 ms,
+// the 192 short ones a second, mostly empty one — 1.88 ms for 1.0 ms of MFMA work at peak).  A dispatch simulator fed with the
+// measured slab costs predicts a plan's makespan to ~2 % at a fixed clock, but could not rank plans that close: the clock the
+// chip sustains depends on the mix in flight (equal-duration plans that the simulator preferred ran 5-15 % slower than plans of
+// many unequal workgroups).  So the rule is read off a measured grid sweep at 512 / 1024 / 4096 rays (fine x coarse counts,
+// profiles/r03_wgrad_grid.txt; flat within ~1 % for counts of 32-64, cliffs when the smaller network gets < 1/4 of the larger
+// one's count): 64 ranges for a network of >= 3072 slabs (98 304 points), 32 for a smaller one, never shorter than 16 slabs,
+// never beyond the partial buffer's capacity — (64, 32) at 512 and 1024 rays, (64, 64) from 1536 rays up.  The count depends on
+// the network's OWN point count only, so the merged coarse+fine launch sums its partials in exactly the order of two separate
+// launches (bit-identical gradients, tests), and every GEMM of a network shares it (GEMMs that write columns of one parameter
+// tensor must: one reduction per tensor).
+void plan_ranges(WgArgs& a, int nj, const int* cap, int* ns_out) {
+  int forced[2];
+  forced_counts(forced);
+  for (int i = 0; i < nj; ++i) {
+    const int net = a.job[i].net;
+    const int64_t slabs = a.net[net].Mp / TM;
+    int v = slabs >= 3072 ? 64 : (slabs >= 512 ? 32 : (int)(slabs / 16));
+    if (forced[0] > 0) v = forced[net] > 0 ? forced[net] : forced[0];
+    const int64_t vmin = (slabs * TM + 98303) / 98304;   // <= 98304 points per range: 32-bit byte offsets of a range's rows
+    if (v < vmin) v = (int)vmin;
+    if (v > cap[net]) v = cap[net];
+    if ((int64_t)v > slabs) v = (int)slabs;
+    ns_out[i] = v < 1 ? 1 : v;
+  }
+}
+
+void order_jobs(const WgJob* job, int nj, const int* ns, const int64_t* slabs, int* order) {
+  // longest workgroups first (stable): the short ones fill the tail
+  for (int i = 0; i < nj; ++i) order[i] = i;
+  auto t = [&](int i) { return (double)((slabs[i] + ns[i] - 1) / ns[i]) * (1024.0 * job[i].an * job[i].ak + 560.0); };
+  for (int i = 1; i < nj; ++i) {
+    const int v = order[i];
+    int k = i - 1;
+    for (; k >= 0 && t(order[k]) < t(v); --k) order[k + 1] = order[k];
+    order[k + 1] = v;
+  }
 }
 
 }  // namespace
 
-// Weight gradients of one network (n = 1) or of two independent ones in one grid (n = 2; cnerf_mlp_bwd_pair).
+// Weight gradients of one network (n = 1) or of two independent ones in one grid (n = 2; cnerf_mlp_bwd_pair).  `nsplit` is the
+// capacity of each network's partial buffer in slices (cn_wgrad_nsplit).
 int cn_wgrad_launch_n(int n, const NetGeom* const* g, const float* const* stash, const float* const* G, const int64_t* Mp,
                       float* const* partials, const int* nsplit, const cnerf_ptrs* const* grads, int accumulate,
                       hipStream_t st) {
   WgArgs a;
   RedArgs r;
-  int nj = 0, nr = 0, max_split = 0;
+  int nj = 0, nr = 0, r0[2] = {0, 0};
   for (int i = 0; i < n; ++i) {
-    if (!add_net_jobs(*g[i], i, stash[i], G[i], Mp[i], partials[i], nsplit[i], grads[i], a, nj, r, nr))
-      return CNERF_E_UNSUPPORTED;
-    max_split = nsplit[i] > max_split ? nsplit[i] : max_split;
+    r0[i] = nr;
+    if (!add_net_jobs(*g[i], i, stash[i], G[i], Mp[i], partials[i], grads[i], a, nj, r, nr)) return CNERF_E_UNSUPPORTED;
   }
   if (n == 1) a.net[1] = a.net[0];
-  // largest workgroups first (the grid is dispatched job-major): the busiest wave's tile count x the points of a range;
-  // the small ones fill the tail.  Stable, so one network's GEMMs keep their order.
-  auto cost = [&](const WgJob& j) { return (int64_t)j.an * j.ak * a.net[j.net].chunk; };
-  for (int i = 1; i < nj; ++i) {
-    const WgJob j = a.job[i];
-    int k = i - 1;
-    for (; k >= 0 && cost(a.job[k]) < cost(j); --k) a.job[k + 1] = a.job[k];
-    a.job[k + 1] = j;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return CNERF_E_NODEVICE;
+  int ns[MAX_WG_JOBS];
+  {
+    const int cap[2] = {nsplit[0], n > 1 ? nsplit[1] : nsplit[0]};
+    plan_ranges(a, nj, cap, ns);
   }
+  int64_t slabs[MAX_WG_JOBS];
+  int order[MAX_WG_JOBS];
+  for (int i = 0; i < nj; ++i) {
+    WgJob& j = a.job[i];
+    slabs[i] = a.net[j.net].Mp / TM;
+    j.nsplit = ns[i];
+    j.chunk = (int)(cn_div_up(slabs[i], (int64_t)ns[i]) * TM);
+    // a range's operand rows sit behind one buffer resource each: 32-bit byte offsets
+    const NetGeom& gg = *g[j.net];
+    if ((int64_t)j.chunk * (gg.s_rows > gg.g_rows ? gg.s_rows : gg.g_rows) * 4 >= (int64_t)0x7fffffff) return CNERF_E_UNSUPPORTED;
+    if (j.nsplit > nsplit[j.net]) return CNERF_E_UNSUPPORTED;
+    r.nsplit[r0[j.net] + j.tensor] = j.nsplit;
+    if (j.bias_tensor >= 0) r.nsplit[r0[j.net] + j.bias_tensor] = j.nsplit;
+  }
+  // grid order: longest workgroups first, jobs back to back
+  order_jobs(a.job, nj, ns, slabs, order);
+  WgArgs b = a;
+  int first = 0;
+  for (int oi = 0; oi < nj; ++oi) {
+    b.job[oi] = a.job[order[oi]];
+    b.job[oi].first = first;
+    first += b.job[oi].nsplit;
+  }
+  b.nj = nj;
   const size_t lds_bytes = LDS_BYTES;
   // the 160 KiB dynamic-LDS opt-in is a per-device function attribute: set it once per device this process launches on
   // (idempotent, so a race between two host threads only repeats the call)
   static bool attr_set[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return CNERF_E_NODEVICE;
   if (!attr_set[dev]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_k), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds_bytes) != hipSuccess)
       return (int)hipGetLastError();
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL(wgrad_k, dim3(max_split, nj), dim3(64 * NWAVES), lds_bytes, st, a);
+  hipLaunchKernelGGL(wgrad_k, dim3(first), dim3(64 * NWAVES), lds_bytes, st, b);
   CN_CHECK_LAUNCH();
   r.accumulate = accumulate;
   hipLaunchKernelGGL(wgrad_reduce_k, dim3(64, nr), dim3(256), 0, st, r);
   CN_CHECK_LAUNCH();
   return CNERF_OK;
+}
+
+// Host-only view of the range plan (no launch, no device): for the GEMM jobs of one or two networks at Mp0 / Mp1 points ->
+// per job {net, N, K, tiles of the busiest wave, ranges, points per range, destination tensor} (7 ints each, grid order).
+// Returns the number of jobs.  Used by tests/test_host.py and scripts/wgrad_plan.py.
+extern "C" int cnerf_debug_wgrad_plan(const cnerf_net* net0, int64_t Mp0, const cnerf_net* net1, int64_t Mp1, int* out7,
+                                      int max_jobs) {
+  NetGeom g[2];
+  const cnerf_net* nets[2] = {net0, net1};
+  const int64_t Mps[2] = {cn_round_up(Mp0, 32), cn_round_up(Mp1, 32)};
+  const int n = net1 ? 2 : 1;
+  WgArgs a;
+  RedArgs r;
+  cnerf_ptrs dummy;
+  memset(&dummy, 0, sizeof(dummy));
+  int nj = 0, nr = 0, cap[2] = {1, 1};
+  for (int i = 0; i < n; ++i) {
+    int rc = cn_make_geom(nets[i], &g[i]);
+    if (rc) return rc < 0 ? rc : -rc;
+    if (!add_net_jobs(g[i], i, nullptr, nullptr, Mps[i], nullptr, &dummy, a, nj, r, nr)) return CNERF_E_UNSUPPORTED;
+    cap[i] = cn_wgrad_nsplit(Mps[i]);
+  }
+  if (n == 1) cap[1] = cap[0];
+  if (nj > max_jobs) return CNERF_E_ARG;
+  int ns[MAX_WG_JOBS], order[MAX_WG_JOBS];
+  int64_t slabs[MAX_WG_JOBS];
+  plan_ranges(a, nj, cap, ns);
+  for (int i = 0; i < nj; ++i) slabs[i] = a.net[a.job[i].net].Mp / TM;
+  order_jobs(a.job, nj, ns, slabs, order);
+  for (int oi = 0; oi < nj; ++oi) {
+    const WgJob& j = a.job[order[oi]];
+    int* o = out7 + 7 * oi;
+    o[0] = j.net; o[1] = j.N - j.n_lo; o[2] = j.K; o[3] = j.an * j.ak; o[4] = ns[order[oi]];
+    o[5] = (int)(cn_div_up(slabs[order[oi]], (int64_t)ns[order[oi]]) * TM); o[6] = j.tensor;
+  }
+  return nj;
 }
 
 int cn_wgrad_launch(const NetGeom& g, const float* stash, const float* G, int64_t M, int64_t Mp, float* partials,

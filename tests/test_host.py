@@ -361,3 +361,37 @@ def test_engine_query_probe_selects_the_plain_route_without_the_private_symbol(m
     monkeypatch.setattr(R, "_ENGINE_QUERY", real)
     R._link_levels(a, b)
     assert a.grad_fn.pair is b.grad_fn.pair
+
+
+def test_wgrad_range_plan_invariants():
+    """csrc/wgrad.hip::plan_ranges through its host-only debug view (no GPU): for the merged coarse+fine launch at the C4 shard
+    (512 rays), the C2 batch (4096 rays) and ragged / tiny sizes — every range is a whole number of 32-point slabs and the
+    ranges of a GEMM cover its network's points; GEMMs writing one parameter tensor share their count; 64 ranges from 98 304
+    points up, 32 below (the measured optimum: (64, 32) at the C4 shard, (64, 64) at C2); the count of a network does not
+    depend on its partner in a merged launch (merged == separate, bit for bit); workgroups are launched longest first;
+    counts stay within the partial buffer's capacity."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import wgrad_plan
+    for B in (1, 7, 64, 512, 1000, 4096, 32768):
+        jobs = wgrad_plan.plan(B)
+        assert len(jobs) == 28
+        t_prev = None
+        by_tensor = {}
+        for net, N, K, tiles, ns, ch, tensor in jobs:
+            Mp = (B * (192 if net == 0 else 64) + 31) // 32 * 32
+            assert ch % 32 == 0 and ns >= 1 and ns * ch >= Mp and (ns - 1) * ch < Mp, (B, net, ns, ch, Mp)
+            assert ns <= max(1, min(128, Mp // 512)) and ch * 2600 * 4 < 2 ** 31
+            by_tensor.setdefault((net, tensor), set()).add(ns)
+            t = ch // 32 * (1024 * tiles + 560)
+            assert t_prev is None or t <= t_prev, "grid order must be longest workgroup first"
+            t_prev = t
+        assert all(len(v) == 1 for v in by_tensor.values())
+        n_f = {ns for net, *_, ns, ch, t in jobs if net == 0}
+        n_c = {ns for net, *_, ns, ch, t in jobs if net == 1}
+        assert len(n_f) == 1 and len(n_c) == 1
+        n_f, n_c = n_f.pop(), n_c.pop()
+        if B >= 512:
+            assert n_f == 64 and n_c == (64 if B >= 1536 else 32), (B, n_f, n_c)
+        # one network alone gets the same count as in the merged launch
+        assert {j[4] for j in wgrad_plan.plan(B, S=(192,))} == {n_f} and {j[4] for j in wgrad_plan.plan(B, S=(64,))} == {n_c}
+    assert len(wgrad_plan.plan(4096, S=(192,))) == 14
