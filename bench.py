@@ -465,7 +465,7 @@ def c3_leg(dev, steps=20):
 
 def pmc_traffic(kernel, points):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
-    each in their own `--pmc` run, scripts/gpu_pmc.sh -> profiles/r02_pmc/, r01_pmc_final/ as a fallback): KB units,
+    each in their own `--pmc` run, scripts/gpu_pmc.sh -> profiles/r03_pmc/): KB units,
     FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md (16-byte-per-lane streaming reads are tallied at
     half).  A STATIC LOOKUP, not a measurement of this run (counters cannot be sampled from inside this process); None when
     no pass of that kernel at that launch size is on file."""
@@ -474,8 +474,9 @@ def pmc_traffic(kernel, points):
     name = {"mlp_wgrad": "wgrad", "mlp_dgrad": "mlp_dgrad", "mlp_fwd_train": "mlp_fwd_train", "mlp_fwd": "mlp_fwd_inf"}.get(kernel)
     # grid threads of the launch: forward / dgrad run 64 threads per 32 points; wgrad's grid is (point ranges) x (GEMMs) x
     # 256 threads: 128 x 14 for the fine level alone (round 1), 128 x 28 for both levels in one grid (round 2)
-    want = {"wgrad": {786432: 128 * 14 * 256, 1048576: 128 * 28 * 256}.get(points)}.get(name, 2 * points)
-    for d in ("r02_pmc", "r01_pmc_final"):
+    # round 3: a 1-D grid of (ranges) x 256 threads: 64 ranges x 14 GEMMs for the fine level alone, 64 x 28 for both levels
+    want = {"wgrad": {786432: 64 * 14 * 256, 1048576: 64 * 28 * 256}.get(points)}.get(name, 2 * points)
+    for d in ("r03_pmc",):
         val = {}
         for f, ctr in (("pass2_summary.csv", "FETCH_SIZE"), ("pass3_summary.csv", "WRITE_SIZE")):
             path = os.path.join(here, "profiles", d, f)

@@ -68,14 +68,16 @@ struct BfPackJob {
 struct BfCopyJob { const float* src; int n; int64_t dst; };
 struct BfPackArgs { BfPackJob job[24]; BfCopyJob cp[24]; int njobs, ncopies, NP; unsigned char* out; };
 
-__global__ void pack_bf_k(BfPackArgs a) {
+__global__ void pack_bf_k(BfPackArgs a_by_value) {
+  (void)a_by_value;   // job table read in place from the kernarg segment (a by-value copy indexed by blockIdx.y lives in scratch)
+  const __attribute__((address_space(4))) BfPackArgs& a = *(const __attribute__((address_space(4))) BfPackArgs*)__builtin_amdgcn_kernarg_segment_ptr();
   if ((int)blockIdx.y >= a.njobs) {
-    const BfCopyJob c = a.cp[blockIdx.y - a.njobs];
+    const __attribute__((address_space(4))) BfCopyJob& c = a.cp[blockIdx.y - a.njobs];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < c.n; i += gridDim.x * blockDim.x)
       reinterpret_cast<float*>(a.out + c.dst)[i] = c.src[i];
     return;
   }
-  const BfPackJob j = a.job[blockIdx.y];
+  const __attribute__((address_space(4))) BfPackJob& j = a.job[blockIdx.y];
   const int NTO = j.NTM, NP = a.NP;             // tiles per K-step in memory (rows >= N are zero)
   const int64_t n = (int64_t)(j.Kp / 16) * NTO * 512;           // (s, to, i, hh, e): all planes of one weight together
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {

@@ -357,7 +357,9 @@ struct RedArgs {    // entries [0, nt0) belong to the first network, [nt0, nt0 +
 
 // Fixed-order sum of the split partials (bit-reproducible).  Bandwidth-bound (nsplit x ~2.4 MB): 16-byte loads, 8
 // independent partial streams in flight per thread, enough blocks to cover the chip.
-__global__ __launch_bounds__(256) void wgrad_reduce_k(RedArgs a) {
+__global__ __launch_bounds__(256) void wgrad_reduce_k(RedArgs a_by_value) {
+  (void)a_by_value;   // read in place (kernarg segment, scalar loads): indexed by blockIdx.y a by-value copy lives in scratch
+  const CN_CONST RedArgs& a = *(const CN_CONST RedArgs*)__builtin_amdgcn_kernarg_segment_ptr();
   const int t = blockIdx.y;
   float* g = a.grad[t];
   if (g == nullptr) return;

@@ -18,7 +18,20 @@ Two sides, because the CPU side needs no GPU (and the GPU box's minutes are budg
   python scripts/psnr_parity.py hip --oracle profiles/r02_psnr_oracle.npz --out profiles/r02_psnr_parity_seeds.json
         on the MI355X: the HIP runs on the same seeds / batches, then the merged statistics.
 
-Reduced size so the CPU side finishes: 64x80 images, 512-ray batches, coarse 64 + fine 64+128, D=8/W=256, viewdirs.
+Reduced size so the CPU side finishes: 64x80 images, 512-ray batches, coarse 64 + fine 64+128, D=8/W=256, viewdirs
+(`--size c2` on either side: the TRUE C2 shapes — 512x640 images, 4096-ray batches, near 2.125 / far 4.67).
+
+Round 3 (criteria fixed BEFORE the runs):
+  chaos   python scripts/psnr_parity.py chaos --seeds 0..31 --steps 600          (MI355X; HIP vs HIP started 1 ulp away)
+          sigma_chaos(steps) = rms over seeds of PSNR(HIP+1ulp) - PSNR(HIP) at each milestone: the spread ANY bit-different
+          correct implementation shows.
+  curve   oracle --milestones 25 50 100 150 300 600 (CPU) then hip --curve: gap(steps) = mean over seeds of PSNR(HIP) -
+          PSNR(oracle) at each milestone.
+          Criterion A (pre-decorrelation): at every milestone where the two loss curves still agree to 1e-3 relative on every
+          seed, |gap| <= 0.02 dB on every seed.
+          Criterion B (after decorrelation): |mean gap| <= 2 sigma_chaos(steps) / sqrt(n_seeds) at every milestone.
+  c2      one seed at the true C2 batch size, 150 steps: |gap| <= 2 sigma_chaos_c2(150) with sigma_chaos_c2 from 8 HIP seed
+          pairs at that size (Criterion C).
 """
 import argparse
 import json
@@ -37,14 +50,25 @@ import _inputs as I  # noqa: E402
 
 H, W, FOCAL, NEAR, FAR, B = 64, 80, 180.0, 2.0, 6.0, 512
 LRATE, LRATE_DECAY = 5e-4, 250
+RADIUS = 4.0
+
+
+def set_size(name):
+    """`small`: the reduced scene above; `c2`: BASELINE configs[1] shapes (512x640, focal 1446, ring radius 3,
+    near 2.125 / far 4.67, 4096-ray batches)."""
+    global H, W, FOCAL, NEAR, FAR, B, RADIUS
+    if name == "c2":
+        H, W, FOCAL, NEAR, FAR, B, RADIUS = 512, 640, 1446.0, 2.125, 4.67, 4096, 3.0
+    elif name != "small":
+        raise SystemExit("--size must be small or c2")
 
 
 def scene(seed):
     """Ray bank [3*H*W, 11] + colours (shuffled with `seed`), held-out rays + colours, the two initial state dicts."""
     from oracle import nerf_oracle as O
     K = I.intrinsics(H, W, FOCAL)
-    train_poses = [I.camera_pose(th, -20.0, 4.0) for th in (0.0, 25.0, -25.0)]
-    test_pose = I.camera_pose(12.0, -15.0, 4.0)
+    train_poses = [I.camera_pose(th, -20.0, RADIUS) for th in (0.0, 25.0, -25.0)]
+    test_pose = I.camera_pose(12.0, -15.0, RADIUS)
     rays, cols = [], []
     for p in train_poses:
         ro, rd = O.get_rays(H, W, K, torch.from_numpy(p))
@@ -84,7 +108,8 @@ def batch_bounds(i, n):
 
 # ------------------------------------------------------------------------------------------------ CPU side
 def oracle_job(job):
-    seed, nudged, milestones, threads, cores, partdir = job
+    seed, nudged, milestones, threads, cores, partdir, size = job
+    set_size(size)
     if cores:                               # each worker on its own cores (no OpenMP pool sharing cores with another's)
         os.sched_setaffinity(0, cores)
     torch.set_num_threads(threads)
@@ -117,7 +142,8 @@ def oracle_job(job):
             print(f"[oracle {tag}] step {i} loss {losses[-1]:.6f} ({time.perf_counter() - t0:.0f} s)", flush=True)
         if i + 1 in milestones:             # a milestone's result survives an interrupted run
             with torch.no_grad():
-                img = O.render_rays(test_rays, osd[0], osd[1], net, O.RenderCfg(64, 128, 0.0))["rgb_map"]
+                img = torch.cat([O.render_rays(test_rays[c:c + 8192], osd[0], osd[1], net, O.RenderCfg(64, 128, 0.0))["rgb_map"]
+                                 for c in range(0, test_rays.shape[0], 8192)])
             psnr = O.psnr_from_mse(O.mse(img, test_rgb)).item()
             np.savez_compressed(os.path.join(partdir, f"{tag}_m{i + 1}.npz"), loss=np.asarray(losses, np.float32), psnr=psnr,
                                 img=img.numpy().astype(np.float32), secs=time.perf_counter() - t0, steps=i + 1)
@@ -126,27 +152,31 @@ def oracle_job(job):
 
 
 def merge_parts(partdir, out):
-    """Largest milestone every (seed, run) pair reached -> one .npz (what the GPU side reads)."""
+    """Every (seed, run) pair found -> one .npz (what the GPU side reads): the results at the largest common milestone, plus
+    the held-out PSNR at EVERY common milestone (`milestones`, `s<seed>_<run>_psnr_at`)."""
     import glob
     import re
     have = {}
     for f in glob.glob(os.path.join(partdir, "s*_m*.npz")):
         mo = re.match(r"s(\d+)_(ref|ctl)_m(\d+)\.npz", os.path.basename(f))
         have.setdefault((int(mo.group(1)), mo.group(2)), set()).add(int(mo.group(3)))
-    seeds = sorted({s for s, _ in have if (s, "ref") in have and (s, "ctl") in have})
+    seeds = sorted({s for s, t in have if t == "ref"})
     if not seeds:
-        raise SystemExit("no seed has both runs")
-    common = set.intersection(*[have[(s, t)] for s in seeds for t in ("ref", "ctl")])
+        raise SystemExit("no reference run found")
+    runs = [(s, t) for s in seeds for t in ("ref", "ctl") if (s, t) in have]
+    common = sorted(set.intersection(*[have[r] for r in runs]))
     if not common:
         raise SystemExit(f"no common milestone: {have}")
-    steps = max(common)
-    res = {"seeds": np.asarray(seeds), "steps": np.asarray(steps)}
-    for s in seeds:
-        for t in ("ref", "ctl"):
-            d = np.load(os.path.join(partdir, f"s{s}_{t}_m{steps}.npz"))
-            for k in ("loss", "psnr", "img", "secs"):
-                res[f"s{s}_{t}_{k}"] = d[k]
-            print(f"s{s}_{t}: {steps} steps, held-out {float(d['psnr']):.3f} dB, final loss {d['loss'][-1]:.6f}, {float(d['secs']):.0f} s")
+    steps = common[-1]
+    res = {"seeds": np.asarray(seeds), "steps": np.asarray(steps), "milestones": np.asarray(common),
+           "has_control": np.asarray([int((s, "ctl") in have) for s in seeds])}
+    for s, t in runs:
+        d = np.load(os.path.join(partdir, f"s{s}_{t}_m{steps}.npz"))
+        for k in ("loss", "psnr", "img", "secs"):
+            res[f"s{s}_{t}_{k}"] = d[k]
+        res[f"s{s}_{t}_psnr_at"] = np.asarray([float(np.load(os.path.join(partdir, f"s{s}_{t}_m{m}.npz"))["psnr"]) for m in common])
+        print(f"s{s}_{t}: {steps} steps, held-out {float(d['psnr']):.3f} dB, final loss {d['loss'][-1]:.6f}, {float(d['secs']):.0f} s; "
+              f"PSNR at {common}: {np.round(res[f's{s}_{t}_psnr_at'], 3).tolist()}")
     np.savez_compressed(out, **res)
     print("wrote", out, "seeds", seeds, "steps", steps)
 
@@ -158,9 +188,9 @@ def run_oracle(a):
     milestones = sorted(set(m for m in a.milestones if m <= a.steps) | {a.steps})
     avail = sorted(os.sched_getaffinity(0))
     jobs = []
-    for k, (s, n) in enumerate((s, n) for s in a.seeds for n in (False, True)):
+    for k, (s, n) in enumerate((s, n) for s in a.seeds for n in ((False,) if a.no_control else (False, True))):
         cores = set(avail[(a.core_offset + k * a.cores_per_worker) % len(avail):][:a.cores_per_worker]) if a.cores_per_worker else None
-        jobs.append((s, n, milestones, a.threads, cores, partdir))
+        jobs.append((s, n, milestones, a.threads, cores, partdir, a.size))
     print(f"{len(jobs)} jobs, {a.workers} workers x {a.threads} threads, {a.cores_per_worker} cores each of {len(avail)} usable; "
           f"milestones {milestones}", flush=True)
     with mp.get_context("spawn").Pool(a.workers) as pool:
@@ -170,7 +200,7 @@ def run_oracle(a):
 
 
 # ------------------------------------------------------------------------------------------------ GPU side
-def hip_run(seed, steps, nudged=False):
+def hip_run(seed, steps, nudged=False, milestones=(), reduced_too=True):
     from consistentnerf_amd import run_nerf as R
     dev = torch.device("cuda:0")
     K, bank, target, test_rays, test_rgb, sds = scene(seed)
@@ -187,7 +217,8 @@ def hip_run(seed, steps, nudged=False):
     kw.update(near=NEAR, far=FAR)
     kw_test.update(near=NEAR, far=FAR)
     bank_d, target_d = bank.to(dev), target.to(dev)
-    losses = []
+    test_d = torch.stack([test_rays[:, 0:3], test_rays[:, 3:6]]).to(dev)
+    losses, at = [], {}
     for i in range(steps):
         lo, hi = batch_bounds(i, bank.shape[0])
         rb, tg = bank_d[lo:hi], target_d[lo:hi]
@@ -200,11 +231,18 @@ def hip_run(seed, steps, nudged=False):
         for g_ in opt.param_groups:                # R:784-788
             g_["lr"] = LRATE * (0.1 ** (i / (LRATE_DECAY * 1000)))
         losses.append(loss.detach())
+        if i + 1 in milestones:
+            with torch.no_grad():
+                im, *_ = R.render(H, W, K, chunk=32768, rays=test_d, **kw_test)
+            at[i + 1] = (-10. * torch.log10(torch.mean((im.cpu() - test_rgb) ** 2))).item()
+    hip_run.psnr_at = at
     with torch.no_grad():
-        img, *_ = R.render(H, W, K, chunk=32768, rays=torch.stack([test_rays[:, 0:3], test_rays[:, 3:6]]).to(dev),
-                           **kw_test)
+        img, *_ = R.render(H, W, K, chunk=32768, rays=test_d, **kw_test)
     img = img.cpu()
     mse = torch.mean((img - test_rgb) ** 2)
+    if not reduced_too:
+        hip_run.reduced = {}
+        return torch.stack(losses).cpu().numpy(), (-10. * torch.log10(mse)).item(), img.numpy()
     # the SAME trained model rendered through the opt-in reduced-precision inference forward (csrc/mlp_fwd_bf.hip): held-out
     # PSNR against the ground truth and image PSNR against the fp32 render — the gate for that mode
     reduced = {}
@@ -288,6 +326,82 @@ def run_hip(a):
     print(json.dumps({k: v for k, v in summary.items() if k != "runs"}))
 
 
+def run_chaos(a):
+    """HIP vs HIP started one ulp away, many seeds: sigma_chaos(steps) at every milestone (seconds per run on the MI355X)."""
+    set_size(a.size)
+    ms = sorted(set(m for m in a.milestones if m <= a.steps) | {a.steps})
+    rows = []
+    for s in a.seeds:
+        t0 = time.perf_counter()
+        _, p0, im0 = hip_run(s, a.steps, False, ms, reduced_too=False)
+        at0 = dict(hip_run.psnr_at)
+        _, p1, im1 = hip_run(s, a.steps, True, ms, reduced_too=False)
+        at1 = dict(hip_run.psnr_at)
+        rows.append({"seed": s, "psnr_hip": [at0[m] for m in ms], "psnr_hip_1ulp": [at1[m] for m in ms],
+                     "image_psnr_pair_dB": psnr_img(im0, im1), "seconds": time.perf_counter() - t0})
+        print(json.dumps(rows[-1]), flush=True)
+    d = np.array([[b - c for b, c in zip(r["psnr_hip_1ulp"], r["psnr_hip"])] for r in rows])
+    out = {"what": "HIP path vs the HIP path started 1 ulp away (every initial weight moved to its fp32 neighbour): the chaos "
+                   "spread of held-out PSNR, per milestone", "size": a.size, "rays_per_step": B, "image": [H, W], "seeds": list(a.seeds),
+           "milestones": ms, "sigma_chaos_dB": np.sqrt(np.mean(d ** 2, 0)).tolist(), "mean_diff_dB": d.mean(0).tolist(),
+           "max_abs_diff_dB": np.abs(d).max(0).tolist(),
+           "mean_heldout_psnr_dB": np.mean([r["psnr_hip"] for r in rows], 0).tolist(), "runs": rows}
+    with open(a.out, "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps({k: v for k, v in out.items() if k != "runs"}))
+
+
+def run_curve(a):
+    """gap(steps): PSNR(HIP) - PSNR(oracle) at every milestone the oracle file holds, per seed, with the loss-curve agreement
+    up to that milestone (criteria A / B of the module docstring; sigma from --chaos)."""
+    set_size(a.size)
+    ref = np.load(a.oracle)
+    seeds, steps, ms = [int(s) for s in ref["seeds"]], int(ref["steps"]), [int(m) for m in ref["milestones"]]
+    chaos = json.load(open(a.chaos)) if a.chaos and os.path.exists(a.chaos) else None
+    rows = []
+    for s in seeds:
+        hl, hp, himg = hip_run(s, steps, False, ms, reduced_too=False)
+        at = dict(hip_run.psnr_at)
+        ol = ref[f"s{s}_ref_loss"]
+        rel = np.abs(hl - ol) / np.abs(ol)
+        row = {"seed": s, "psnr_hip": [at[m] for m in ms], "psnr_oracle": [float(x) for x in ref[f"s{s}_ref_psnr_at"]],
+               "max_rel_loss_diff_up_to": [float(rel[:m].max()) for m in ms]}
+        if f"s{s}_ctl_psnr_at" in ref.files:
+            row["psnr_oracle_1ulp"] = [float(x) for x in ref[f"s{s}_ctl_psnr_at"]]
+            cl = ref[f"s{s}_ctl_loss"]
+            row["control_max_rel_loss_diff_up_to"] = [float((np.abs(cl - ol) / np.abs(ol))[:m].max()) for m in ms]
+        rows.append(row)
+        print(json.dumps(row), flush=True)
+    gap = np.array([[h - o for h, o in zip(r["psnr_hip"], r["psnr_oracle"])] for r in rows])
+    track = np.array([r["max_rel_loss_diff_up_to"] for r in rows])
+    out = {"size": a.size, "rays_per_step": B, "image": [H, W], "seeds": seeds, "milestones": ms,
+           "gap_mean_dB": gap.mean(0).tolist(), "gap_std_dB": gap.std(0, ddof=1).tolist() if len(rows) > 1 else None,
+           "gap_max_abs_dB": np.abs(gap).max(0).tolist(), "max_rel_loss_diff_up_to_milestone_worst_seed": track.max(0).tolist(),
+           "runs": rows}
+    ctl_rows = [r for r in rows if "psnr_oracle_1ulp" in r]
+    if ctl_rows:
+        cg = np.array([[c - o for c, o in zip(r["psnr_oracle_1ulp"], r["psnr_oracle"])] for r in ctl_rows])
+        out["oracle_control_rms_dB"] = np.sqrt(np.mean(cg ** 2, 0)).tolist()
+        out["oracle_control_max_abs_dB"] = np.abs(cg).max(0).tolist()
+    tracking = [bool(t <= 1e-3) for t in track.max(0)]
+    out["criterion_A"] = {"text": "at every milestone where the HIP and oracle loss curves agree to 1e-3 relative on every seed up to that "
+                                  "step: |gap| <= 0.02 dB on every seed",
+                          "milestones_tracking": [m for m, t in zip(ms, tracking) if t],
+                          "max_abs_gap_there_dB": [float(g) for g, t in zip(np.abs(gap).max(0), tracking) if t],
+                          "pass": bool(all(g <= 0.02 for g, t in zip(np.abs(gap).max(0), tracking) if t))}
+    if chaos is not None:
+        sig = dict(zip(chaos["milestones"], chaos["sigma_chaos_dB"]))
+        n = len(rows)
+        lim = [2.0 * sig[m] / np.sqrt(n) if m in sig else None for m in ms]
+        out["criterion_B"] = {"text": "|mean gap| <= 2 sigma_chaos(steps) / sqrt(n_seeds) at every milestone (sigma_chaos from the "
+                                      f"{len(chaos['seeds'])}-seed HIP-vs-HIP+1ulp run)",
+                              "sigma_chaos_dB": [sig.get(m) for m in ms], "limit_dB": lim,
+                              "pass": bool(all(l_ is None or abs(g) <= l_ for g, l_ in zip(gap.mean(0), lim)))}
+    with open(a.out, "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps({k: v for k, v in out.items() if k != "runs"}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     sub = ap.add_subparsers(dest="side", required=True)
@@ -305,10 +419,29 @@ def main():
     h = sub.add_parser("hip")
     h.add_argument("--oracle", default=os.path.join(ROOT, "profiles", "r02_psnr_oracle.npz"))
     h.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_psnr_parity_seeds.json"))
+    o.add_argument("--size", default="small")
+    o.add_argument("--no-control", action="store_true", help="reference runs only (no 1-ulp twin)")
+    h.add_argument("--size", default="small")
+    c = sub.add_parser("chaos")
+    c.add_argument("--seeds", type=int, nargs="+", default=list(range(32)))
+    c.add_argument("--steps", type=int, default=600)
+    c.add_argument("--milestones", type=int, nargs="*", default=[25, 50, 100, 150, 300])
+    c.add_argument("--size", default="small")
+    c.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "psnr_chaos.json"))
+    cv = sub.add_parser("curve")
+    cv.add_argument("--oracle", required=True)
+    cv.add_argument("--chaos", default=None)
+    cv.add_argument("--size", default="small")
+    cv.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "psnr_curve.json"))
     a = ap.parse_args()
     if a.side == "merge":
         merge_parts(a.out + ".parts", a.out)
+    elif a.side == "chaos":
+        run_chaos(a)
+    elif a.side == "curve":
+        run_curve(a)
     else:
+        set_size(a.size)
         (run_oracle if a.side == "oracle" else run_hip)(a)
 
 
