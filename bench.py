@@ -283,12 +283,24 @@ def hbm_kernels(dev, reps=20):
     rows = []
 
     def timeit(fn):
+        """`reps` launches recorded into ONE hipGraph and replayed: what the events bracket is GPU time of back-to-back kernels
+        (an eager loop of 10-us kernels measures the host's launch rate instead)"""
         fn()
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn()
+        torch.cuda.current_stream().wait_stream(side)
+        g_ = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_):
+            for _ in range(reps):
+                fn()
+        g_.replay()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(reps):
-            fn()
+        g_.replay()
         e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps
@@ -343,8 +355,10 @@ def hbm_kernels(dev, reps=20):
     ms = timeit(lambda: ops.pack_weights(spec, m.kernel_tensors(), packed))
     add("pack_weights (per network)", f"{nparam} parameters -> {packed.numel()} packed floats", 4 * (nparam + packed.numel()), ms,
         "parameters read once, forward + transposed panels written")
-    return {"peak_GBps": HBM_PEAK_GBPS, "reps": reps, "note": "each kernel alone, HIP events over back-to-back launches; these are "
-            "0.3 % of a C2 step (latency-bound at 4096 rays) — the table says how far from the HBM roof they sit at both sizes",
+    return {"peak_GBps": HBM_PEAK_GBPS, "reps": reps, "note": "each kernel alone: `reps` launches recorded in one hipGraph, HIP events around its "
+            "replay (back-to-back GPU time incl. the inter-kernel gap, no host launch cost); the C2-batch working sets (7-30 MB) sit in "
+            "the 256 MB Infinity Cache between launches, so those rows are cache-resident rates; these kernels are 0.3 % of a C2 step "
+            "(5 % of the 512-ray C4-shard step) — the table says how far from the HBM roof they sit at both sizes",
             "kernels": rows}
 
 
@@ -612,8 +626,10 @@ class Workload:
         return 1e3 * ts[len(ts) // 2]
 
 
-def shard_leg(wl, per_rank, steps, warmup, collective="split", i0=100000):
-    """The `per_rank`-ray step of a strong-scaling shard on this process group: eager and graphed, per-kernel table."""
+def shard_leg(wl, per_rank, steps, warmup, collective="split", i0=100000, also_capture=False):
+    """The `per_rank`-ray step of a strong-scaling shard on this process group: eager and graphed, per-kernel table.
+    also_capture (RCCL groups): a third timing with the all-reduce recorded INSIDE the graph, attempted last and reported as an
+    error string if the recording fails."""
     ms = {}
     el, loss, prof = wl.run(per_rank, steps, warmup, i0=i0)
     ms["eager"] = el / steps * 1e3
@@ -622,12 +638,20 @@ def shard_leg(wl, per_rank, steps, warmup, collective="split", i0=100000):
     g = wl.graphed(per_rank, collective)
     el_g, loss_g, _ = wl.run(per_rank, steps, warmup, i0=i0 + steps + warmup, graphed=g)
     ms["graph"] = el_g / steps * 1e3
+    ms_capture = None
+    if also_capture and wl.reducer_active():
+        try:
+            gc = wl.graphed(per_rank, "capture")
+            el_c, _, _ = wl.run(per_rank, steps, warmup, i0=i0 + 2 * (steps + warmup), graphed=gc)
+            ms_capture = round(el_c / steps * 1e3, 4)
+        except Exception as e:  # noqa: BLE001
+            ms_capture = f"{type(e).__name__}: {e}"
     n = per_rank * (NC + NC + NF) * wl.world
     mfma_ms = sum(r["avg_ms"] * r["launches"] for r in table) / steps
     ideal_ms = n / wl.world * 2 * (MAC_FWD + MAC_DGRAD + MAC_WGRAD) / (PEAK_FP32_MFMA_TFLOPS * 1e12) * 1e3
     return {"rays_per_gpu": per_rank, "global_batch": per_rank * wl.world, "steps": steps, "warmup": warmup,
             "ms_per_step_eager": round(ms["eager"], 4), "ms_per_step_graph": round(ms["graph"], 4),
-            "graph_collective": collective if wl.reducer_active() else None,
+            "graph_collective": collective if wl.reducer_active() else None, "ms_per_step_graph_capture": ms_capture,
             "ray_samples_per_s_eager": n / (ms["eager"] * 1e-3), "ray_samples_per_s_graph": n / (ms["graph"] * 1e-3),
             "host_enqueue_ms_per_eager_step": round(host, 3),
             "mfma_kernels_ms_per_step": round(mfma_ms, 4), "step_ms_at_mfma_peak": round(ideal_ms, 4),
@@ -718,8 +742,8 @@ def main():
         ex = wl.reducer.exposed_ms()
         be = dist.get_backend()
         dist_info = {"rccl_ranks": dist.get_world_size() if be == "nccl" else 0, "ranks": dist.get_world_size(), "backend": be,
-                     "messages_per_step": len(wl.reducer.slices),
-                     "message_bytes": [4 * (hi - lo) for lo, hi in wl.reducer.slices.values()],
+                     "messages_per_step": round(wl.reducer.messages / max(wl.reducer.steps, 1), 3),
+                     "slice_bytes": [4 * (hi - lo) for lo, hi in wl.reducer.slices.values()],
                      "bytes_per_step": wl.reducer.bytes_per_step, "one_over_world": "folded into the Adam kernel (grad_scale)",
                      "allreduce_exposed_ms": round(sum(ex) / max(len(ex), 1), 4), "allreduce_exposed_ms_max": round(max(ex), 4) if ex else None,
                      "measured": "HIP events on the launch stream: last slice issued -> launch stream released (this rank)"}
@@ -755,7 +779,8 @@ def main():
             sys.stdout.flush()
             os.write(json_fd, (json.dumps(out) + "\n").encode())
 
-    if not a.no_extra and world > 1 and per_rank == B_PER_GPU and B_PER_GPU % world == 0:
+    force_leg = os.environ.get("CNERF_BENCH_FORCE_LEG") == "1" and dist.is_initialized()     # (exercise the leg on a 1-rank group)
+    if not a.no_extra and (world > 1 or force_leg) and per_rank == B_PER_GPU and B_PER_GPU % world == 0:
         # the same process group on the strong-scaling shard of C4.  A watchdog prints the line without this leg and ends
         # the process if the leg has not finished (a collective that never completes cannot be interrupted from Python).
         import threading
@@ -769,14 +794,15 @@ def main():
                 os._exit(0)
         threading.Thread(target=watchdog, daemon=True).start()
         try:
-            leg = shard_leg(wl, B_PER_GPU // world, min(a.steps, 100), 10, collective=a.graph_collective)
+            leg = shard_leg(wl, B_PER_GPU // (8 if force_leg and world == 1 else world), 100, 10, collective="split",
+                            also_capture=dist.get_backend() == "nccl")
         except Exception as e:  # noqa: BLE001 — the main line must survive a failure of the side leg
             leg = {"error": f"{type(e).__name__}: {e}"}
         done.set()
         if rank == 0:
             out["extra"] = {"note": "same process group, after the timed region; not part of `value`", "c4_strong": leg}
     if rank == 0:
-        if world == 1 and not a.no_extra:
+        if world == 1 and not a.no_extra and not force_leg:
             extra = {"note": "same process, after the timed C2 region; not part of `value`"}
             if per_rank == B_PER_GPU:
                 extra["c4_shard"] = shard_leg(wl, B_PER_GPU // 8, 200, 20)

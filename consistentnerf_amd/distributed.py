@@ -115,16 +115,28 @@ class GradReducer:
         self._works, self._done, self._ev = [], set(), None
         self.bytes_per_step = 4 * sum(hi - lo for lo, hi in self.slices.values())
         self.exposed = []
+        self.messages = self.steps = 0      # all-reduce calls issued / finish() calls: messages per step = their ratio
 
-    def _issue(self, m):
-        lo, hi = self.slices[id(m)]
-        self._done.add(id(m))
+    def _issue(self, *ms):
+        """all-reduce the slices of the networks `ms`; adjacent slices leave as ONE message (xGMI is point-to-point: fewer,
+        larger messages — and every message costs two cross-stream hand-overs on the launch stream)"""
+        spans = sorted(self.slices[id(m)] for m in ms)
+        merged = [list(spans[0])]
+        for lo, hi in spans[1:]:
+            if lo == merged[-1][1]:
+                merged[-1][1] = hi
+            else:
+                merged.append([lo, hi])
+        for m in ms:
+            self._done.add(id(m))
         if not dist.is_initialized():
             return
         if self.timing and len(self._done) == len(self.modules):
             self._ev = torch.cuda.Event(enable_timing=True)
             self._ev.record(torch.cuda.current_stream())
-        self._works.append(dist.all_reduce(self.opt.flat_grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+        for lo, hi in merged:
+            self._works.append(dist.all_reduce(self.opt.flat_grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+            self.messages += 1
 
     @property
     def grad_scale(self) -> float:
@@ -136,6 +148,12 @@ class GradReducer:
         if not self.hold and id(m) in self.slices and id(m) not in self._done:
             self._issue(m)
 
+    def networks_ready(self, ms):
+        """several networks became final together (the merged coarse+fine backward): one message for adjacent slices"""
+        ms = [m for m in ms if id(m) in self.slices and id(m) not in self._done]
+        if ms and not self.hold:
+            self._issue(*ms)
+
     def reset(self):
         """forget the bookkeeping of a backward pass whose exchange is not going to be finished (a recorded, not executed one)"""
         for m in self.modules:
@@ -143,10 +161,12 @@ class GradReducer:
         self._works, self._done, self._ev = [], set(), None
 
     def finish(self):
+        rest = [m for m in self.modules if id(m) not in self._done]
+        if rest:
+            self._issue(*rest)
         for m in self.modules:
-            if id(m) not in self._done:
-                self._issue(m)
             m._cnerf_pending = 0
+        self.steps += 1
         for w in self._works:
             w.wait()                 # the launch stream waits for RCCL's stream; the host does not block
         if self.timing and self._ev is not None:

@@ -178,6 +178,22 @@ def _report_ready(model, direct):
             model._cnerf_reducer.network_ready(model)
 
 
+def _report_ready_pair(model_a, model_b):
+    """The merged backward finished BOTH networks at once: report them together, so that a reducer that owns both sends their
+    (adjacent) slices of the flat gradient as ONE message instead of two back-to-back ones."""
+    ready = []
+    for m in (model_a, model_b):
+        if hasattr(m, "_cnerf_pending"):
+            m._cnerf_pending -= 1
+            if m._cnerf_pending <= 0:
+                ready.append(m)
+    if len(ready) == 2 and ready[0]._cnerf_reducer is ready[1]._cnerf_reducer:
+        ready[0]._cnerf_reducer.networks_ready(ready)
+    else:
+        for m in ready:
+            m._cnerf_reducer.network_ready(m)
+
+
 class _MlpFn(torch.autograd.Function):
     """Fused gamma(x), gamma(d) + MLP (replaces R:37-52 + H:44-45 + H:107-130 and their autograd)."""
 
@@ -232,8 +248,7 @@ class _MlpFn(torch.autograd.Function):
             fs, fp, fg, fB, fS, fst, fgr, fmodel = parked
             ops.mlp_backward_pair(fs, fp, fg, fB, fS, fst, fgr, ctx.spec, ctx.packed, g_raw.contiguous(), ctx.B, ctx.S,
                                   ctx.stash, [p.grad for p in params], accumulate=True)
-            _report_ready(fmodel, True)
-            _report_ready(ctx.model, True)
+            _report_ready_pair(fmodel, ctx.model)
             ctx.stash = ctx.packed = ctx.params = ctx.model = None
             return nret
         if parked is not None:        # (cannot happen — the fine node checked this node's route — but never drop a gradient)

@@ -145,6 +145,22 @@ for mean in (True, False):
     want = torch.arange(28, dtype=torch.float32) * sum(r + 1 for r in range(world)) * ((1.0 / world) if mean else 1.0)
     assert torch.allclose(opt.flat_grad, want), (opt.flat_grad, want)
     assert not red._works and not red._done and mods[1]._cnerf_pending == 0
+# the merged coarse+fine backward reports both networks at once: their adjacent slices leave as ONE message
+red = D.GradReducer(opt, mods, mean=False)
+opt.flat_grad.copy_(torch.arange(28, dtype=torch.float32) * (rank + 1))
+mods[0]._cnerf_pending = mods[1]._cnerf_pending = 1
+RN._report_ready_pair(mods[1], mods[0])
+assert red.messages == 1 and red._done == {id(mods[0]), id(mods[1])}
+red.finish()
+assert red.messages == 1 and red.steps == 1
+assert torch.allclose(opt.flat_grad, torch.arange(28, dtype=torch.float32) * sum(r + 1 for r in range(world)))
+# a network evaluated twice (two pending nodes) next to one evaluated once: the pair report only releases what is final
+opt.flat_grad.zero_()
+mods[0]._cnerf_pending, mods[1]._cnerf_pending = 2, 1
+RN._report_ready_pair(mods[1], mods[0])
+assert red._done == {id(mods[1])} and red.messages == 2
+red.finish()
+assert red.messages == 3
 D.barrier()
 if rank == 0: print("DIST_OK", world, err)
 dist.destroy_process_group()
