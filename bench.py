@@ -166,10 +166,19 @@ def cpu_baseline(seconds_budget=25.0):
             phys_val, phys_sample = pv2, f"{pn} steps of 256 rays, {pdt2:.2f} s/step"
     v1, _, dt1 = timed(64, 1, 0.0)
     torch.set_num_threads(ncores)
+    # forward only (the C5 shapes: perturb 0, no gradient): 2048 rays, one warm + one timed call (SURVEY 8d asks for both views)
+    cfg_inf = O.RenderCfg(NC, NF, 0.0)
+    with torch.no_grad():
+        O.render_rays(rays_all[:512], sd[0], sd[1], net, cfg_inf)
+        t0 = time.perf_counter()
+        for c in range(0, 2048, 1024):
+            O.render_rays(rays_all[:1024], sd[0], sd[1], net, cfg_inf)
+        inf_val = 2048 * (NC + NC + NF) / (time.perf_counter() - t0)
     best, cores = (val, ncores) if (phys_val is None or val >= phys_val) else (phys_val, phys)
     return {"value": best, "unit": "ray-samples/s", "cores": cores, "kind": "port",
             "threads_main": ncores, "value_main": val, "physical_cores": phys, "value_physical_cores": phys_val,
             "sample_physical_cores": phys_sample, "single_thread_value": v1, "logical_cpus_usable": avail,
+            "inference_value": inf_val, "inference_sample": f"forward only, 2 x 1024 rays, {ncores} threads (the C5 shapes)",
             "sample": f"{n} training steps of {Bc} rays (same C2 shapes: 64+192 samples, D=8/W=256, fwd+bwd+Adam), "
                       f"{dt:.2f} s/step on {ncores} threads, torch {torch.__version__} CPU fp32; host has {phys} physical cores "
                       f"({avail} usable logical cpus of {os.cpu_count()}); `value` = the better of the {ncores}-thread and the "

@@ -37,7 +37,7 @@ def main():
     m = m.to(dev)
     spec, packed = m.spec(), _packed(m)
     rays = torch.from_numpy(I.ray_batch(B, seed=5, near=2.125, far=4.67)).to(dev)
-    for S in (192, 64):
+    for S in [int(x) for x in os.environ.get("KBENCH_LEVELS", "192,64").split(",")]:
         M = B * S
         z = ops.coarse_z(rays, S, torch.rand(B, S, device=dev), False)
         t_inf = timeit(lambda: ops.mlp_forward(spec, packed, B, S, rays=rays, z=z))
