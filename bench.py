@@ -47,8 +47,12 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+# multi-process GPU work on this pool needs dmabuf IPC (the host driver has no legacy IPC): RCCL's communicator setup fails with
+# `hipIpcGetMemHandle: invalid argument` otherwise.  Set before the HIP runtime initialises; an explicit setting wins.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "tests", "golden")):
