@@ -207,30 +207,16 @@ def barrier():
 
 # ---- inference: a frame's rows sharded over ranks (precedent RegNeRF/internal/models.py:311-322) ----------
 def row_block(H: int, r: Optional[int] = None, w: Optional[int] = None):
-    """Rank r renders image rows [lo, hi); every rank renders `rows` = ceil(H/w) rows so that the gather is
-    rectangular: the `rows - (hi - lo)` extra ones repeat the block's last row (edge padding) and are dropped when
-    the frame is reassembled.  Returns (lo, hi, row_index[rows])."""
+    """RegNeRF-style block of a frame's rows for rank r (RegNeRF/internal/models.py:311-322 pads the RAYS): rows [lo, hi) plus
+    `ceil(H/w) - (hi - lo)` repeats of the block's last row (edge padding), as an index vector.  render_path_sharded pads the
+    rendered OUTPUT block instead (same frame, nothing rendered twice); this form is what the tests' hand-made splits through
+    render(rays=...) use.  Returns (lo, hi, row_index[rows])."""
     r = rank() if r is None else r
     w = world() if w is None else w
     lo, hi = shard_bounds(H, r, w)
     rows = -(-H // w)
     idx = torch.arange(lo, lo + rows).clamp_(max=max(hi - 1, lo)).clamp_(max=H - 1)
     return lo, hi, idx
-
-
-def gather_rows(block: torch.Tensor, H: int) -> torch.Tensor:
-    """All-gather of the per-rank row blocks [rows, W, ...] -> the frame [H, W, ...] on every rank (padding rows
-    dropped).  The only collective of the render path, one per output per frame."""
-    w = world()
-    if w == 1:
-        return block[:H]
-    parts = [torch.empty_like(block) for _ in range(w)]
-    dist.all_gather(parts, block.contiguous())
-    keep = []
-    for r, p in enumerate(parts):
-        lo, hi = shard_bounds(H, r, w)
-        keep.append(p[:hi - lo])
-    return torch.cat(keep, 0)
 
 
 def _pad_rows(t: torch.Tensor, n: int) -> torch.Tensor:
