@@ -8,8 +8,11 @@ export TMPDIR=/tmp
 i=0
 for SET in "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_LDS"; do
   i=$((i+1))
-  timeout 600 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d gpurun_out/pmc -o pass$i -- bash -c "python scripts/kbench_pair.py $B 2; KBENCH_LEVELS=192 python scripts/kbench.py $B 2" > gpurun_out/pmc/pass$i.log 2>&1
-  echo "pass$i rc=$? : $SET" >> gpurun_out/pmc/passes.txt
+  # (one rocprofv3 run per script: two children of one run write the same output file)
+  timeout 600 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d gpurun_out/pmc -o pass${i}a -- python scripts/kbench_pair.py $B 2 > gpurun_out/pmc/pass${i}a.log 2>&1
+  ra=$?
+  KBENCH_LEVELS=192 timeout 600 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d gpurun_out/pmc -o pass${i}b -- python scripts/kbench.py $B 2 > gpurun_out/pmc/pass${i}b.log 2>&1
+  echo "pass$i rc=$ra/$? : $SET" >> gpurun_out/pmc/passes.txt
 done
 rm -f gpurun_out/pmc/*.db
 ls gpurun_out/pmc

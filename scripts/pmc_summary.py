@@ -28,11 +28,13 @@ def main():
     src, dst = sys.argv[1], sys.argv[2]
     os.makedirs(dst, exist_ok=True)
     allv = {}
+    by_tag = collections.defaultdict(list)          # pass<i>a (kbench_pair.py) and pass<i>b (kbench.py) -> one summary per pass
     for path in sorted(glob.glob(os.path.join(src, "pass*_counter_collection.csv"))):
-        tag = re.match(r"(pass\d+)_", os.path.basename(path)).group(1)
+        by_tag[re.match(r"(pass\d+)[ab]?_", os.path.basename(path)).group(1)].append(path)
+    for tag, paths in sorted(by_tag.items()):
         acc = collections.defaultdict(lambda: [0.0, 0, 0.0])
         seen = set()
-        for r in csv.DictReader(open(path)):
+        for r in (row for path in paths for row in csv.DictReader(open(path))):
             k = short(r["Kernel_Name"])
             if k is None:
                 continue
