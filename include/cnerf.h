@@ -151,7 +151,10 @@ int cnerf_composite_bwd(const float* raw, int raw_ch, const float* z, const floa
 
 /* ---- a8: inverse-CDF sampling  (sample_pdf H:206-250) ------------------------------------------ */
 /* bins[B,Nb], weights[B,Nb-1], u[B,Nf] (u_row_stride 0 broadcasts one row) -> samples[B,Nf];
- * inds[B,Nf] int64 (searchsorted right=True result, the bit-exact parity target) optional. */
+ * inds[B,Nf] int64 (searchsorted right=True result, the bit-exact parity target) optional.
+ * The pdf normaliser sum(weights + 1e-5) (H:213) is associated exactly as ATen's CPU `sum` kernel does it (8-float vectors, four
+ * interleaved accumulators, tail, lanes in order) and the CDF scan is carried in fp64 like ATen's `cumsum`: the indices equal the
+ * reference's CPU run bit for bit, CDF ties (the u = 1.0 sample of the deterministic test-time stream) included. */
 int cnerf_sample_pdf(const float* bins, const float* weights, const float* u, int64_t u_row_stride,
                      int64_t B, int Nb, int Nf, float* samples, int64_t* inds, void* stream);
 /* a8+a9 fused for render_rays (R:395-399,415): z_mid, sample_pdf(z_mid, weights[:,1:-1]), sort of the
