@@ -87,8 +87,27 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 // the DMA target and drains vmcnt inside the first MFMA step of each slab — i.e. it waits for the prefetch of the
 // NEXT slab — which serialises the double buffering.  Completion is awaited explicitly (vmcnt(0)) before the
 // barrier that publishes the slab.
+// Cache policy of the DMA loads: `nt` (non-temporal).  The operands are streamed exactly once per GEMM (10+ GB per C2 step)
+// while the split partials the workgroups write (0.1-0.3 GB) are read back by the reduction right after the launch: with the
+// stream marked non-temporal the partials survive in the cache hierarchy — wgrad + reduction 1.216 -> 1.188 ms at the 512-ray C4
+// shard, 2.31 -> 2.29 ms at 1024 rays, level at 4096 (`sc1` / `sc0 sc1`: no effect; profiles/r03_wgrad_dma_policy.txt).
+// -DCN_DMA_POL=0 builds without it.
+#ifndef CN_DMA_POL
+#define CN_DMA_POL 1
+#endif
+#if CN_DMA_POL == 1
+#define CN_DMA_POLICY " nt"
+#elif CN_DMA_POL == 2
+#define CN_DMA_POLICY " sc1"
+#elif CN_DMA_POL == 3
+#define CN_DMA_POLICY " sc0 sc1"
+#elif CN_DMA_POL == 4
+#define CN_DMA_POLICY " sc1 nt"
+#else
+#define CN_DMA_POLICY ""
+#endif
 __device__ __forceinline__ void dma16(const i32x4& rs, unsigned lds_addr, int voff, int soff) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen" CN_DMA_POLICY " lds"
                :
                : "s"(__builtin_amdgcn_readfirstlane((int)lds_addr)), "v"(voff), "s"(rs),
                  "s"(__builtin_amdgcn_readfirstlane(soff))
