@@ -130,7 +130,8 @@ __device__ __forceinline__ void wgrad_body(WgNetC& a, WgJobC& jb, float* lds) {
   // (the by-value argument struct is indexed dynamically, so it lives in scratch: anything the slab loop needs is
   // pulled into SGPRs here — a scratch_load inside the loop would also drain vmcnt, i.e. wait for the DMA in flight)
   const int g_rows4 = __builtin_amdgcn_readfirstlane(a.g_rows * 4), s_rows4 = __builtin_amdgcn_readfirstlane(a.s_rows * 4);
-  const int64_t m_begin = (int64_t)split * jb.chunk;
+  const int64_t m_begin0 = (int64_t)split * jb.chunk;
+  const int64_t m_begin = m_begin0 < a.Mp ? m_begin0 : a.Mp;      // (a range past the end is empty: zero-sized resources, zero partial)
   const int64_t m_end = m_begin + jb.chunk < a.Mp ? m_begin + jb.chunk : a.Mp;
   const int nslab = __builtin_amdgcn_readfirstlane(m_end > m_begin ? (int)((m_end - m_begin) / TM) : 0);
   const int ntn = (jb.N + 31) >> 5, ntk = (jb.K + 31) >> 5;
@@ -554,6 +555,10 @@ void plan_ranges(WgArgs& a, int nj, const int* cap, int* ns_out) {
     if (v < vmin) v = (int)vmin;
     if (v > cap[net]) v = cap[net];
     if ((int64_t)v > slabs) v = (int)slabs;
+    if (v < 1) v = 1;
+    // no empty trailing ranges: with ranges of ceil(slabs / v) slabs, only ceil(slabs / that) of them hold points
+    const int64_t per = (slabs + v - 1) / v;
+    if (per > 0) v = (int)((slabs + per - 1) / per);
     ns_out[i] = v < 1 ? 1 : v;
   }
 }

@@ -1668,7 +1668,11 @@ def test_forced_dist_world1_step_is_bit_identical(dev, tmp_path):
 
 @pytest.mark.parametrize("cfg0,cfg1,M0,M1", [((8, 256, True, 5), (8, 256, True, 5), 3 * 192, 3 * 64),
                                              ((8, 256, True, 5), (4, 128, True, 5), 2 * 192 + 7, 1000),
-                                             ((4, 128, False, 5), (4, 128, False, 5), 33, 4097)])
+                                             ((4, 128, False, 5), (4, 128, False, 5), 33, 4097),
+                                             # point counts whose ceil-divided ranges leave the last of the nominal 19 / 63 empty
+                                             # (round 3: the plan drops it; the kernel treats a range past the end as empty)
+                                             ((8, 256, True, 5), (8, 256, True, 5), 51 * 192, 51 * 64),
+                                             ((8, 256, True, 5), (8, 256, True, 5), 513 * 192, 513 * 64)])
 def test_bwd_pair_equals_two_separate_backwards(dev, cfg0, cfg1, M0, M1):
     """cnerf_mlp_bwd_pair (one dgrad grid when the architectures match, one wgrad grid + one reduction always) against two
     cnerf_mlp_bwd calls: bit-identical gradients, overwrite and accumulate, ragged point counts, mixed architectures."""
