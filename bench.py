@@ -558,10 +558,18 @@ class Workload:
         self.reducer = D.GradReducer(self.opt, [self.kw['network_fn'], self.kw['network_fine']], mean=True,
                                      timing=dist.is_initialized(), fold_scale=True)
 
+    def set_sharding(self, per_rank, strong):
+        """strong (the global batch cut N ways): every rank draws the jitter / resampling streams of the WHOLE batch from the same
+        generator state and takes its rows (`_global_rows`), so that the N-rank step sees the random numbers of the 1-rank step
+        on that batch; weak: independent per-rank streams (RegNeRF/train.py:364-365)."""
+        self.global_rows = (self.rank * per_rank, per_rank * self.world) if (strong and self.world > 1) else None
+        torch.manual_seed(99 if self.global_rows is not None else 99 + self.rank)
+
     def fwd_bwd(self, rays, tgt):
         R = self.R
         rays_od = torch.stack([rays[:, 0:3], rays[:, 3:6]], 0)
-        rgb, disp, acc, extras = R.render(H_IMG, W_IMG, self.K, chunk=32768, rays=rays_od, retraw=True, **self.kw)
+        extra_kw = {} if getattr(self, "global_rows", None) is None else {"_global_rows": self.global_rows}
+        rgb, disp, acc, extras = R.render(H_IMG, W_IMG, self.K, chunk=32768, rays=rays_od, retraw=True, **self.kw, **extra_kw)
         self.opt.zero_grad()
         loss = R.img2mse(rgb, tgt) + R.img2mse(extras['rgb0'], tgt)
         loss.backward()
@@ -644,6 +652,7 @@ def shard_leg(wl, per_rank, steps, warmup, collective="split", i0=100000, also_c
     also_capture (RCCL groups): a third timing with the all-reduce recorded INSIDE the graph, attempted last and reported as an
     error string if the recording fails."""
     ms = {}
+    wl.set_sharding(per_rank, strong=True)
     el, loss, prof = wl.run(per_rank, steps, warmup, i0=i0)
     ms["eager"] = el / steps * 1e3
     table = per_kernel_table(prof, el * 1e3)
@@ -726,6 +735,7 @@ def main():
     else:
         per_rank = B_PER_GPU
     wl = Workload(dev, rank, world)
+    wl.set_sharding(per_rank, strong=(per_rank * world == B_PER_GPU and world > 1))
     graphed = wl.graphed(per_rank, a.graph_collective) if a.graph else None
     elapsed, loss, prof = wl.run(per_rank, a.steps, a.warmup, graphed=graphed)
     if graphed is not None:      # a replayed graph carries no events: the per-kernel table from an eager pass of the same steps

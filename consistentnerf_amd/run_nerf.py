@@ -342,18 +342,32 @@ def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0, white_bkgd=False, pytest=F
     return _CompositeFn.apply(raw.contiguous(), z_vals.contiguous(), rays, noise, bool(white_bkgd))
 
 
-def _density_noise(shape, raw_noise_std, pytest, device):
+def _rows_of_global(draw, rows, cols, global_rows):
+    """`draw(n, cols)` for this call's `rows` rays — or, when the rays are rows [offset, offset + rows) of a GLOBAL batch of
+    `total` rays sharded over ranks (`global_rows = (offset, total)`), the matching rows of the draw for the whole batch: every
+    rank consumes the identical generator state for the identical global stream, so an N-rank step sees exactly the random
+    numbers the 1-rank step on the whole batch sees ("t_rand / u generated from the global batch and sliced")."""
+    if global_rows is None:
+        return draw(rows, cols)
+    off, total = global_rows
+    return draw(int(total), cols)[int(off):int(off) + rows].contiguous()
+
+
+def _density_noise(shape, raw_noise_std, pytest, device, global_rows=None):
     if not raw_noise_std > 0.:
         return None
     if pytest:   # R:290-294: uniform in pytest mode
         return pytest_uniform(tuple(shape), device) * raw_noise_std
-    return torch.randn(tuple(shape), device=device) * raw_noise_std
+    return _rows_of_global(lambda n, c: torch.randn(n, c, device=device), shape[0], shape[1], global_rows) * raw_noise_std
 
 
 def batchify_rays(rays_flat, chunk=1024 * 32, **kwargs):
     """R:55-67."""
     all_ret = {}
+    gr = kwargs.pop("_global_rows", None)
     for i in range(0, rays_flat.shape[0], chunk):
+        if gr is not None:     # this chunk's rows of the global batch
+            kwargs["_global_rows"] = (gr[0] + i, gr[1])
         ret = render_rays(rays_flat[i:i + chunk], **kwargs)
         for k in ret:
             all_ret.setdefault(k, []).append(ret[k])
@@ -614,8 +628,10 @@ def _create_nerf(args, model_cls, view_variant):
 
 def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False, lindisp=False, perturb=0.,
                 N_importance=0, network_fine=None, white_bkgd=False, raw_noise_std=0., verbose=False, pytest=False,
-                _with_depth=False, _debug=False):
-    """R:311-421 (V:441-551 when _with_depth).  Returns the same dict (+ the sample depths when _debug)."""
+                _with_depth=False, _debug=False, _global_rows=None):
+    """R:311-421 (V:441-551 when _with_depth).  Returns the same dict (+ the sample depths when _debug).
+    `_global_rows = (offset, total)`: `ray_batch` is rows [offset, offset + N_rays) of a global batch of `total` rays sharded over
+    ranks — the jitter / resampling / noise streams are drawn for the whole batch and sliced (_rows_of_global)."""
     rays = ray_batch if ray_batch.is_contiguous() else ray_batch.contiguous()
     N_rays, dev = rays.shape[0], rays.device
     if N_rays == 0:   # nothing to launch (the reference's batchify_rays raises on an empty batch; here: empty maps)
@@ -635,21 +651,25 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
     viewdirs = rays[:, -3:] if rays.shape[-1] > 8 else None
     t_rand = None
     if perturb > 0.:
-        t_rand = pytest_uniform((N_rays, N_samples), dev) if pytest else torch.rand(N_rays, N_samples, device=dev)
+        t_rand = (pytest_uniform((N_rays, N_samples), dev) if pytest else
+                  _rows_of_global(lambda n, c: torch.rand(n, c, device=dev), N_rays, N_samples, _global_rows))
     z_vals = ops.coarse_z(rays, N_samples, t_rand, lindisp)
     raw = network_query_fn(RayPoints(rays, z_vals), viewdirs, network_fn)
-    noise = _density_noise((N_rays, N_samples), raw_noise_std, pytest, dev)
+    noise = _density_noise((N_rays, N_samples), raw_noise_std, pytest, dev, _global_rows)
     rgb_map, disp_map, acc_map, weights, depth_map = _CompositeFn.apply(raw, z_vals, rays, noise, bool(white_bkgd))
     z_coarse = z_vals
     if N_importance > 0:
         rgb_map_0, disp_map_0, acc_map_0, depth_map_0 = rgb_map, disp_map, acc_map, depth_map
-        u = sample_u(N_rays, N_importance, perturb == 0., pytest, dev)
+        if _global_rows is not None and not pytest and perturb != 0.:
+            u = _rows_of_global(lambda n, c: torch.rand(n, c, device=dev), N_rays, N_importance, _global_rows)
+        else:
+            u = sample_u(N_rays, N_importance, perturb == 0., pytest, dev)
         z_vals, z_std = ops.resample(z_vals, weights, u)          # R:395-399 + R:415, no gradient (R:397)
         run_fn = network_fn if network_fine is None else network_fine
         raw_coarse = raw
         raw = network_query_fn(RayPoints(rays, z_vals), viewdirs, run_fn)
         _link_levels(raw_coarse, raw)
-        noise = _density_noise((N_rays, N_samples + N_importance), raw_noise_std, pytest, dev)
+        noise = _density_noise((N_rays, N_samples + N_importance), raw_noise_std, pytest, dev, _global_rows)
         rgb_map, disp_map, acc_map, weights, depth_map = _CompositeFn.apply(raw, z_vals, rays, noise,
                                                                             bool(white_bkgd))
     ret = {'rgb_map': rgb_map, 'disp_map': disp_map, 'acc_map': acc_map}

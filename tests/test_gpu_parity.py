@@ -2543,3 +2543,33 @@ def test_c4_eight_way_shard_equals_the_whole_batch_step(dev):
     frac = float((dp > 1e-7).float().mean())
     print(f"  stepped weights: max|d| {float(dp.max()):.3e}, fraction differing by > 1e-7: {frac:.4f}")
     assert float(dp.max()) <= 1e-4 and frac < 0.01
+
+
+def test_sharded_ranks_consume_the_global_random_streams(dev):
+    """render_rays(..., _global_rows=(offset, total)): a rank holding rows [offset, offset + n) of a global batch draws the
+    jitter (R:368-382), the resampling u (H:214-229) and the density noise (R:287-288) for the WHOLE batch and takes its rows, so
+    with the same generator state on every rank an N-rank step sees exactly the random numbers of the 1-rank step on the whole
+    batch — the shard's outputs equal the whole batch's rows bit for bit."""
+    from consistentnerf_amd import run_nerf_view as V
+    coarse, _ = make_model(4, 128, True, 5, 71, dev)
+    fine, _ = make_model(4, 128, True, 5, 72, dev)
+    rays = T(I.ray_batch(384, seed=9), dev)
+    kw = _kwargs(coarse, fine, 32, 48, 1.0, False, 1.0, False)       # perturb = 1, raw_noise_std = 1: all three streams live
+    with torch.no_grad():
+        torch.manual_seed(123)
+        whole = V.render_rays(rays, _debug=True, **kw)
+        for w in (2, 3):
+            for r in range(w):
+                lo, hi = r * 384 // w, (r + 1) * 384 // w
+                torch.manual_seed(123)                              # (every rank holds the same generator state)
+                part = V.render_rays(rays[lo:hi], _debug=True, _global_rows=(lo, 384), **kw)
+                for k in ("rgb_map", "depth_map", "rgb0", "_z_coarse", "_z_vals", "z_std"):
+                    assert torch.equal(part[k], whole[k][lo:hi]), (w, r, k)
+        # through render() (one chunk per step, the training case: N_rand <= chunk)
+        K = I.intrinsics(100, 100, 138.0)
+        kwr = dict({k: v for k, v in kw.items() if k != "lindisp"}, lindisp=False, near=2.0, far=6.0, use_viewdirs=True, ndc=False)
+        torch.manual_seed(123)
+        ref = V.render(100, 100, K, chunk=32768, rays=torch.stack([rays[:, 0:3], rays[:, 3:6]], 0), **kwr)
+        torch.manual_seed(123)
+        out1 = V.render(100, 100, K, chunk=32768, rays=torch.stack([rays[128:384, 0:3], rays[128:384, 3:6]], 0), _global_rows=(128, 384), **kwr)
+        assert torch.equal(out1[0], ref[0][128:384]) and torch.equal(out1[3], ref[3][128:384])
