@@ -412,3 +412,21 @@ def test_wgrad_range_plan_invariants():
         # one network alone gets the same count as in the merged launch
         assert {j[4] for j in wgrad_plan.plan(B, S=(192,))} == {n_f} and {j[4] for j in wgrad_plan.plan(B, S=(64,))} == {n_c}
     assert len(wgrad_plan.plan(4096, S=(192,))) == 14
+
+
+def test_rows_of_global_draws_the_whole_batch_and_slices():
+    """run_nerf._rows_of_global (strong sharding): with `global_rows = (offset, total)` the random block is drawn for
+    the WHOLE batch and sliced, so ranks holding the same generator state reproduce the single-rank stream row for row; without
+    it the draw is just the shard's own."""
+    import torch
+    from consistentnerf_amd.run_nerf import _rows_of_global
+    draw = lambda n, c: torch.rand(n, c)  # noqa: E731
+    torch.manual_seed(5)
+    whole = draw(12, 3)
+    parts = []
+    for lo, hi in ((0, 5), (5, 9), (9, 12)):
+        torch.manual_seed(5)
+        parts.append(_rows_of_global(draw, hi - lo, 3, (lo, 12)))
+    assert torch.equal(torch.cat(parts), whole) and all(p.is_contiguous() for p in parts)
+    torch.manual_seed(5)
+    assert torch.equal(_rows_of_global(draw, 12, 3, None), whole)
