@@ -21,7 +21,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 192
 TRAIN = (sys.argv[3] != "0") if len(sys.argv) > 3 else True
 WHICH = sys.argv[4] if len(sys.argv) > 4 else "fwd"
-PH = ["prologue", "barrier", "gemm", "park", "heads", "total"]   # wgrad: prologue/epilogue, barrier, mfma loop, vmcnt wait, dma issue
+PH = ["prologue", "barrier", "gemm", "park", "heads", "total"]
 NS = 40
 
 
@@ -60,16 +60,7 @@ def main():
         fn = lambda: ops.mlp_forward(spec, packed, B, S, rays=rays, z=z, want_stash=TRAIN)  # noqa: E731
         getter, wpb = lib.cnerf_debug_timing, 1
     elif WHICH == "wgrad":
-        raw, stash = ops.mlp_forward(spec, packed, B, S, rays=rays, z=z, want_stash=True)
-        d_raw = torch.randn_like(raw)
-        net = spec.c()
-        ws = torch.empty(lib.cnerf_mlp_bwd_ws_floats(C.byref(net), M), device=dev)
-        st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)  # noqa: E731
-        lib.cnerf_mlp_dgrad(C.byref(net), ops._p(packed), ops._p(d_raw), B, S, ops._p(stash), ops._p(ws), st())
-        grads = [torch.empty(s_, device=dev) for s_ in spec.tensor_shapes()]
-        ptrs = ops._ptrs(grads)
-        fn = lambda: lib.cnerf_mlp_wgrad(C.byref(net), B, S, ops._p(stash), ops._p(ws), C.byref(ptrs), 0, st())  # noqa: E731
-        getter, wpb = lib.cnerf_debug_timing_wgrad, 4
+        raise SystemExit("the weight-gradient launch has its own per-workgroup trace: scripts/wgrad_trace.py (1-D grid, ranges per GEMM)")
     else:
         raw, stash = ops.mlp_forward(spec, packed, B, S, rays=rays, z=z, want_stash=True)
         d_raw = torch.randn_like(raw)
@@ -87,23 +78,13 @@ def main():
     e0.record(); fn(); e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1)
-    nw = min(65536, wpb * ((M + 31) // 32)) if WHICH != "wgrad" else min(65536, 4 * 192 * 15)
+    nw = min(65536, wpb * ((M + 31) // 32))
     buf = np.zeros(nw * NS, dtype=np.uint64)
     assert getter(buf.ctypes.data, buf.size) == 0
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     np.save(os.path.join(ROOT, "gpurun_out", f"ktiming_{WHICH}_{int(TRAIN)}.npy"), buf.reshape(nw, NS))
     t = buf.reshape(nw, NS).astype(np.float64)
     print(f"{WHICH} B={B} S={S} train={TRAIN}: kernel {ms:.3f} ms, {nw} waves sampled")
-    if WHICH == "wgrad":   # slots are (job, split, wave): report the 256x256 jobs (first 9) and the rest separately
-        nsp = 128
-        for name, lo, hi in (("256x256 jobs", 0, 8), ("hv 128x256", 8, 9), ("enc 256x64", 9, 10), ("skipenc 256x64", 10, 11),
-                             ("denc 128x32", 11, 12), ("alpha 4x256", 12, 13), ("rgb 3x128", 13, 14)):
-            r = t[lo * nsp * 4: hi * nsp * 4]
-            r = r[r[:, 5] > 0]
-            tot = r[:, 5].mean()
-            print(f"  {name:13s} ({len(r)} waves): lifetime {tot:9.0f} cyc | " +
-                  " | ".join(f"{PH[i]} {r[:, i].mean():8.0f} ({100 * r[:, i].mean() / tot:4.1f}%)" for i in range(5)))
-        return
     for w in range(wpb):
         r = t[w::wpb]
         tot = r[:, 5].mean()
