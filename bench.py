@@ -19,8 +19,9 @@ resident in HBM before the timed region.
   --graph          replay the step as captured hipGraphs (consistentnerf_amd/graph.py): one graph at N=1; at N>1 two graphs
                    around the eager gradient exchange (--graph-collective split, default) or the RCCL all-reduce recorded
                    inside one graph (--graph-collective capture).
-  --pmc            re-runs this command twice under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes,
-                   kernel-trace only) and fills roofline.traffic from THOSE runs instead of the committed lookup.
+  --pmc [auto|on|off]  re-runs this command twice under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, kernel-trace
+                   only, 3 steps each) and fills roofline.traffic from THOSE runs instead of the committed lookup.  Default auto: on at
+                   N=1 when the extra legs run and rocprofv3 is on PATH (adds ~40 s); any failure falls back to the lookup.
 
 Extra objects on the JSON line:
   roofline     — dominant kernel of the step, algorithmic FLOPs per launch / its average duration measured
@@ -396,7 +397,7 @@ def pmc_rerun(per_rank, dom_kernel):
                sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "2", "--no-extra", "--no-cpu-baseline",
                "--rays-per-gpu", str(per_rank)]
         try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd="/tmp")
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=180, env=env, cwd="/tmp")
         except subprocess.TimeoutExpired:
             return {"traffic": None, "source": f"rocprofv3 --pmc {ctr} timed out"}
         files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
@@ -696,7 +697,9 @@ def main():
                     help="replay the step as captured hipGraph(s) (consistentnerf_amd/graph.py); the per-kernel table then comes "
                          "from a separate eager pass of the same steps, and the JSON says so")
     ap.add_argument("--graph-collective", choices=("split", "capture"), default="split")
-    ap.add_argument("--pmc", action="store_true", help="fill roofline.traffic from rocprofv3 --pmc passes of THIS command")
+    ap.add_argument("--pmc", nargs="?", const="on", default="auto", choices=("auto", "on", "off"),
+                    help="fill roofline.traffic from two rocprofv3 --pmc passes of THIS command (auto: at N=1 when the extra legs run and "
+                         "rocprofv3 is on PATH; the committed lookup is the fallback)")
     a = ap.parse_args()
 
     # stdout carries exactly ONE line, the JSON: everything else that writes to fd 1 — the reference-style prints of
@@ -749,7 +752,9 @@ def main():
         "static lookup: committed rocprofv3 PMC passes of this kernel at this launch size (profiles/*_pmc*/pass2+pass3 "
         "summaries, 2*FETCH_SIZE + WRITE_SIZE); NOT sampled in this run")
     pmc_live = None
-    if a.pmc and rank == 0 and world == 1:
+    import shutil
+    want_pmc = a.pmc == "on" or (a.pmc == "auto" and not a.no_extra and shutil.which("rocprofv3") is not None)
+    if want_pmc and rank == 0 and world == 1:
         pmc_live = pmc_rerun(per_rank, dom["kernel"])
         if pmc_live and pmc_live.get("traffic") is not None:
             traffic, traffic_source = pmc_live["traffic"], pmc_live["source"]
