@@ -847,7 +847,15 @@ def main():
         emit()
     os.close(json_fd)
     if dist.is_initialized():
+        if world > 1:
+            # the line is out: a communicator that a failed experiment of the side leg left in a bad state must not keep the
+            # process (and the launcher waiting for it) alive
+            import threading
+            threading.Timer(30.0, lambda: os._exit(0)).start()
         dist.destroy_process_group()
+        if world > 1:
+            sys.stderr.flush()
+            os._exit(0)
 
 
 if __name__ == "__main__":
