@@ -393,30 +393,33 @@ def pmc_rerun(per_rank, dom_kernel):
     env = dict(os.environ, TMPDIR="/tmp")
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="cnerf_pmc_")
-        cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
-               sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "2", "--no-extra", "--no-cpu-baseline",
-               "--rays-per-gpu", str(per_rank)]
         try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=180, env=env, cwd="/tmp")
-        except subprocess.TimeoutExpired:
-            return {"traffic": None, "source": f"rocprofv3 --pmc {ctr} timed out"}
-        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
-        if r.returncode != 0 or not files:
-            return {"traffic": None, "source": f"rocprofv3 --pmc {ctr} rc={r.returncode}: {r.stderr[-300:]}"}
-        vals = {}
-        for f in files:
-            for row in csv.DictReader(open(f)):
-                if pat in row["Kernel_Name"] and "reduce" not in row["Kernel_Name"] and row["Counter_Name"] == ctr:
-                    vals.setdefault(row["Dispatch_Id"], 0.0)
-                    vals[row["Dispatch_Id"]] += float(row["Counter_Value"])
-        if not vals:
-            return {"traffic": None, "source": f"no {pat} dispatch in the {ctr} pass"}
-        v = sorted(vals.values())
-        big = [x for x in v if x >= 0.5 * v[-1]]          # the largest launch size of that kernel (fine / merged level)
-        res[ctr], launches[ctr] = sum(big) / len(big) * 1024.0, len(big)
-        shutil.rmtree(d, ignore_errors=True)
+            cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
+                   sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "2", "--no-extra", "--no-cpu-baseline",
+                   "--rays-per-gpu", str(per_rank)]
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=180, env=env, cwd="/tmp")
+            except subprocess.TimeoutExpired:
+                return {"traffic": None, "source": f"rocprofv3 --pmc {ctr} timed out"}
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return {"traffic": None, "source": f"rocprofv3 --pmc {ctr} rc={r.returncode}: {r.stderr[-300:]}"}
+            vals = {}
+            for f in files:
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if pat in row["Kernel_Name"] and "reduce" not in row["Kernel_Name"] and row["Counter_Name"] == ctr:
+                            vals.setdefault(row["Dispatch_Id"], 0.0)
+                            vals[row["Dispatch_Id"]] += float(row["Counter_Value"])
+            if not vals:
+                return {"traffic": None, "source": f"no {pat} dispatch in the {ctr} pass"}
+            v = sorted(vals.values())
+            big = [x for x in v if x >= 0.5 * v[-1]]          # the largest launch size of that kernel (fine / merged level)
+            res[ctr], launches[ctr] = sum(big) / len(big) * 1024.0, len(big)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
     return {"traffic": int(2 * res["FETCH_SIZE"] + res["WRITE_SIZE"]), "FETCH_SIZE_bytes_x2": int(2 * res["FETCH_SIZE"]),
-            "WRITE_SIZE_bytes": int(res["WRITE_SIZE"]), "launches_averaged": launches,
+            "FETCH_SIZE_bytes_raw": int(res["FETCH_SIZE"]), "WRITE_SIZE_bytes": int(res["WRITE_SIZE"]), "launches_averaged": launches,
             "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of THIS command (3 steps each), per launch of the "
                       "dominant kernel: 2*FETCH_SIZE + WRITE_SIZE"}
 
@@ -682,6 +685,63 @@ def shard_leg(wl, per_rank, steps, warmup, collective="split", i0=100000, also_c
             "final_loss": float(loss_g.item()), "kernels": table}
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        return s_.getsockname()[1]
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without torchrun's environment: re-run THIS command line under
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` (one rank per GPU), pass rank 0's one
+    JSON line through, return the launcher's exit status.  Fewer than N visible GPUs under RCCL, a launcher failure or a run that
+    produced no line -> ONE JSON error line on stdout and a non-zero status (no traceback).  (Single-host multi-device launch from
+    one command: RegNeRF/train.py:326-328 does the same with jax.pmap over the local devices.)"""
+    import subprocess
+    backend = os.environ.get("CNERF_DIST_BACKEND", "nccl")
+    ngpu = torch.cuda.device_count()
+
+    def fail(msg, rc, **kw):
+        err = {"metric": "train_ray_samples_per_sec", "value": None, "unit": "ray-samples/s", "n_gpus": n, "error": msg}
+        err.update(kw)
+        sys.stdout.write(json.dumps(err) + "\n")
+        sys.stdout.flush()
+        return rc
+
+    if backend == "nccl" and ngpu < n:
+        return fail(f"--gpus {n} needs {n} visible GPUs (one rank per GPU over RCCL); this host shows {ngpu}", 2, gpus_visible=ngpu)
+    if ngpu < 1:
+        return fail("no GPU visible (there is no CPU execution path)", 2, gpus_visible=0)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    try:
+        limit = float(os.environ.get("CNERF_BENCH_LAUNCH_TIMEOUT", "1500"))
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=None, timeout=limit)
+        rc, text = r.returncode, r.stdout.decode(errors="replace")
+    except subprocess.TimeoutExpired as e:
+        return fail(f"the {n}-rank run did not finish within {limit:.0f} s", 3, launcher=" ".join(cmd[:9]),
+                    stdout_tail=(e.stdout or b"").decode(errors="replace")[-400:])
+    line = None
+    for ln in text.splitlines():
+        ln = ln.strip()
+        if ln.startswith("{") and '"metric"' in ln:
+            try:
+                json.loads(ln)
+                line = ln
+            except ValueError:
+                pass
+    if line is None:
+        return fail(f"the {n}-rank run ended with status {rc} and printed no result line", rc or 4, launcher=" ".join(cmd[:9]),
+                    stdout_tail=text[-400:])
+    sys.stdout.write(line + "\n")
+    sys.stdout.flush()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -701,6 +761,9 @@ def main():
                     help="fill roofline.traffic from two rocprofv3 --pmc passes of THIS command (auto: at N=1 when the extra legs run and "
                          "rocprofv3 is on PATH; the committed lookup is the fallback)")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` launched plainly (no torchrun around it): become the launcher
+        raise SystemExit(self_launch(a.gpus))
 
     # stdout carries exactly ONE line, the JSON: everything else that writes to fd 1 — the reference-style prints of
     # create_nerf(), and RCCL's version banner, which the C library flushes at exit, i.e. AFTER the JSON — goes to stderr
@@ -719,7 +782,12 @@ def main():
         raise SystemExit(f"LOCAL_RANK {os.environ.get('LOCAL_RANK')} but only {ngpu} GPU(s) visible: one rank per GPU over RCCL")
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(ngpu, 1))
     rank, world, local = D.init_from_env(backend if (a.gpus > 1 or os.environ.get("CNERF_FORCE_DIST") == "1") else None)
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if world != a.gpus:
+        if rank == 0:
+            os.write(json_fd, (json.dumps({"metric": "train_ray_samples_per_sec", "value": None, "unit": "ray-samples/s",
+                                           "n_gpus": a.gpus, "error": f"--gpus {a.gpus} but the launcher's WORLD_SIZE is {world}"})
+                               + "\n").encode())
+        raise SystemExit(2)
     local = local % max(ngpu, 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -802,16 +870,21 @@ def main():
         if dist_info is not None:
             out["dist"] = dist_info
 
+    import threading
+    emit_lock, emitted, status = threading.Lock(), [False], [0]
+
     def emit():
-        if rank == 0:
-            sys.stdout.flush()
-            os.write(json_fd, (json.dumps(out) + "\n").encode())
+        """ONE line, whoever gets here first (the watchdog thread or the main thread)."""
+        with emit_lock:
+            if rank == 0 and not emitted[0]:
+                emitted[0] = True
+                sys.stdout.flush()
+                os.write(json_fd, (json.dumps(out) + "\n").encode())
 
     force_leg = os.environ.get("CNERF_BENCH_FORCE_LEG") == "1" and dist.is_initialized()     # (exercise the leg on a 1-rank group)
     if not a.no_extra and (world > 1 or force_leg) and per_rank == B_PER_GPU and B_PER_GPU % world == 0:
         # the same process group on the strong-scaling shard of C4.  A watchdog prints the line without this leg and ends
         # the process if the leg has not finished (a collective that never completes cannot be interrupted from Python).
-        import threading
         done = threading.Event()
 
         def watchdog():
@@ -819,13 +892,15 @@ def main():
                 if rank == 0:
                     out.setdefault("extra", {})["c4_strong"] = {"error": "leg did not finish within the watchdog's limit"}
                     emit()
-                os._exit(0)
+                sys.stderr.flush()
+                os._exit(6)        # the main line is out, but the launcher must see that a leg hung
         threading.Thread(target=watchdog, daemon=True).start()
         try:
             leg = shard_leg(wl, B_PER_GPU // (8 if force_leg and world == 1 else world), 100, 10, collective="split",
                             also_capture=dist.get_backend() == "nccl")
         except Exception as e:  # noqa: BLE001 — the main line must survive a failure of the side leg
             leg = {"error": f"{type(e).__name__}: {e}"}
+            status[0] = 5
         done.set()
         if rank == 0:
             out["extra"] = {"note": "same process group, after the timed region; not part of `value`", "c4_strong": leg}
@@ -850,12 +925,13 @@ def main():
         if world > 1:
             # the line is out: a communicator that a failed experiment of the side leg left in a bad state must not keep the
             # process (and the launcher waiting for it) alive
-            import threading
-            threading.Timer(30.0, lambda: os._exit(0)).start()
+            threading.Timer(30.0, lambda: os._exit(status[0] or 7)).start()     # teardown hung: say so in the status
         dist.destroy_process_group()
         if world > 1:
             sys.stderr.flush()
-            os._exit(0)
+            os._exit(status[0])
+    if status[0]:
+        raise SystemExit(status[0])
 
 
 if __name__ == "__main__":

@@ -2105,6 +2105,34 @@ def test_two_ranks_product_step_on_one_gpu(dev, tmp_path):
     assert r.returncode == 0 and "DIST2_GPU_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
+def test_bench_gpus_2_launched_plainly_is_its_own_launcher(dev):
+    """`python bench.py --gpus 2 ...` with NO torchrun around it (the shape of the driver's N = 1 command)
+    re-executes itself under torch.distributed.run and still prints exactly one JSON line from rank 0.  Two ranks on the box's
+    one MI355X over gloo (CNERF_DIST_BACKEND=gloo; the timing means nothing, the contract does): n_gpus 2, dist.ranks 2,
+    exit status 0.  With RCCL and one GPU the same command answers with one JSON error line and a non-zero status."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                            "CNERF_FORCE_DIST")}
+    env.update(CNERF_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-extra",
+                        "--no-cpu-baseline", "--rays-per-gpu", "512"], capture_output=True, text=True, env=env, timeout=900)
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, lines, r.stderr[-3000:])
+    o = json.loads(lines[0])
+    assert o["n_gpus"] == 2 and o["dist"]["ranks"] == 2 and o["dist"]["backend"] == "gloo" and o["value"] > 0
+    assert o["config"]["rays_per_gpu"] == 512 and o["steps"] == 3
+    if torch.cuda.device_count() < 2:
+        env.pop("CNERF_DIST_BACKEND")
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                           capture_output=True, text=True, env=env, timeout=300)
+        lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+        assert r.returncode != 0 and len(lines) == 1 and "error" in json.loads(lines[0]), (r.returncode, lines)
+        assert "Traceback" not in r.stderr
+
+
 def test_graphed_step_equals_eager_steps(dev):
     """graph.GraphedStep: the whole training step (render of both levels, fused losses, the merged backward, FusedAdam with its
     scalars in device memory, weight packing) recorded once as a hipGraph and replayed — bit-identical to the same steps run

@@ -430,3 +430,32 @@ def test_rows_of_global_draws_the_whole_batch_and_slices():
     assert torch.equal(torch.cat(parts), whole) and all(p.is_contiguous() for p in parts)
     torch.manual_seed(5)
     assert torch.equal(_rows_of_global(draw, 12, 3, None), whole)
+
+
+def _run_bench(args, env_extra=None, timeout=600):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    return r.returncode, lines, [json.loads(ln) for ln in lines if ln.startswith("{")], r.stderr
+
+
+def test_bench_gpus_n_launched_plainly_reports_missing_gpus_as_one_json_line():
+    """`python bench.py --gpus N` with no torchrun around it must not die on an assertion.  Here (no GPU, or
+    fewer than N): exactly ONE line on stdout, JSON, with an `error`, and a non-zero exit status — for RCCL and for gloo."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("host has the GPUs: the launch itself is covered by the gpu-marked test")
+    for extra in ({}, {"CNERF_DIST_BACKEND": "gloo"} if torch.cuda.device_count() == 0 else {}):
+        rc, lines, objs, err = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1"], extra, timeout=120)
+        assert rc != 0
+        assert len(lines) == 1 and len(objs) == 1, (lines, err[-500:])
+        assert objs[0]["n_gpus"] == 2 and objs[0]["value"] is None and "GPU" in objs[0]["error"]
+        assert "Traceback" not in err
