@@ -32,6 +32,32 @@ Round 3 (criteria fixed BEFORE the runs):
           Criterion B (after decorrelation): |mean gap| <= 2 sigma_chaos(steps) / sqrt(n_seeds) at every milestone.
   c2      one seed at the true C2 batch size, 150 steps: |gap| <= 2 sigma_chaos_c2(150) with sigma_chaos_c2 from 8 HIP seed
           pairs at that size (Criterion C).
+
+Round 4 (criteria fixed BEFORE the runs, committed before any twin result existed).  The Gaussian
+two-sigma limits of round 3 do not describe a spread made of discrete sigma-sign flips (R:281), so the C2-size statistical leg
+becomes a PERMUTATION test with a real null:
+  runs    per seed s in {0, 1, 2, 3} at the true C2 size, 150 steps, milestones 25 / 50 / 100 / 150:
+            O_s   the CPU oracle from the seed's initial weights              (round 3, kept)
+            O'_s  the CPU oracle from ulp_nudge(weights, s)                   (seed 1: round 3; seeds 0, 2, 3: round 4)
+            H_s,j the HIP path from ulp_nudge(weights, s + 1000 j), j = 1..6  (six draws, none sharing an init with an oracle run)
+            H_s,0 the HIP path from the seed's initial weights                (criterion A only: same init as O_s)
+          every run of a seed differs from every other by a one-ulp change of the initial weights; O / O' additionally differ from
+          the H runs by the implementation.  H0: the implementation label carries no information about held-out PSNR beyond what a
+          one-ulp perturbation does, i.e. the 8 runs {O, O', H_1..H_6} of a seed are exchangeable.
+  twins   python scripts/psnr_parity.py twins --oracle <npz with O, O'> --draws 6 --out profiles/r04_psnr_parity.json   (MI355X)
+  T_bias  (primary, two-sided) per milestone m:  B_m = mean_s [ mean_j P(H_s,j) - (P(O_s) + P(O'_s)) / 2 ]; null distribution by
+          relabelling, independently per seed, which 2 of the 8 runs are "the oracle's" (28^4 = 614 656 relabellings, enumerated
+          by Monte-Carlo with 200 000 draws, fixed RNG seed); p_m = P(|B_perm| >= |B_obs|).
+  T_dist  (secondary, one-sided) D_m = mean_s [ mean_j (|H_s,j - O_s| + |H_s,j - O'_s|) / 2 - mean_{j<k} |H_s,j - H_s,k| ]: cross-
+          implementation distance minus within-HIP distance; same relabelling; p_m = P(D_perm >= D_obs).
+  T_pair  (the literal VERDICT form, reported for completeness) d_s = |H_s,0 - O_s| - |O'_s - O_s| per milestone, one-sided
+          sign-flip test over the 4 seeds; with n = 4 its smallest attainable p is 1/16, so it cannot reject at 0.05 and carries
+          no weight in the verdict below.
+  Criterion D (parity at the C2 size): PASS iff no milestone has p(T_bias) < 0.0125 or p(T_dist) < 0.0125 (Bonferroni over the
+          4 milestones at the 5 % level, each statistic) AND criterion A holds for H_s,0 vs O_s (|gap| <= 0.02 dB at every
+          milestone where the two loss curves agree to 1e-3 relative on every seed).  FAIL otherwise; DESIGN.md states the outcome
+          without prose rescue.  The chaos-free evidence is the teacher-forced test
+          (tests/test_gpu_training_parity.py::test_c2_teacher_forced_training_steps), not this.
 """
 import argparse
 import json
@@ -200,11 +226,13 @@ def run_oracle(a):
 
 
 # ------------------------------------------------------------------------------------------------ GPU side
-def hip_run(seed, steps, nudged=False, milestones=(), reduced_too=True):
+def hip_run(seed, steps, nudged=False, milestones=(), reduced_too=True, nudge_key=None):
     from consistentnerf_amd import run_nerf as R
     dev = torch.device("cuda:0")
     K, bank, target, test_rays, test_rgb, sds = scene(seed)
-    if nudged:
+    if nudge_key is not None:
+        sds = ulp_nudge(sds, nudge_key)
+    elif nudged:
         sds = ulp_nudge(sds, seed)
     args = argparse.Namespace(
         multires=10, i_embed=0, use_viewdirs=True, multires_views=4, N_importance=128, netdepth=8, netwidth=256,
@@ -351,6 +379,98 @@ def run_chaos(a):
     print(json.dumps({k: v for k, v in out.items() if k != "runs"}))
 
 
+def run_twins(a):
+    """Round-4 criterion D (module docstring): blocked permutation tests of HIP draws against the oracle and its one-ulp twin at
+    the true C2 size."""
+    set_size(a.size)
+    ref = np.load(a.oracle)
+    seeds = [int(s_) for s_, c in zip(ref["seeds"], ref["has_control"]) if c]
+    ms = [int(m) for m in ref["milestones"]]
+    steps = int(ref["steps"])
+    rows = []
+    for s_ in seeds:
+        t0 = time.perf_counter()
+        K, bank, target, test_rays, test_rgb, sds = scene(s_)
+        hl0, _, _ = hip_run(s_, steps, False, ms, reduced_too=False)
+        h0 = [hip_run.psnr_at[m] for m in ms]
+        draws = []
+        for j in range(1, a.draws + 1):
+            hip_run(s_, steps, False, ms, reduced_too=False, nudge_key=s_ + 1000 * j)
+            draws.append([hip_run.psnr_at[m] for m in ms])
+        ol = ref[f"s{s_}_ref_loss"]
+        rel = np.abs(hl0 - ol) / np.abs(ol)
+        rows.append({"seed": s_, "psnr_oracle": [float(x) for x in ref[f"s{s_}_ref_psnr_at"]],
+                     "psnr_oracle_1ulp": [float(x) for x in ref[f"s{s_}_ctl_psnr_at"]],
+                     "psnr_hip_same_init": h0, "psnr_hip_draws": draws,
+                     "max_rel_loss_diff_up_to_hip_same_init": [float(rel[:m].max()) for m in ms],
+                     "seconds": time.perf_counter() - t0})
+        print(json.dumps(rows[-1]), flush=True)
+    out = twins_statistics(rows, ms)
+    out.update({"size": a.size, "rays_per_step": B, "image": [H, W], "steps": steps, "runs": rows})
+    with open(a.out, "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps({k: v for k, v in out.items() if k != "runs"}))
+
+
+def twins_statistics(rows, ms, n_perm=200000, rng_seed=20260929):
+    """T_bias / T_dist / T_pair of the module docstring from the per-seed PSNR tables; pure numpy (unit-tested on the CPU)."""
+    n_s, n_m = len(rows), len(ms)
+    k = len(rows[0]["psnr_hip_draws"])
+    # runs[s, r, m]: r = 0, 1 the oracle and its twin, 2.. the HIP draws
+    runs = np.array([[r["psnr_oracle"], r["psnr_oracle_1ulp"]] + list(r["psnr_hip_draws"]) for r in rows], dtype=np.float64)
+    n_r = runs.shape[1]
+
+    def stats(idx):
+        """idx[s] = the two run indices labelled 'oracle' for seed s -> (B_m, D_m)."""
+        Bm, Dm = np.zeros(n_m), np.zeros(n_m)
+        for s_ in range(n_s):
+            o = runs[s_, list(idx[s_])]                                   # [2, m]
+            h = np.delete(runs[s_], list(idx[s_]), axis=0)                # [k, m]
+            Bm += h.mean(0) - o.mean(0)
+            cross = np.abs(h[:, None, :] - o[None, :, :]).mean((0, 1))
+            iu = np.triu_indices(h.shape[0], 1)
+            within = np.abs(h[:, None, :] - h[None, :, :])[iu].mean(0)
+            Dm += cross - within
+        return Bm / n_s, Dm / n_s
+
+    B_obs, D_obs = stats([(0, 1)] * n_s)
+    pairs = [(i, j) for i in range(n_r) for j in range(i + 1, n_r)]
+    rs = np.random.RandomState(rng_seed)
+    ge_B, ge_D = np.zeros(n_m), np.zeros(n_m)
+    for _ in range(n_perm):
+        idx = [pairs[q] for q in rs.randint(0, len(pairs), n_s)]
+        Bp, Dp = stats(idx)
+        ge_B += np.abs(Bp) >= np.abs(B_obs) - 1e-12
+        ge_D += Dp >= D_obs - 1e-12
+    p_B, p_D = (ge_B + 1) / (n_perm + 1), (ge_D + 1) / (n_perm + 1)
+    # T_pair: the literal paired form, sign-flip over seeds (exact: 2^n)
+    h0 = np.array([r["psnr_hip_same_init"] for r in rows])
+    d = np.abs(h0 - runs[:, 0]) - np.abs(runs[:, 1] - runs[:, 0])          # [s, m]
+    p_pair = []
+    for m in range(n_m):
+        obs, cnt = d[:, m].mean(), 0
+        for mask in range(2 ** n_s):
+            sg = np.array([1 if (mask >> b) & 1 else -1 for b in range(n_s)])
+            cnt += (sg * d[:, m]).mean() >= obs - 1e-12
+        p_pair.append(float(cnt) / 2 ** n_s)
+    gap0 = h0 - runs[:, 0]
+    track = np.array([r["max_rel_loss_diff_up_to_hip_same_init"] for r in rows]).max(0) <= 1e-3
+    crit_a = bool(all(np.abs(gap0[:, m]).max() <= 0.02 for m in range(n_m) if track[m]))
+    alpha = 0.05 / n_m
+    crit_d = bool(crit_a and (p_B >= alpha).all() and (p_D >= alpha).all())
+    return {
+        "criteria_fixed_before_the_runs": "scripts/psnr_parity.py docstring, 'Round 4' block (commit precedes every twin result)",
+        "milestones": ms, "seeds": [r["seed"] for r in rows], "hip_draws_per_seed": k, "permutations": n_perm,
+        "T_bias": {"B_dB": B_obs.tolist(), "p_two_sided": p_B.tolist()},
+        "T_dist": {"D_dB": D_obs.tolist(), "p_one_sided": p_D.tolist()},
+        "T_pair": {"d_dB_per_seed": d.tolist(), "p_one_sided": p_pair, "smallest_attainable_p": 1.0 / 2 ** n_s},
+        "criterion_A": {"milestones_tracking": [m for m, t in zip(ms, track) if t],
+                        "max_abs_gap_same_init_dB": np.abs(gap0).max(0).tolist(), "pass": crit_a},
+        "bonferroni_alpha_per_milestone": alpha,
+        "criterion_D_pass": crit_d,
+    }
+
+
 def run_curve(a):
     """gap(steps): PSNR(HIP) - PSNR(oracle) at every milestone the oracle file holds, per seed, with the loss-curve agreement
     up to that milestone (criteria A / B of the module docstring; sigma from --chaos)."""
@@ -433,7 +553,14 @@ def main():
     cv.add_argument("--chaos", default=None)
     cv.add_argument("--size", default="small")
     cv.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "psnr_curve.json"))
+    tw = sub.add_parser("twins")
+    tw.add_argument("--oracle", required=True)
+    tw.add_argument("--draws", type=int, default=6)
+    tw.add_argument("--size", default="c2")
+    tw.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "psnr_twins.json"))
     a = ap.parse_args()
+    if a.side == "twins":
+        return run_twins(a)
     if a.side == "merge":
         merge_parts(a.out + ".parts", a.out)
     elif a.side == "chaos":

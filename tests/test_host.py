@@ -459,3 +459,33 @@ def test_bench_gpus_n_launched_plainly_reports_missing_gpus_as_one_json_line():
         assert len(lines) == 1 and len(objs) == 1, (lines, err[-500:])
         assert objs[0]["n_gpus"] == 2 and objs[0]["value"] is None and "GPU" in objs[0]["error"]
         assert "Traceback" not in err
+
+
+def test_psnr_twins_permutation_statistics_have_size_and_power():
+    """scripts/psnr_parity.py::twins_statistics (round-4 criterion D): on synthetic PSNR tables whose HIP draws come from the
+    oracle's own distribution the blocked permutation test does not reject; with a 2 dB systematic bias it does, at every
+    milestone; the literal 4-seed paired form can never go below 1/16."""
+    import importlib
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "scripts"))
+    P = importlib.import_module("psnr_parity")
+    ms = [25, 50, 100, 150]
+
+    def table(bias, seed):
+        rs = np.random.RandomState(seed)
+        rows = []
+        for s_ in range(4):
+            base = rs.normal(25, 1, 4)
+            rows.append({"seed": s_, "psnr_oracle": (base + rs.normal(0, 1, 4)).tolist(),
+                         "psnr_oracle_1ulp": (base + rs.normal(0, 1, 4)).tolist(),
+                         "psnr_hip_same_init": (base + bias).tolist(),
+                         "psnr_hip_draws": [(base + rs.normal(0, 1, 4) + bias).tolist() for _ in range(6)],
+                         "max_rel_loss_diff_up_to_hip_same_init": [1e-5, 1e-2, 1.0, 1.0]})
+            rows[-1]["psnr_hip_same_init"][0] = rows[-1]["psnr_oracle"][0] + 1e-3 + bias
+        return rows
+    null = [P.twins_statistics(table(0.0, k), ms, n_perm=3000) for k in range(6)]
+    assert sum(o["criterion_D_pass"] for o in null) >= 5                      # size: at most one false alarm in six
+    alt = P.twins_statistics(table(2.0, 0), ms, n_perm=3000)
+    assert not alt["criterion_D_pass"] and max(alt["T_bias"]["p_two_sided"]) < 0.0125
+    assert min(alt["T_pair"]["p_one_sided"]) >= 1.0 / 16 and alt["T_pair"]["smallest_attainable_p"] == 1.0 / 16
