@@ -182,6 +182,7 @@ def cpu_baseline(seconds_budget=25.0):
     best, cores = (val, ncores) if (phys_val is None or val >= phys_val) else (phys_val, phys)
     return {"value": best, "unit": "ray-samples/s", "cores": cores, "kind": "port",
             "threads_main": ncores, "value_main": val, "physical_cores": phys, "value_physical_cores": phys_val,
+            "value_all_physical_cores": phys_val, "value_32_threads": val,
             "sample_physical_cores": phys_sample, "single_thread_value": v1, "logical_cpus_usable": avail,
             "inference_value": inf_val, "inference_sample": f"forward only, 2 x 1024 rays, {ncores} threads (the C5 shapes)",
             "sample": f"{n} training steps of {Bc} rays (same C2 shapes: 64+192 samples, D=8/W=256, fwd+bwd+Adam), "
@@ -390,6 +391,7 @@ def pmc_rerun(per_rank, dom_kernel):
     if shutil.which("rocprofv3") is None:
         return {"traffic": None, "source": "rocprofv3 not on PATH"}
     res, launches = {}, {}
+    dispatches = {"FETCH_SIZE": {}, "WRITE_SIZE": {}}
     env = dict(os.environ, TMPDIR="/tmp")
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="cnerf_pmc_")
@@ -408,6 +410,8 @@ def pmc_rerun(per_rank, dom_kernel):
             for f in files:
                 with open(f) as fh:
                     for row in csv.DictReader(fh):
+                        if row["Counter_Name"] == ctr:
+                            dispatches[ctr][int(row["Dispatch_Id"])] = row["Kernel_Name"]
                         if pat in row["Kernel_Name"] and "reduce" not in row["Kernel_Name"] and row["Counter_Name"] == ctr:
                             vals.setdefault(row["Dispatch_Id"], 0.0)
                             vals[row["Dispatch_Id"]] += float(row["Counter_Value"])
@@ -418,10 +422,43 @@ def pmc_rerun(per_rank, dom_kernel):
             res[ctr], launches[ctr] = sum(big) / len(big) * 1024.0, len(big)
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    return {"traffic": int(2 * res["FETCH_SIZE"] + res["WRITE_SIZE"]), "FETCH_SIZE_bytes_x2": int(2 * res["FETCH_SIZE"]),
+    return {"launches": launches_per_step(dispatches["FETCH_SIZE"]),
+            "traffic": int(2 * res["FETCH_SIZE"] + res["WRITE_SIZE"]), "FETCH_SIZE_bytes_x2": int(2 * res["FETCH_SIZE"]),
             "FETCH_SIZE_bytes_raw": int(res["FETCH_SIZE"]), "WRITE_SIZE_bytes": int(res["WRITE_SIZE"]), "launches_averaged": launches,
             "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of THIS command (3 steps each), per launch of the "
                       "dominant kernel: 2*FETCH_SIZE + WRITE_SIZE"}
+
+
+def route_of(table, steps):
+    """Which autograd route the timed steps took (consistentnerf_amd/run_nerf.py): "merged" = ONE dgrad + ONE wgrad launch per step
+    for both networks (the engine query `torch._C._will_engine_execute_node` is usable and CNERF_MERGE_BWD != 0), "plain" = one
+    backward per level.  Read off the launch counts of the timed region, with what the module selected at import beside it."""
+    from consistentnerf_amd import run_nerf as R
+    wg = [r for r in table if r["kernel"] == "mlp_wgrad"]
+    per_step = sum(r["launches"] for r in wg) / max(steps, 1)
+    return {"backward": "merged" if abs(per_step - 1.0) < 1e-9 else "plain", "wgrad_launches_per_step": per_step,
+            "engine_query_usable": R._ENGINE_QUERY is not None, "merge_bwd_enabled": bool(R.MERGE_BWD),
+            "direct_accumulation_into_flat_grad": R._ENGINE_QUERY is not None}
+
+
+def launches_per_step(dispatches):
+    """Kernel launches of ONE training step, from the ordered dispatch list of a rocprofv3 pass over this command: every step ends
+    with exactly one `adam_k`, so the dispatches between two consecutive ones are one step's.  -> {"total", "own" (kernels of
+    libcnerf_hip.so), "aten" (torch glue: RNG, fills, copies, cat ...), "kernels": {short name: count}} of the last full step."""
+    ids = sorted(dispatches)
+    names = [dispatches[i] for i in ids]
+    ends = [k for k, n in enumerate(names) if "adam_k" in n]
+    if len(ends) < 2:
+        return None
+    step = names[ends[-2] + 1:ends[-1] + 1]
+    own = [n for n in step if "anonymous namespace)::" in n and "at::native" not in n]
+    hist = {}
+    for n in step:
+        short = n.split("(anonymous namespace)::")[1].split("(")[0] if n in own else (
+            "aten:" + n.split("at::native::")[-1].split("<")[0].split("(")[0] if "at::native" in n else n.split("(")[0])
+        hist[short] = hist.get(short, 0) + 1
+    return {"total": len(step), "own": len(own), "aten_and_runtime": len(step) - len(own), "kernels": hist,
+            "source": "ordered dispatch list of the rocprofv3 pass of THIS command; one step = the dispatches between two adam_k"}
 
 
 def c3_leg(dev, steps=20):
@@ -829,6 +866,7 @@ def main():
     roofline = {"bound": "mfma", "kernel": f'{dom["kernel"]} (M={dom["points"]} points)', "achieved": dom["tflops"],
                 "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(dom["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4),
                 "traffic": traffic, "traffic_source": traffic_source, "avg_launch_ms": dom["avg_ms"], "kernels": table}
+    launches_live = pmc_live.pop("launches", None) if pmc_live else None
     if pmc_live:
         roofline["pmc"] = pmc_live
     if graphed is not None:
@@ -860,6 +898,7 @@ def main():
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if (a.scaling == "strong" and a.rays_per_gpu <= 0) else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic", "hip_graph": graphed is not None,
+            "route": route_of(table, a.steps),
             "config": {"workload": f"DTU scan8 3-view (synthetic 512x640 ray bank), {per_rank} rays/GPU/step (global batch "
                                    f"{per_rank * world}), coarse 64 + fine 64+128 samples, D=8 W=256 viewdirs MLPs (random init), "
                                    f"perturb=1, mse(rgb)+mse(rgb0), backward, Adam; {cfgname}",
@@ -916,6 +955,8 @@ def main():
             extra["c5"] = c5_leg(dev)
             extra["c3"] = c3_leg(dev)
             extra["hbm_kernels"] = hbm_kernels(dev)
+            extra["launches_per_step"] = launches_live if launches_live is not None else {
+                "total": None, "source": "needs the rocprofv3 pass (--pmc auto|on with rocprofv3 on PATH)"}
             out["extra"] = extra
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

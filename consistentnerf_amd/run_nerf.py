@@ -684,6 +684,8 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
         ret['z_std'] = z_std
     if _debug:
         ret['_z_coarse'], ret['_z_vals'], ret['_weights'] = z_coarse, z_vals, weights
+        if N_importance > 0:
+            ret['_raw_coarse'] = raw_coarse
     if DEBUG:
         for k in ret:
             if torch.isnan(ret[k]).any() or torch.isinf(ret[k]).any():

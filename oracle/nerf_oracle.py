@@ -74,34 +74,53 @@ def _lin(sd: Dict[str, Tensor], name: str, x: Tensor) -> Tensor:
     return torch.addmm(sd[name + ".bias"], x, sd[name + ".weight"].t())
 
 
-def mlp_forward(sd: Dict[str, Tensor], x_pts: Tensor, x_dir: Optional[Tensor], cfg: NetCfg) -> Tensor:
+def mlp_forward(sd: Dict[str, Tensor], x_pts: Tensor, x_dir: Optional[Tensor], cfg: NetCfg,
+                masks=None, flips: Optional[list] = None) -> Tensor:
     """[M, input_ch] (+ [M, input_ch_views]) -> [M, 4] (or output_ch without viewdirs).
     Trunk of D ReLU layers; after trunk layer i in `skips` the encoded point is concatenated IN FRONT
     of the hidden state (H:110-114); heads per H:116-128: sigma from the trunk, rgb through the
-    W/2-wide view branch fed [feature | dir-encoding]; output order [rgb, sigma]."""
+    W/2-wide view branch fed [feature | dir-encoding]; output order [rgb, sigma].
+
+    `masks` (teacher-forced gradient tests only): a list of D (+1 with viewdirs) bool tensors [M, width] — the ReLU pattern to
+    APPLY instead of this function's own (z > 0), i.e. h = z * mask.  With the kernel's sign bits passed in, the oracle's
+    backward differentiates exactly the piecewise-linear branch the kernel took; wherever the patterns differ the value changes by
+    |z| only, and `flips` (a list) receives per ReLU layer (number of units whose own (z > 0) differs from the mask, max |z| there)
+    so that a test can assert such units only exist within round-off of zero."""
+    def act(z, k):
+        if masks is None:
+            return torch.relu(z)
+        m = masks[k]
+        if flips is not None:
+            with torch.no_grad():
+                diff = (z > 0) != m
+                n = int(diff.sum())
+                flips.append((n, float(z[diff].abs().max()) if n else 0.0))
+        return z * m.to(z.dtype)
+
     h = x_pts
     for i in range(cfg.D):
-        h = torch.relu(_lin(sd, f"pts_linears.{i}", h))
+        h = act(_lin(sd, f"pts_linears.{i}", h), i)
         if i in cfg.skips:
             h = torch.cat([x_pts, h], dim=-1)
     if not cfg.use_viewdirs:
         return _lin(sd, "output_linear", h)
     sigma = _lin(sd, "alpha_linear", h)
     feat = _lin(sd, "feature_linear", h)
-    hv = torch.relu(_lin(sd, "views_linears.0", torch.cat([feat, x_dir], dim=-1)))
+    hv = act(_lin(sd, "views_linears.0", torch.cat([feat, x_dir], dim=-1)), cfg.D)
     rgb = _lin(sd, "rgb_linear", hv)
     return torch.cat([rgb, sigma], dim=-1)
 
 
-def query(sd: Dict[str, Tensor], pts: Tensor, viewdirs: Optional[Tensor], cfg: NetCfg) -> Tensor:
+def query(sd: Dict[str, Tensor], pts: Tensor, viewdirs: Optional[Tensor], cfg: NetCfg, masks=None,
+          flips: Optional[list] = None) -> Tensor:
     """a4 run_network (R:37-52): pts [B,S,3], viewdirs [B,3] (one per ray, broadcast over samples)
-    -> raw [B,S,C].  (The reference's netchunk loop does not change results.)"""
+    -> raw [B,S,C].  (The reference's netchunk loop does not change results.)  masks / flips: see mlp_forward."""
     B, S = pts.shape[:2]
     xp = embed(pts.reshape(-1, 3), cfg.multires)
     xd = None
     if cfg.use_viewdirs:
         xd = embed(viewdirs[:, None, :].expand(B, S, 3).reshape(-1, 3), cfg.multires_views)
-    out = mlp_forward(sd, xp, xd, cfg)
+    out = mlp_forward(sd, xp, xd, cfg, masks, flips)
     return out.reshape(B, S, out.shape[-1])
 
 
@@ -194,7 +213,8 @@ def coarse_z(near: Tensor, far: Tensor, Nc: int, lindisp: bool, t_rand: Optional
 def render_rays(ray_batch: Tensor, sd_coarse, sd_fine, net: NetCfg, cfg: RenderCfg,
                 t_rand: Optional[Tensor] = None, u: Optional[Tensor] = None,
                 noise0: Optional[Tensor] = None, noise1: Optional[Tensor] = None,
-                retraw: bool = True, net_fine: Optional[NetCfg] = None, z_fine: Optional[Tensor] = None):
+                retraw: bool = True, net_fine: Optional[NetCfg] = None, z_fine: Optional[Tensor] = None,
+                masks_coarse=None, masks_fine=None, flips: Optional[list] = None):
     """ray_batch [B, 8|11] = o, d, near, far, (viewdirs).  Randoms are passed IN (t_rand [B,Nc] for
     the stratified jitter when perturb>0; u [B,Nf] for sample_pdf; noise0/noise1 already scaled by
     raw_noise_std) so oracle and kernels consume identical streams.  If perturb==0, u defaults to
@@ -206,7 +226,7 @@ def render_rays(ray_batch: Tensor, sd_coarse, sd_fine, net: NetCfg, cfg: RenderC
     near, far = ray_batch[:, 6:7], ray_batch[:, 7:8]
     z = coarse_z(near, far, cfg.N_samples, cfg.lindisp, t_rand if cfg.perturb > 0 else None)
     pts = o[:, None, :] + d[:, None, :] * z[:, :, None]
-    raw = query(sd_coarse, pts, vd, net)
+    raw = query(sd_coarse, pts, vd, net, masks_coarse, flips)
     rgb, disp, acc, w, depth = composite(raw, z, d, noise0, cfg.white_bkgd)
     out = {}
     if cfg.N_importance > 0:
@@ -218,11 +238,13 @@ def render_rays(ray_batch: Tensor, sd_coarse, sd_fine, net: NetCfg, cfg: RenderC
         z_new, _ = sample_pdf(z_mid, w[:, 1:-1], u)
         z_new = z_new.detach()
         z, _ = torch.sort(torch.cat([z, z_new], dim=-1), dim=-1)
+        z_own = z
         if z_fine is not None:   # "teacher forcing" for kernel tests: evaluate the fine level at given depths
             z = z_fine
         pts = o[:, None, :] + d[:, None, :] * z[:, :, None]
         sd2, net2 = (sd_coarse, net) if sd_fine is None else (sd_fine, net_fine or net)
-        raw = query(sd2, pts, vd, net2)
+        out["z_own"] = z_own       # this function's own sorted depths (== z unless z_fine overrides them)
+        raw = query(sd2, pts, vd, net2, masks_fine, flips)
         rgb, disp, acc, w, depth = composite(raw, z, d, noise1, cfg.white_bkgd)
         out["z_std"] = torch.std(z_new, dim=-1, unbiased=False)
     out.update(rgb_map=rgb, disp_map=disp, acc_map=acc, depth_map=depth, z_vals=z, weights=w)

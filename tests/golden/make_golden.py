@@ -918,16 +918,93 @@ def fx_ssloss_primary():
     save("ssloss_primary", **out)
 
 
-ALL = dict(train_v=fx_train_v, ssloss_primary=fx_ssloss_primary, ssloss=fx_ssloss, poses=fx_poses, patch=fx_patch, formats=fx_formats, raybank=fx_raybank, embed=fx_embed, mlp=fx_mlp, raw2outputs=fx_raw2outputs, sample_pdf=fx_sample_pdf, sample_pdf_bulk=fx_sample_pdf_bulk,
+def fx_trained():
+    """A WELL-CONDITIONED end-to-end fixture: the reference itself trains the C2 networks (D=8/W=256, viewdirs,
+    64 + 128 samples) for 200 steps of its vanilla loop (run_nerf.py:764-788, pytest RNG, 1024-ray batches) on the analytic
+    sphere-over-floor scene seen from 3 DTU-like views, then renders 1024 held-out rays FREE-RUNNING through its own
+    `render_rays` (run_nerf_view.py:441-551) — once with perturb = 1 (pytest streams) and once test-time (perturb = 0).  Stored:
+    the trained weights (inputs of the parity test) and the reference's maps.  The random-init fixtures above amplify a 1e-6 depth
+    difference by ~1e3 through the 2^9-frequency encodings; a trained network does not, so HIP free-running is held to 1e-4 here."""
+    Hh, Ww, focal, near, far, radius, nb, steps = 128, 160, 361.5, 2.125, 4.67, 3.0, 1024, 200
+    K = I.intrinsics(Hh, Ww, focal)
+    rays, cols = [], []
+    for th in (0.0, 25.0, -25.0):
+        pose = I.camera_pose(th, -20.0, radius)
+        ro, rd = H.get_rays_np(Hh, Ww, K, pose[:3, :4])
+        rays.append(np.concatenate([ro.reshape(-1, 3), rd.reshape(-1, 3)], -1).astype(np.float32))
+        cols.append(I.analytic_scene(Hh, Ww, K, pose)[1].reshape(-1, 3))
+    bank, target = np.concatenate(rays), np.concatenate(cols).astype(np.float32)
+    perm = np.random.RandomState(5).permutation(bank.shape[0])
+    bank, target = bank[perm], target[perm]
+    with tempfile.TemporaryDirectory() as tmp:
+        os.makedirs(os.path.join(tmp, "exp"))
+        args = argparse.Namespace(
+            multires=10, i_embed=0, use_viewdirs=True, multires_views=4, N_importance=128, netdepth=8,
+            netwidth=256, netdepth_fine=8, netwidth_fine=256, netchunk=1024 * 64, lrate=5e-4,
+            basedir=tmp, expname="exp", ft_path=None, no_reload=True, perturb=1.0, N_samples=64,
+            white_bkgd=False, raw_noise_std=0.0, dataset_type="dtu", no_ndc=True, lindisp=False)
+        kw_train, kw_test, start, grad_vars, optimizer = R.create_nerf(args)
+    for k_, seed in (("network_fn", 1001), ("network_fine", 1002)):
+        sd = I.nerf_state_dict(8, 256, 10, 4, 5, True, seed=seed, gain=0.6)
+        kw_train[k_].load_state_dict({k: T(v) for k, v in sd.items()})
+    kw_train.update(near=near, far=far)
+    losses, lrate_decay, global_step = [], 250, start
+    import time
+    t0 = time.time()
+    for i in range(steps):
+        lo = (i * nb) % (bank.shape[0] - nb)
+        b = T(bank[lo:lo + nb])
+        batch_rays = torch.stack([b[:, 0:3], b[:, 3:6]], 0)
+        rgb, disp, acc, extras = R.render(Hh, Ww, K, chunk=32768, rays=batch_rays, retraw=True, pytest=True, **kw_train)
+        optimizer.zero_grad()
+        tg = T(target[lo:lo + nb])
+        loss = H.img2mse(rgb, tg) + H.img2mse(extras["rgb0"], tg)
+        losses.append(loss.item())
+        loss.backward()
+        optimizer.step()
+        new_lrate = args.lrate * (0.1 ** (global_step / (lrate_decay * 1000)))
+        for g in optimizer.param_groups:
+            g["lr"] = new_lrate
+        global_step += 1
+        if i % 20 == 0:
+            print(f"    step {i} loss {losses[-1]:.5f} ({time.time() - t0:.0f} s)", flush=True)
+    # held-out rays: a fourth view, every 20th pixel
+    pose = I.camera_pose(12.0, -15.0, radius)
+    ro, rd = H.get_rays_np(Hh, Ww, K, pose[:3, :4])
+    sel = np.arange(0, Hh * Ww, 20)[:1024]
+    ro, rd = ro.reshape(-1, 3)[sel].astype(np.float32), rd.reshape(-1, 3)[sel].astype(np.float32)
+    vd = rd / np.linalg.norm(rd, axis=-1, keepdims=True)
+    test_rays = np.concatenate([ro, rd, np.full((len(sel), 1), near, np.float32), np.full((len(sel), 1), far, np.float32), vd],
+                               -1).astype(np.float32)
+    gt = I.analytic_scene(Hh, Ww, K, pose)[1].reshape(-1, 3)[sel]
+    arrays = {"rays": test_rays, "gt": gt.astype(np.float32), "losses": np.array(losses, np.float32),
+              "near_far": np.array([near, far], np.float32)}
+    for tag, k_ in (("c.", "network_fn"), ("f.", "network_fine")):
+        arrays.update({tag + k: v for k, v in kw_train[k_].state_dict().items()})
+    embed_fn, _ = H.get_embedder(10, 0)
+    for tag, perturb in (("p1.", 1.0), ("p0.", 0.0)):
+        with torch.no_grad():
+            ret = V.render_rays(T(test_rays), retraw=False, pytest=True,
+                                **_render_kwargs(V, kw_train["network_fn"], kw_train["network_fine"], 64, 128, perturb, False, 0.0))
+        arrays.update({tag + k: v for k, v in ret.items()})
+        mse = float(((ret["rgb_map"] - T(gt)) ** 2).mean())
+        print(f"    held-out {tag} PSNR {-10 * np.log10(mse):.2f} dB")
+    save("render_rays_trained", **arrays)
+
+
+ALL = dict(trained=fx_trained, train_v=fx_train_v, ssloss_primary=fx_ssloss_primary, ssloss=fx_ssloss, poses=fx_poses, patch=fx_patch, formats=fx_formats, raybank=fx_raybank, embed=fx_embed, mlp=fx_mlp, raw2outputs=fx_raw2outputs, sample_pdf=fx_sample_pdf, sample_pdf_bulk=fx_sample_pdf_bulk,
            render_rays=fx_render_rays, render_full=fx_render_full, warp=fx_warp, hardmask=fx_hardmask,
            losses=fx_losses, train=fx_train, pairs=fx_pairs)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", nargs="*", default=None)
+    ap.add_argument("--skip", nargs="*", default=[], help="fixtures to leave alone (e.g. `trained`: ~30 min of reference training)")
+    ap.add_argument("--threads", type=int, default=8)
     a = ap.parse_args()
+    torch.set_num_threads(a.threads)
     for name, fn in ALL.items():
-        if a.only and name not in a.only:
+        if (a.only and name not in a.only) or name in a.skip:
             continue
         print(f"[{name}]")
         fn()

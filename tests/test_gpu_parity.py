@@ -8,8 +8,10 @@ Stated tolerances (fp32 path, v_mfma_f32_32x32x2_f32 + OCML sin/cos/exp vs ATen/
   weights                  |d| <= 2e-5          z (coarse) bit-exact;  z (fine) |d| <= 2e-5 * far
   sample_pdf indices       bit-exact wherever min_k |u - cdf_k| > 1e-5 (SURVEY hard part 3), mismatch rate reported
   warp pixels / masks      bit-exact wherever the projected pixel is > 1e-3 px away from a rounding tie
-  gradients                |d| <= 1e-5 * max|g| per tensor against an fp64 replay from the kernel's own ReLU masks;
-                           vs the reference capture 5e-2 rel-max / 5e-3 rel-L2 (one near-zero ReLU may flip)
+  gradients                |d| <= 1e-5 * max|g| per tensor against an fp64 replay from the kernel's own ReLU masks, AND
+                           against the CPU oracle (pinned on the reference captures) differentiating the kernel's own ReLU
+                           branch (its sign bits passed in; pattern differences counted, only within 1e-5 of zero);
+                           vs the reference capture itself 2e-1 rel-max (one near-zero ReLU may flip: loose by construction)
   end to end (fine level)  |d rgb| <= 5e-3, PSNR-equivalent >= 50 dB vs the capture (conditioning of the
                            2^9-frequency encoding, see test_render_rays_golden); 2e-5 when the oracle is evaluated at
                            the kernel's own sample depths
@@ -138,6 +140,21 @@ def stash_blocks(stash, M, D, W, vd, in_chp=64):
     if vd:
         assert np.array_equal(decode(D * 2 * md, max(nt // 2, 1), mdv), out["hv"].numpy() > 0), "sign bits (view branch)"
     return out
+
+
+def relu_masks(stash, M, D, W, vd):
+    """The ReLU patterns of a training forward, from its stash: [M, W] bool per trunk layer (+ [M, W/2] for the view branch) on
+    the CPU — what O.mlp_forward(..., masks=) applies instead of its own (z > 0).  stash_blocks() checks the sign-bit words the
+    dgrad kernel reads against (h > 0) of the stored activations, so these ARE the kernel's derivative patterns."""
+    blk = stash_blocks(stash, M, D, W, vd)
+    return [blk[f"h{l}"] > 0 for l in range(D)] + ([blk["hv"] > 0] if vd else [])
+
+
+def check_flips(flips, tol=1e-5):
+    """Units whose ReLU pattern differs between the kernel and the oracle must sit within round-off of zero."""
+    n, zmax = sum(f[0] for f in flips), max([f[1] for f in flips] + [0.0])
+    print(f"  ReLU pattern differences kernel vs oracle: {n} units, max |z| there {zmax:.2e} (bound {tol:.0e})")
+    assert zmax < tol, f"a ReLU unit with |z| = {zmax:.3e} took different branches"
 
 
 # ------------------------------------------------------------------------------------------------
@@ -296,10 +313,24 @@ def test_mlp_golden(dev, tag, D, W, vd, och):
     raw = run_network(T(g["pts"], dev), T(g["dirs"], dev) if vd else None, model, e, ed)
     scale = max(1.0, float(np.abs(g["raw"]).max()))
     check(raw, g["raw"], 3e-5 * scale, "raw")
+    M = raw.shape[0] * raw.shape[1]
+    masks = relu_masks(raw.grad_fn.stash, M, D, W, vd)
     (raw * T(g["G"], dev)).sum().backward()
-    # loose on purpose (a near-zero ReLU may take a different branch than on the CPU, see check_param_grads);
-    # the same inputs are checked to 1e-5 against an fp64 replay in test_mlp_backward_exact_from_stash[24-16-*]
+    # (a) vs the reference capture: loose on purpose (a near-zero ReLU may take a different branch than on the CPU, see
+    # check_param_grads)
     check_param_grads(model, g, "grad.", "gs.", rtol=2e-1, l2tol=1e-1)
+    # (b) TIGHT, with the ReLU patterns held equal: the oracle — pinned on this very capture by
+    # tests/test_oracle_golden.py — differentiates the branch the kernel took (its sign bits are passed in), and every unit
+    # where the two patterns differ must lie within round-off of zero
+    sd = O.as_tensors(I.nerf_state_dict(D, W, 10, 4, och, vd, 11), True)
+    cfg = O.NetCfg(D, W, use_viewdirs=vd, output_ch=och)
+    pts, flips = T(g["pts"]), []
+    ref = O.query(sd, pts, T(g["dirs"]) if vd else None, cfg, masks, flips)
+    check_flips(flips)
+    (ref * T(g["G"])).sum().backward()
+    tight = {"t." + k: (p.grad if p.grad is not None else torch.zeros_like(p)).numpy() for k, p in sd.items()}
+    print("  parameter gradients vs the oracle on the kernel's ReLU branch:")
+    check_param_grads(model, tight, "t.", "t.", rtol=1e-5, l2tol=1e-5)    # measured 3e-6
 
 
 # (the envelope's far corners too: their capture-style gradient check is loose by construction, this one is not)
@@ -413,6 +444,7 @@ def test_render_rays_golden(dev, tag, D, W, Nc, Nf, perturb, white, noise, lindi
     ret = V.render_rays(rays, retraw=True, pytest=True, _debug=True,
                         **_kwargs(coarse, fine, Nc, Nf, perturb, white, noise, lindisp))
     dbg = {k: ret.pop(k) for k in ("_z_coarse", "_z_vals", "_weights")}
+    ret.pop("_raw_coarse", None)
     assert set(ret) == {k for k in g if not k.startswith(("gc.", "gf.")) and k not in ("target", "prior", "loss")}
     far = 6.0
     # (1) coarse level: identical sample depths on both sides (coarse z is bit-exact) -> tight bounds
@@ -424,9 +456,15 @@ def test_render_rays_golden(dev, tag, D, W, Nc, Nf, perturb, white, noise, lindi
         # (2) fine level, teacher-forced: the CPU oracle evaluated at the GPU's own fine depths -> tight bounds.
         sdc = O.as_tensors(I.nerf_state_dict(D, W, 10, 4, och, True, seed=21), True)
         sdf = O.as_tensors(I.nerf_state_dict(D, W, 10, 4, och, True, seed=22), True)
+        node_f = ret["raw"].grad_fn
+        node_c = node_f.pair.coarse()
+        flips = []
         ref = O.render_rays_pytest(rays.cpu(), sdc, sdf, O.NetCfg(D, W, output_ch=och),
                                    O.RenderCfg(Nc, Nf, perturb, lindisp, white, noise),
-                                   z_fine=dbg["_z_vals"].cpu())
+                                   z_fine=dbg["_z_vals"].cpu(), flips=flips,
+                                   masks_coarse=relu_masks(node_c.stash, B * Nc, D, W, True),
+                                   masks_fine=relu_masks(node_f.stash, B * (Nc + Nf), D, W, True))
+        check_flips(flips)
         tf_target, tf_prior = T(g["target"]), T(g["prior"])
         tf_loss = (O.mse(ref["rgb_map"], tf_target) + O.mse(ref["depth_map"] / far, tf_prior / far) +
                    O.mse(ref["rgb0"], tf_target) + O.mse(ref["depth0"] / far, tf_prior / far))
@@ -465,9 +503,10 @@ def test_render_rays_golden(dev, tag, D, W, Nc, Nf, perturb, white, noise, lindi
     loss.backward()
     if Nf > 0:
         # gradients against the oracle differentiated AT THE KERNEL'S DEPTHS (same sample set on both sides)
-        print("  parameter gradients vs oracle at the kernel's depths:")
-        check_param_grads(coarse, tf_grads, "gc.", "gc.", rtol=2e-3, l2tol=1e-3)
-        check_param_grads(fine, tf_grads, "gf.", "gf.", rtol=2e-3, l2tol=1e-3)
+        # TIGHT: same sample set AND same ReLU branch on both sides
+        print("  parameter gradients vs oracle at the kernel's depths, on the kernel's ReLU branch:")
+        check_param_grads(coarse, tf_grads, "gc.", "gc.", rtol=1e-5, l2tol=1e-5)       # measured <= 3e-6
+        check_param_grads(fine, tf_grads, "gf.", "gf.", rtol=1e-5, l2tol=1e-5)
         print("  parameter gradients vs the reference capture (different fine sample set at CDF ties):")
         check_param_grads(coarse, g, "gc.", "gc.", rtol=2e-1, l2tol=1e-1)
         check_param_grads(fine, g, "gf.", "gf.", rtol=2e-1, l2tol=1e-1)

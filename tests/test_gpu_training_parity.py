@@ -1,0 +1,301 @@
+"""Chaos-free training parity at the true C2 size.
+
+The PSNR-parity clause of the north star cannot be closed by comparing two free-running fp32 Adam trajectories: they
+decorrelate at the rate round-off is amplified (profiles/r03_psnr_*).  What CAN be asserted is the map one training step
+applies — (weights, Adam moments, batch, random streams) -> (loss, gradient, new weights) — at points ALONG a real trajectory:
+the HIP path trains the synthetic DTU-like scene at the true C2 shapes (scripts/psnr_parity.py::scene: 512x640 views, 4096-ray
+batches, 64 + 128 samples, D=8/W=256, the reference's pytest=True RNG hook), and at steps {0, 2, 17, 50, 100, 150} the state is
+snapshotted and ONE oracle step is run on the CPU from exactly that state (O.query -> O.composite on both levels -> mse + mse ->
+autograd -> O.adam_step; reference: run_nerf.py:764-789, run_nerf.py:281, run_nerf_helpers.py:9-10).
+
+Teacher forcing INSIDE the step.  The step map is piecewise smooth; its discontinuities are (a) the hidden ReLU patterns, (b) the
+resampled fine depths (no gradient, R:397) and (c) the sign of the LAST sample's sigma — its interval is 1e10 wide (R:281), so
+alpha_last jumps from 0 to 1 across sigma_last = 0 and the derivative between 0 and ~1e-8 is ~1e10.  The oracle is therefore
+evaluated on the kernel's branch: at the kernel's depths (its own resampled depths are compared separately), with the kernel's ReLU
+sign bits applied instead of its own (z > 0) (`masks` of O.query), and with the kernel's sigma_last substituted for the rays whose
+own sigma_last is on the other side of 0 or inside the 1e-7 spike zone — every such substitution / pattern difference is counted and
+must sit within round-off of the discontinuity.
+
+The step is evaluated twice: in float64 (g_exact: the exact gradient of the reference's step map on that branch) and in fp32
+(g_ref32: the reference arithmetic itself — ATen / MKL sgemm sum ~10^6 signed products per weight in fp32).
+
+Stated bounds:
+  loss                       |d| <= 1e-6 relative, vs g_ref32's loss, vs the float64 loss, and vs the oracle running FREE
+                             (O.render_rays_pytest: its own depths, ReLU patterns and tail signs) 1e-5
+  gradient                   in units of fp32 round-off of the sum being computed: every gradient element is a sum over ~10^6
+                             ray-samples of signed products that largely cancel once training converges, so the scale of its
+                             rounding error is eps32 * A, A = sum of |dZ| |h| over the samples (computed in float64, per element).
+                             K_hip = max |g_HIP - g_exact| / (eps32 * A) <= 16 per tensor (a sequential fp32 sum of n terms may
+                             lose n eps; blocked / pairwise ones ~log n: 16 eps is a bound a correct fp32 implementation with
+                             tree-like summation meets and a systematic error of 1e-6 of the mass does not), with
+                             K_ref32 (the reference's own arithmetic, same units) reported beside it;
+                             plus the plain figure |g_HIP - g_exact| <= 1e-4 * max|g| per tensor
+  ReLU pattern differences   only where the oracle's own |z| < 1e-5, fewer than 1e-6 of all units
+  tail-branch substitutions  only where the kernel's |sigma_last| < 1e-5
+  Adam on the SAME gradient  new weights |d| <= 2e-7 (+ 2 ulp), moments 1e-6 relative to their max
+  new weights end to end     |d| <= 2e-6 + the first-order propagation of the measured gradient difference through Adam's
+                             normalisation (an element whose gradient history is ~0 moves by ~lr whatever its sign), and the
+                             fraction of elements beyond the plain 2e-6 is reported and <= 1e-3
+  fine depths                the oracle's own resampled depths vs the kernel's: median <= 2e-6 * far, 99 % <= 2e-5 * far, max <=
+                             1e-3 * far (inverse-CDF interpolation divides by a CDF gap that may be as small as 1e-5, H:246-247:
+                             a 1e-7 CDF difference moves such a sample by 1e-2 of its bin; test_gpu_parity pins the indices)
+"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SNAPSHOTS = (0, 2, 17, 50, 100, 150)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def _masks_from_stash(stash, M, D=8, W=256):
+    """The ReLU patterns the kernel's backward uses, from its training stash: [M, W] bool per trunk layer + [M, W/2] for the
+    view branch, on the CPU.  (_stash_blocks_dev decodes the sign-bit words and asserts they equal (h > 0) of the stored
+    activations.)"""
+    import test_gpu_parity as G
+    blk = G._stash_blocks_dev(stash, M, D, W, True)
+    masks = [(blk[f"h{l}"] > 0).cpu() for l in range(D)] + [(blk["hv"] > 0).cpu()]
+    del blk
+    torch.cuda.empty_cache()
+    return masks
+
+
+def _adam_first_order_bound(dg, g, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8):
+    """|d w| allowed for a gradient difference of at most `dg` (scalar) per element, to first order in dg, through
+    w -= lr/bc1 * m' / (sqrt(v'/bc2) + eps) with m' = b1 m + (1-b1) g, v' = b2 v + (1-b2) g^2."""
+    bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
+    m1 = b1 * m + (1 - b1) * g
+    v1 = b2 * v + (1 - b2) * g * g
+    den = (v1 / bc2).sqrt() + eps
+    d_m = (1 - b1) * dg
+    d_v = (1 - b2) * 2 * g.abs() * dg + (1 - b2) * dg * dg
+    d_den = d_v / bc2 / (2 * (v1 / bc2).sqrt() + eps)
+    return lr / bc1 * (d_m / den + m1.abs() * d_den / (den * den))
+
+
+EPS32 = 2.0 ** -24      # unit round-off of fp32
+
+
+def _oracle_step(dtype, w0, names, rays, tgt, z_c, z_f, masks_c, masks_f, raw_k, ncfg, want_abs=False):
+    """The oracle's training step on the KERNEL'S BRANCH (module docstring) in `dtype`: O.query -> O.composite on both levels ->
+    mse + mse -> autograd.  raw_k = the kernel's (coarse, fine) raw outputs (fp32, CPU) for the tail-branch substitution.
+    -> dict(loss, grad flat [dtype], flips, tail, A) with A = sum over samples of |dZ| |h| per gradient element (float64 runs)."""
+    osd = [{k: v.to(dtype).clone().requires_grad_(True) for k, v in d.items()} for d in w0]
+    r = rays.to(dtype)
+    o_, d_, vd = r[:, 0:3], r[:, 3:6], r[:, 8:11]
+    tg = tgt.to(dtype)
+    recs, orig_lin = [], O._lin
+
+    def lin(sd, name, x):
+        y = orig_lin(sd, name, x)
+        rec = {"k": 0 if sd is osd[0] else 1, "name": name, "x": x.detach()}
+        y.register_hook(lambda g, rec=rec: rec.__setitem__("g", g.detach()))
+        recs.append(rec)
+        return y
+    if want_abs:
+        O._lin = lin
+    try:
+        flips, tail, loss = [], [], 0.0
+        for k, z, mk in ((0, z_c, masks_c), (1, z_f, masks_f)):
+            zz = z.to(dtype)
+            raw = O.query(osd[k], o_[:, None, :] + d_[:, None, :] * zz[:, :, None], vd, ncfg, mk, flips)
+            sk = raw_k[k][:, -1, 3].to(dtype)
+            so = raw[:, -1, 3]
+            sub = ((so > 0) != (sk > 0)) | ((so > 0) & (so < 1e-7)) | ((sk > 0) & (sk < 1e-7))
+            tail.append((int(sub.sum()), float(sk[sub].abs().max()) if bool(sub.any()) else 0.0))
+            sig = torch.cat([raw[:, :-1, 3], torch.where(sub, sk, so)[:, None]], 1)
+            raw = torch.cat([raw[..., :3], sig[..., None]], -1)
+            loss = loss + O.mse(O.composite(raw, zz, d_)[0], tg)
+        plist = [osd[k][n] for k in (0, 1) for n in names[k]]
+        grads = torch.autograd.grad(loss, plist, allow_unused=True)
+    finally:
+        O._lin = orig_lin
+    flat = torch.cat([(torch.zeros_like(p) if g is None else g).reshape(-1) for p, g in zip(plist, grads)])
+    out = {"loss": float(loss), "grad": flat, "flips": flips, "tail": tail}
+    if want_abs:
+        A = [{n: torch.zeros_like(osd[k][n]) for n in names[k]} for k in (0, 1)]
+        for rec in recs:
+            g, x = rec["g"].abs(), rec["x"].abs()
+            A[rec["k"]][rec["name"] + ".weight"] += g.t() @ x
+            A[rec["k"]][rec["name"] + ".bias"] += g.sum(0)
+        out["A"] = torch.cat([A[k][n].reshape(-1) for k in (0, 1) for n in names[k]])
+    return out
+
+
+def test_c2_teacher_forced_training_steps(dev, monkeypatch):
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import importlib
+    import argparse
+    import json
+    P = importlib.import_module("psnr_parity")
+    from consistentnerf_amd import ops, run_nerf as R
+    P.set_size("c2")
+    seed = 1                         # the seed whose free-running trajectory left the oracle's at step 2 in round 3
+    K, bank, target, _, _, sds = P.scene(seed)
+    args = argparse.Namespace(
+        multires=10, i_embed=0, use_viewdirs=True, multires_views=4, N_importance=128, netdepth=8, netwidth=256,
+        netdepth_fine=8, netwidth_fine=256, netchunk=1024 * 64, lrate=P.LRATE, basedir=tempfile.mkdtemp(), expname="tf",
+        ft_path=None, no_reload=True, perturb=1.0, N_samples=64, white_bkgd=False, raw_noise_std=0.0,
+        dataset_type="dtu", no_ndc=True, lindisp=False)
+    kw, _, _, grad_vars, opt = R.create_nerf(args)
+    nets = [kw["network_fn"], kw["network_fine"]]
+    for n_, sd in zip(nets, sds):
+        n_.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    rr_kw = {k: v for k, v in kw.items() if k not in ("near", "far", "ndc", "use_viewdirs")}
+    bank_d, target_d = bank.to(dev), target.to(dev)
+    names = [[n for n, _ in m.named_parameters()] for m in nets]
+    sizes = [[p.numel() for _, p in m.named_parameters()] for m in nets]
+    seen = {}
+    orig_pair = ops.mlp_backward_pair
+
+    def spy(*a, **k):
+        seen["args"] = a
+        return orig_pair(*a, **k)
+    monkeypatch.setattr(ops, "mlp_backward_pair", spy)
+
+    ncfg, rcfg = O.NetCfg(8, 256, output_ch=5), O.RenderCfg(64, 128, 1.0)
+    torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
+    report, regime_rays = [], 0
+    for i in range(max(SNAPSHOTS) + 1):
+        lo, hi = P.batch_bounds(i, bank.shape[0])
+        rb, tg = bank_d[lo:hi], target_d[lo:hi]
+        snap = i in SNAPSHOTS
+        if snap:
+            torch.cuda.synchronize()
+            w0 = [{k: v.detach().cpu().clone() for k, v in m.state_dict().items()} for m in nets]
+            m0, v0, p0 = opt.exp_avg.cpu().clone(), opt.exp_avg_sq.cpu().clone(), opt.flat_param.cpu().clone()
+            lr_i, step_i = opt.param_groups[0]["lr"], opt._step + 1
+        out = R.render_rays(rb, retraw=True, pytest=True, _debug=snap, **rr_kw)
+        opt.zero_grad()
+        loss = R.img2mse(out["rgb_map"], tg) + R.img2mse(out["rgb0"], tg)
+        seen.pop("args", None)
+        loss.backward()
+        if snap:
+            assert "args" in seen, "the step did not take the merged coarse+fine backward"
+            fs, fp, fg, fB, fS, fst, fgr, cs, cp, cg, cB, cS, cst, cgr = seen.pop("args")
+            g_hip = opt.flat_grad.cpu().clone()
+            masks_f = _masks_from_stash(fst, fB * fS)
+            masks_c = _masks_from_stash(cst, cB * cS)
+            del fst, cst, fg, cg
+            z_f, z_c = out["_z_vals"].cpu(), out["_z_coarse"].cpu()
+            raw_k = (out["_raw_coarse"].detach().cpu(), out["raw"].detach().cpu())
+        opt.step()
+        for g_ in opt.param_groups:                # R:784-788
+            g_["lr"] = P.LRATE * (0.1 ** (i / (P.LRATE_DECAY * 1000)))
+        if not snap:
+            continue
+        torch.cuda.synchronize()
+        loss_hip, p1_hip = float(loss), opt.flat_param.cpu().clone()
+        m1_hip, v1_hip = opt.exp_avg.cpu().clone(), opt.exp_avg_sq.cpu().clone()
+        rays_c, tgt_c = bank[lo:hi], target[lo:hi]
+        common = (w0, names, rays_c, tgt_c, z_c, z_f, masks_c, masks_f, raw_k, ncfg)
+        ex = _oracle_step(torch.float64, *common, want_abs=True)
+        r32 = _oracle_step(torch.float32, *common)
+        del masks_c, masks_f
+        with torch.no_grad():      # the oracle running free: its own depths, ReLU patterns, tail signs
+            osd = [{k: v.clone() for k, v in d.items()} for d in w0]
+            fr = O.render_rays_pytest(rays_c, osd[0], osd[1], ncfg, rcfg, retraw=False)
+            loss_free = float(O.mse(fr["rgb_map"], tgt_c) + O.mse(fr["rgb0"], tgt_c))
+            dz = (fr["z_vals"] - z_f).abs().flatten()
+        sig_last = raw_k[1][:, -1, 3]
+        row = {"step": i, "loss_hip": loss_hip, "loss_oracle_f32": r32["loss"], "loss_oracle_f64": ex["loss"],
+               "loss_oracle_free_running": loss_free,
+               "loss_rel_f32": abs(loss_hip - r32["loss"]) / abs(r32["loss"]),
+               "loss_rel_f64": abs(loss_hip - ex["loss"]) / abs(ex["loss"]),
+               "loss_rel_free": abs(loss_hip - loss_free) / abs(loss_free),
+               "z_fine_own_vs_kernel_median": float(dz.median()),
+               "z_fine_own_vs_kernel_p99": float(dz.kthvalue(int(dz.numel() * 0.99)).values),
+               "z_fine_own_vs_kernel_max": float(dz.max())}
+        tot_units = 4096 * (64 + 192) * (8 * 256 + 128)
+        for tag, res in (("f64", ex), ("f32", r32)):
+            row[f"relu_flips_{tag}"] = int(sum(n for n, _ in res["flips"]))
+            row[f"relu_flip_max_abs_z_{tag}"] = max(z for _, z in res["flips"])
+            row[f"tail_substitutions_{tag}"] = int(sum(n for n, _ in res["tail"]))
+            row[f"tail_substitution_max_abs_sigma_{tag}"] = max(z for _, z in res["tail"])
+        row["relu_flip_frac"] = max(row["relu_flips_f64"], row["relu_flips_f32"]) / tot_units
+        row["rays_sigma_last_lt_1e-2"] = int((sig_last.abs() < 1e-2).sum())
+        row["rays_sigma_last_lt_1e-3"] = int((sig_last.abs() < 1e-3).sum())
+        regime_rays += row["rays_sigma_last_lt_1e-2"]
+        # gradient, per tensor: round-off units of the sum (K) and the plain relative-to-max figure
+        g_ex, g_32, A = ex["grad"], r32["grad"], ex["A"]
+        off, per_tensor, dg_flat = 0, {}, torch.zeros_like(g_hip)
+        row["K_hip_worst"], row["K_ref32_worst"], row["grad_hip_vs_exact_rel_max_worst"] = 0.0, 0.0, 0.0
+        row["grad_ref32_vs_exact_rel_max_worst"], row["grad_hip_vs_ref32_rel_max_worst"], bad = 0.0, 0.0, []
+        for k in (0, 1):
+            for nme, n in zip(names[k], sizes[k]):
+                a, b, e, aa = g_hip[off:off + n].double(), g_32[off:off + n].double(), g_ex[off:off + n], A[off:off + n]
+                dg_flat[off:off + n] = float((a - b).abs().max())
+                off += n
+                scale = float(e.abs().max())
+                if scale == 0:
+                    assert float(a.abs().max()) == 0 and float(b.abs().max()) == 0
+                    continue
+                live = aa > 0
+                assert float((a - e).abs()[~live].max() if bool((~live).any()) else 0.0) == 0.0
+                k_hip = float(((a - e).abs()[live] / (EPS32 * aa[live])).max())
+                k_ref = float(((b - e).abs()[live] / (EPS32 * aa[live])).max())
+                d_ex, r_ex, d_32 = (float((a - e).abs().max()) / scale, float((b - e).abs().max()) / scale,
+                                    float((a - b).abs().max()) / scale)
+                full = ("coarse." if k == 0 else "fine.") + nme
+                per_tensor[full] = {"K_hip": k_hip, "K_ref32": k_ref, "hip_vs_exact": d_ex, "ref32_vs_exact": r_ex,
+                                    "hip_vs_ref32": d_32, "cancellation_A_over_max": float(aa.max()) / scale}
+                row["K_hip_worst"], row["K_ref32_worst"] = max(row["K_hip_worst"], k_hip), max(row["K_ref32_worst"], k_ref)
+                row["grad_hip_vs_exact_rel_max_worst"] = max(row["grad_hip_vs_exact_rel_max_worst"], d_ex)
+                row["grad_ref32_vs_exact_rel_max_worst"] = max(row["grad_ref32_vs_exact_rel_max_worst"], r_ex)
+                row["grad_hip_vs_ref32_rel_max_worst"] = max(row["grad_hip_vs_ref32_rel_max_worst"], d_32)
+                if k_hip > 16.0 or d_ex > 1e-4:
+                    bad.append((full, k_hip, d_ex))
+        assert off == g_hip.numel()
+        row["grad_bad"], row["grad_per_tensor"] = bad, per_tensor
+        # Adam on the SAME gradient (the kernel's): isolates cnerf_adam_step along the trajectory
+        p_same, m_same, v_same = p0.clone(), m0.clone(), v0.clone()
+        O.adam_step(p_same, g_hip, m_same, v_same, step_i, lr_i)
+        row["adam_same_grad_dw"] = float((p_same - p1_hip).abs().max())
+        row["adam_same_grad_dm_rel"] = float((m_same - m1_hip).abs().max() / m_same.abs().max())
+        row["adam_same_grad_dv_rel"] = float((v_same - v1_hip).abs().max() / v_same.abs().max())
+        # end to end: the reference-arithmetic gradient through the oracle's Adam
+        p_or, m_or, v_or = p0.clone(), m0.clone(), v0.clone()
+        O.adam_step(p_or, g_32, m_or, v_or, step_i, lr_i)
+        dw = (p_or - p1_hip).abs()
+        bound = 2e-6 + 2.0 * _adam_first_order_bound(dg_flat, g_32, m0, v0, step_i, lr_i)
+        row["dw_max"] = float(dw.max())
+        row["dw_frac_beyond_2e-6"] = float((dw > 2e-6).float().mean())
+        row["dw_beyond_conditioning_bound"] = int((dw > bound).sum())
+        report.append(row)
+        print("  " + " ".join(f"{k}={v:.3e}" if isinstance(v, float) else f"{k}={v}" for k, v in row.items()
+                              if not isinstance(v, dict)), flush=True)
+        del ex, r32, fr, osd
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "teacher_forced_c2.json"), "w") as f:
+        json.dump({"what": "tests/test_gpu_training_parity.py::test_c2_teacher_forced_training_steps", "seed": seed,
+                   "snapshots": list(SNAPSHOTS), "rows": report}, f, indent=1)
+    for row in report:
+        s_ = f"step {row['step']}: "
+        assert row["loss_rel_f32"] <= 1e-6 and row["loss_rel_f64"] <= 1e-6, s_ + "loss on the kernel's branch"
+        assert row["loss_rel_free"] <= 1e-5, s_ + "loss vs the free-running oracle"
+        assert (row["z_fine_own_vs_kernel_median"] <= 2e-6 * P.FAR and row["z_fine_own_vs_kernel_p99"] <= 2e-5 * P.FAR
+                and row["z_fine_own_vs_kernel_max"] <= 1e-3 * P.FAR), s_ + "fine depths"
+        for tag in ("f64", "f32"):
+            assert row[f"relu_flip_max_abs_z_{tag}"] < 1e-5, s_ + "ReLU pattern differs away from zero"
+            assert row[f"tail_substitution_max_abs_sigma_{tag}"] < 1e-5, s_ + "sigma_last branch differs away from zero"
+        assert row["relu_flip_frac"] < 1e-6, s_ + "too many ReLU pattern differences"
+        assert not row["grad_bad"], s_ + f"gradient [tensor, K_hip, hip-exact rel max]: {row['grad_bad']}"
+        assert row["adam_same_grad_dw"] <= 2e-7 + 2 * 6e-8 * 4.0, s_ + "Adam kernel on the same gradient"
+        assert row["adam_same_grad_dm_rel"] <= 1e-6 and row["adam_same_grad_dv_rel"] <= 1e-6, s_ + "Adam moments"
+        assert row["dw_beyond_conditioning_bound"] == 0 and row["dw_frac_beyond_2e-6"] <= 1e-3, s_ + "updated weights"
+    assert regime_rays > 0, "no snapshot had rays with |sigma_last| < 1e-2 (the R:281 regime the divergence probe blames)"
