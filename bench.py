@@ -62,6 +62,8 @@ for p in (ROOT, os.path.join(ROOT, "tests", "golden")):
 
 MAC_FWD, MAC_DGRAD, MAC_WGRAD = 593408, 557696, 593408   # per ray-sample, D=8/W=256/viewdirs
 PEAK_FP32_MFMA_TFLOPS = 157.3                              # MI355X_MICROARCH.md
+PEAK_BF16_MFMA_TFLOPS = 2500.0                             # dense bf16 (MI355X_MICROARCH.md; no sparsity)
+PEAK_BF16X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0           # fp32-equivalent FLOPs of a 3-plane split: 6 bf16 products each
 B_PER_GPU, NC, NF = 4096, 64, 128
 H_IMG, W_IMG, FOCAL, NEAR, FAR = 512, 640, 1446.0, 2.125, 4.67   # DTU-like
 
@@ -429,6 +431,28 @@ def pmc_rerun(per_rank, dom_kernel):
                       "dominant kernel: 2*FETCH_SIZE + WRITE_SIZE"}
 
 
+def bf16x3_leg(dev, rank, world, per_rank, f32_ms, steps=40, warmup=10):
+    """The SAME C2 training step with the opt-in "bf16x3" training arithmetic (consistentnerf_amd/run_nerf.py::training_precision):
+    the MLP GEMMs that have a bf16x3 kernel run on the bf16 matrix cores with three bf16 planes per operand (6 cross terms, fp32
+    accumulation: fp32-equivalent, the parity suite passes at the fp32 tolerances in this mode); everything else — and every GEMM
+    without such a kernel yet — is the exact-fp32 path.  A SECOND line: never `value`, never `dtype` of the headline."""
+    wl = Workload(dev, rank, world, precision="bf16x3")
+    wl.set_sharding(per_rank, strong=False)
+    el, loss, prof = wl.run(per_rank, steps, warmup)
+    table = per_kernel_table(prof, el * 1e3)
+    ms = el / steps * 1e3
+    n = per_rank * (NC + NC + NF)
+    tf = n * 2 * (MAC_FWD + MAC_DGRAD + MAC_WGRAD) / (ms * 1e-3) / 1e12
+    which = sorted({r["kernel"] for r in table})
+    return {"ms_per_step": round(ms, 4), "ray_samples_per_s": n / (ms * 1e-3), "speedup_vs_f32_step": round(f32_ms / ms, 4),
+            "steps": steps, "warmup": warmup, "final_loss": float(loss.item()),
+            "dtype": "bf16x3: 3 bf16 planes per operand, 6 cross terms, f32 accumulate (where a bf16x3 kernel exists), else f32",
+            "kernels_in_bf16x3": [k for k in which if k.endswith("_bf3")], "kernels_in_f32": [k for k in which if not k.endswith("_bf3")],
+            "roofline": {"bound": "mfma", "achieved": round(tf, 2), "unit": "TFLOP/s (fp32-equivalent, whole step)",
+                         "peak": round(PEAK_BF16X3_TFLOPS, 1), "frac": round(tf / PEAK_BF16X3_TFLOPS, 4),
+                         "basis": "2.5 PFLOP/s dense bf16 / 6 products per fp32-equivalent MAC", "kernels": table}}
+
+
 def route_of(table, steps):
     """Which autograd route the timed steps took (consistentnerf_amd/run_nerf.py): "merged" = ONE dgrad + ONE wgrad launch per step
     for both networks (the engine query `torch._C._will_engine_execute_node` is usable and CNERF_MERGE_BWD != 0), "plain" = one
@@ -567,15 +591,17 @@ def per_kernel_table(prof, elapsed_ms):
         k = kern.setdefault((nme, units), [0.0, 0])
         k[0] += e0.elapsed_time(e1)
         k[1] += 1
-    flops = {"mlp_fwd_train": 2 * MAC_FWD, "mlp_fwd": 2 * MAC_FWD, "mlp_dgrad": 2 * MAC_DGRAD, "mlp_wgrad": 2 * MAC_WGRAD}
+    flops = {"mlp_fwd_train": 2 * MAC_FWD, "mlp_fwd": 2 * MAC_FWD, "mlp_dgrad": 2 * MAC_DGRAD, "mlp_wgrad": 2 * MAC_WGRAD,
+             "mlp_fwd_train_bf3": 2 * MAC_FWD, "mlp_dgrad_bf3": 2 * MAC_DGRAD, "mlp_wgrad_bf3": 2 * MAC_WGRAD}
     table = []
     for (nme, units), (ms, n) in kern.items():
         if nme not in flops:
             continue
         avg_ms = ms / n
         tf = flops[nme] * units / (avg_ms * 1e-3) / 1e12
+        peak = PEAK_BF16X3_TFLOPS if nme.endswith("_bf3") else PEAK_FP32_MFMA_TFLOPS
         table.append({"kernel": nme, "points": units, "launches": n, "avg_ms": round(avg_ms, 4), "tflops": round(tf, 2),
-                      "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4), "share_of_step": round(ms / elapsed_ms, 4)})
+                      "frac": round(tf / peak, 4), "share_of_step": round(ms / elapsed_ms, 4)})
     table.sort(key=lambda r: -r["avg_ms"] * r["launches"])
     return table
 
@@ -583,7 +609,7 @@ def per_kernel_table(prof, elapsed_ms):
 class Workload:
     """The C2 training step on this rank's shard: model, optimizer, ray bank, exchange."""
 
-    def __init__(self, dev, rank, world, seed=1234):
+    def __init__(self, dev, rank, world, seed=1234, precision="fp32"):
         import tempfile
         import torch.distributed as dist
         from consistentnerf_amd import distributed as D, run_nerf as R
@@ -592,6 +618,8 @@ class Workload:
         with tempfile.TemporaryDirectory() as tmp:
             self.kw, _, _, self.grad_vars, self.opt = R.create_nerf(make_args(tmp))
         self.kw.update(near=NEAR, far=FAR)
+        for k_ in ("network_fn", "network_fine"):     # (the headline line is "fp32" = exact fp32 MFMA; "bf16x3" = the opt-in leg)
+            self.kw[k_].training_precision = precision
         self.K, self.bank, self.targets = build_ray_bank(dev)
         torch.manual_seed(99 + rank)                  # per-rank jitter streams (RegNeRF/train.py:364-365 precedent)
         # the step's gradient exchange: per-network slices of the flat fp32 gradient, all-reduced (RCCL) as _MlpFn.backward
@@ -952,6 +980,12 @@ def main():
                                              "on this one GPU (no exchange: world 1)")
             del wl, graphed
             torch.cuda.empty_cache()
+            if per_rank == B_PER_GPU:
+                try:
+                    extra["c2_bf16x3"] = bf16x3_leg(dev, rank, world, per_rank, elapsed / a.steps * 1e3)
+                except Exception as e:  # noqa: BLE001 — the headline line must survive a failure of the opt-in leg
+                    extra["c2_bf16x3"] = {"error": f"{type(e).__name__}: {e}"}
+                torch.cuda.empty_cache()
             extra["c5"] = c5_leg(dev)
             extra["c3"] = c3_leg(dev)
             extra["hbm_kernels"] = hbm_kernels(dev)

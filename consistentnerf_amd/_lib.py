@@ -69,6 +69,9 @@ SIGNATURES = {
     "cnerf_packed_bf_bytes": (_i64, [_NetP, _i]),
     "cnerf_pack_weights_bf": (_i, [_NetP, _PtrsP, _i, _vp, _vp]),
     "cnerf_mlp_fwd_bf": (_i, [_NetP, _vp, _i, _vp, _vp, _i, _vp, _vp, _i64, _i, _vp, _vp]),
+    "cnerf_mlp_fwd_bf_train": (_i, [_NetP, _vp, _vp, _vp, _i, _vp, _vp, _i64, _i, _vp, _vp, _vp]),
+    "cnerf_mlp_dgrad_bf": (_i, [_NetP, _vp, _vp, _i64, _i, _vp, _vp, _vp]),
+    "cnerf_mlp_dgrad_bf_pair": (_i, [_NetP, _vp, _vp, _i64, _i, _vp, _vp, _NetP, _vp, _vp, _i64, _i, _vp, _vp, _vp]),
     "cnerf_mlp_bwd_ws_floats": (_i64, [_NetP, _i64]),
     "cnerf_mlp_bwd": (_i, [_NetP, _vp, _vp, _i64, _i, _vp, _vp, _PtrsP, _i, _vp]),
     "cnerf_mlp_bwd_pair": (_i, [_NetP, _vp, _vp, _i64, _i, _vp, _vp, _PtrsP, _NetP, _vp, _vp, _i64, _i, _vp, _vp, _PtrsP, _i, _vp]),
@@ -76,6 +79,8 @@ SIGNATURES = {
     "cnerf_mlp_wgrad_pair": (_i, [_NetP, _i64, _i, _vp, _vp, _PtrsP, _NetP, _i64, _i, _vp, _vp, _PtrsP, _i, _vp]),
     "cnerf_mlp_dgrad": (_i, [_NetP, _vp, _vp, _i64, _i, _vp, _vp, _vp]),
     "cnerf_mlp_wgrad": (_i, [_NetP, _i64, _i, _vp, _vp, _PtrsP, _i, _vp]),
+    "cnerf_mlp_wgrad_bf": (_i, [_NetP, _i64, _i, _vp, _vp, _PtrsP, _i, _vp]),
+    "cnerf_mlp_wgrad_bf_pair": (_i, [_NetP, _i64, _i, _vp, _vp, _PtrsP, _NetP, _i64, _i, _vp, _vp, _PtrsP, _i, _vp]),
     "cnerf_composite_fwd": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cnerf_composite_bwd": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cnerf_sample_pdf": (_i, [_vp, _vp, _vp, _i64, _i64, _i, _i, _vp, _vp, _vp]),

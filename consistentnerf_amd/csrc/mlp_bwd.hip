@@ -11,10 +11,10 @@
 #include "timing.hpp"
 
 int cn_wgrad_launch(const NetGeom& g, const float* stash, const float* G, int64_t M, int64_t Mp, float* partials,
-                    int nsplit, const cnerf_ptrs* grads, int accumulate, hipStream_t st);
+                    int nsplit, const cnerf_ptrs* grads, int accumulate, hipStream_t st, int bf3 = 0);
 int cn_wgrad_launch_n(int n, const NetGeom* const* g, const float* const* stash, const float* const* G, const int64_t* Mp,
                       float* const* partials, const int* nsplit, const cnerf_ptrs* const* grads, int accumulate,
-                      hipStream_t st);
+                      hipStream_t st, int bf3 = 0);
 int cn_wgrad_nsplit(int64_t Mp);
 int64_t cn_param_floats(const NetGeom& g);
 
@@ -240,8 +240,19 @@ extern "C" int cnerf_mlp_dgrad(const cnerf_net* net, const float* packed, const 
   return dispatch(a, 1, cn_stream(stream));
 }
 
+static int wgrad_one(const cnerf_net* net, int64_t B, int S, const float* stash, float* workspace, const cnerf_ptrs* grads,
+                     int accumulate, void* stream, int bf3);
 extern "C" int cnerf_mlp_wgrad(const cnerf_net* net, int64_t B, int S, const float* stash, float* workspace,
                                const cnerf_ptrs* grads, int accumulate, void* stream) {
+  return wgrad_one(net, B, S, stash, workspace, grads, accumulate, stream, 0);
+}
+// OPT-IN bf16x3 weight gradients (second bench line only): the wide GEMMs on the bf16 matrix cores at three planes per operand
+extern "C" int cnerf_mlp_wgrad_bf(const cnerf_net* net, int64_t B, int S, const float* stash, float* workspace,
+                                  const cnerf_ptrs* grads, int accumulate, void* stream) {
+  return wgrad_one(net, B, S, stash, workspace, grads, accumulate, stream, 1);
+}
+static int wgrad_one(const cnerf_net* net, int64_t B, int S, const float* stash, float* workspace, const cnerf_ptrs* grads,
+                     int accumulate, void* stream, int bf3) {
   NetGeom g;
   int rc = cn_make_geom(net, &g);
   if (rc) return rc;
@@ -250,7 +261,7 @@ extern "C" int cnerf_mlp_wgrad(const cnerf_net* net, int64_t B, int S, const flo
   const int64_t M = B * S, Mp = cn_round_up(M, 32);
   const int nsplit = cn_wgrad_nsplit(Mp);
   float* partials = workspace + (int64_t)g.g_rows * Mp;
-  return cn_wgrad_launch(g, stash, workspace, M, Mp, partials, nsplit, grads, accumulate, cn_stream(stream));
+  return cn_wgrad_launch(g, stash, workspace, M, Mp, partials, nsplit, grads, accumulate, cn_stream(stream), bf3);
 }
 
 extern "C" int cnerf_mlp_bwd(const cnerf_net* net, const float* packed, const float* d_raw, int64_t B, int S,
@@ -293,14 +304,28 @@ extern "C" int cnerf_mlp_dgrad_pair(const cnerf_net* net0, const float* packed0,
   return cnerf_mlp_dgrad(net1, packed1, d_raw1, B1, S1, stash1, workspace1, stream);
 }
 
+static int wgrad_two(const cnerf_net* net0, int64_t B0, int S0, const float* stash0, float* workspace0, const cnerf_ptrs* grads0,
+                     const cnerf_net* net1, int64_t B1, int S1, const float* stash1, float* workspace1,
+                     const cnerf_ptrs* grads1, int accumulate, void* stream, int bf3);
 extern "C" int cnerf_mlp_wgrad_pair(const cnerf_net* net0, int64_t B0, int S0, const float* stash0, float* workspace0,
                                     const cnerf_ptrs* grads0, const cnerf_net* net1, int64_t B1, int S1,
                                     const float* stash1, float* workspace1, const cnerf_ptrs* grads1, int accumulate,
                                     void* stream) {
+  return wgrad_two(net0, B0, S0, stash0, workspace0, grads0, net1, B1, S1, stash1, workspace1, grads1, accumulate, stream, 0);
+}
+extern "C" int cnerf_mlp_wgrad_bf_pair(const cnerf_net* net0, int64_t B0, int S0, const float* stash0, float* workspace0,
+                                       const cnerf_ptrs* grads0, const cnerf_net* net1, int64_t B1, int S1,
+                                       const float* stash1, float* workspace1, const cnerf_ptrs* grads1, int accumulate,
+                                       void* stream) {
+  return wgrad_two(net0, B0, S0, stash0, workspace0, grads0, net1, B1, S1, stash1, workspace1, grads1, accumulate, stream, 1);
+}
+static int wgrad_two(const cnerf_net* net0, int64_t B0, int S0, const float* stash0, float* workspace0, const cnerf_ptrs* grads0,
+                     const cnerf_net* net1, int64_t B1, int S1, const float* stash1, float* workspace1,
+                     const cnerf_ptrs* grads1, int accumulate, void* stream, int bf3) {
   if (!grads0 || !grads1 || !stash0 || !stash1 || !workspace0 || !workspace1 || B0 < 0 || B1 < 0 || S0 <= 0 || S1 <= 0)
     return CNERF_E_ARG;
-  if (B0 == 0) return cnerf_mlp_wgrad(net1, B1, S1, stash1, workspace1, grads1, accumulate, stream);
-  if (B1 == 0) return cnerf_mlp_wgrad(net0, B0, S0, stash0, workspace0, grads0, accumulate, stream);
+  if (B0 == 0) return wgrad_one(net1, B1, S1, stash1, workspace1, grads1, accumulate, stream, bf3);
+  if (B1 == 0) return wgrad_one(net0, B0, S0, stash0, workspace0, grads0, accumulate, stream, bf3);
   for (int i = 0; i < CNERF_MAX_TENSORS; ++i)
     if (grads0->p[i] && grads0->p[i] == grads1->p[i]) return CNERF_E_ARG;
   NetGeom g0, g1;
@@ -315,7 +340,7 @@ extern "C" int cnerf_mlp_wgrad_pair(const cnerf_net* net0, int64_t B0, int S0, c
   const int ns[2] = {cn_wgrad_nsplit(Mp0), cn_wgrad_nsplit(Mp1)};
   float* parts[2] = {workspace0 + (int64_t)g0.g_rows * Mp0, workspace1 + (int64_t)g1.g_rows * Mp1};
   const cnerf_ptrs* grs[2] = {grads0, grads1};
-  return cn_wgrad_launch_n(2, gs, stashes, Gs, Mps, parts, ns, grs, accumulate, cn_stream(stream));
+  return cn_wgrad_launch_n(2, gs, stashes, Gs, Mps, parts, ns, grs, accumulate, cn_stream(stream), bf3);
 }
 
 extern "C" int cnerf_mlp_bwd_pair(const cnerf_net* net0, const float* packed0, const float* d_raw0, int64_t B0, int S0,

@@ -216,6 +216,12 @@ __device__ __forceinline__ void gemm_reg3(f32x16 (&Q)[NTO], const f32x16 (&X)[NT
 // Tile = 32 points x 64 floats, 16-byte chunks XOR-swizzled with (m & 15): conflict-free b128 for the wave.
 __device__ __forceinline__ int enc_off(int m, int c) { return m * 64 + ((c ^ (m & 15)) << 2); }
 
+// Copy this lane's chunks of an encoding tile to its stash block (lane (m, hh) owns columns 8c + 4hh .. +3)
+__device__ __forceinline__ void stash_tile(const float* T, int chp, rsrc_t srs, int svo, int col, int m, int hh) {
+  for (int c = 0; c < chp / 8; ++c)
+    buf_store(srs, svo, tm_col(col) + c * 1024, *reinterpret_cast<const f32x4*>(T + enc_off(m, 2 * c + hh)));
+}
+
 // Q[t] (+)= sum_k Panel[k-group][32t + i] * T[m][k] over KG (even, >= 4) groups of 8 k's read from tile T; the chunk
 // of group kg+1 is read behind the first MFMA of group kg.  The first four groups are peeled (INIT, and so that the
 // loop carries no special cases).

@@ -34,12 +34,6 @@ struct FwdArgs {
   RayGenDev cam;      // cam.on: the rays are those of a camera, generated here (rays == nullptr)
 };
 
-// Copy this lane's chunks of an encoding tile to its stash block (lane (m, hh) owns columns 8c + 4hh .. +3)
-__device__ __forceinline__ void stash_tile(const float* T, int chp, rsrc_t srs, int svo, int col, int m, int hh) {
-  for (int c = 0; c < chp / 8; ++c)
-    buf_store(srs, svo, tm_col(col) + c * 1024, *reinterpret_cast<const f32x4*>(T + enc_off(m, 2 * c + hh)));
-}
-
 #define CN_CONST __attribute__((address_space(4)))
 
 template <int NT, bool VD, bool TRAIN>

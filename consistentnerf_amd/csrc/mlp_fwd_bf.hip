@@ -22,32 +22,7 @@
 #include "mlp_common.hpp"
 #include "raygen.hpp"
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-struct BfGeom {                 // byte offsets into the packed buffer of cnerf_pack_weights_bf
-  int64_t p_l0, p_trunk[16], p_skip, p_feat, p_views, p_viewsd;   // bf16 panels [K/16][N/32][NP][32 lanes][2][8]
-  int64_t b_trunk[16], b_feat, b_views, b_alpha, b_rgb;           // fp32 biases
-  int64_t v_alpha, v_rgb;                                         // fp32 head weights [W], [3][W/2]
-  int64_t total;
-};
-
-static int make_bf_geom(const NetGeom& g, int NP, BfGeom* b) {
-  if (NP < 1 || NP > 3 || !g.viewdirs || (g.NT != 4 && g.NT != 8) || g.in_chp % 16 || g.dir_chp % 16) return CNERF_E_UNSUPPORTED;
-  int64_t off = 0;
-  auto panel = [&](int K, int N) { const int64_t o = off; off += (int64_t)(K / 16) * (N / 32) * NP * 1024; return o; };
-  auto vec = [&](int n) { const int64_t o = off; off += cn_round_up((int64_t)n * 4, 64); return o; };
-  b->p_l0 = panel(g.in_chp, g.W);
-  for (int l = 1; l < g.D; ++l) b->p_trunk[l] = panel(g.W, g.W);
-  b->p_skip = g.skip >= 0 ? panel(g.in_chp, g.W) : -1;
-  b->p_feat = panel(g.W, g.W);
-  b->p_views = panel(g.W, g.W);            // N = W/2 real rows; every K-step is padded to NT tiles (uniform K-step size:
-  b->p_viewsd = panel(g.dir_chp, g.W);     // the LDS ring of the shared-panel kernel moves whole K-steps)
-  for (int l = 0; l < g.D; ++l) b->b_trunk[l] = vec(g.W);
-  b->b_feat = vec(g.W); b->b_views = vec(g.Wh); b->b_alpha = vec(1); b->b_rgb = vec(3);
-  b->v_alpha = vec(g.W); b->v_rgb = vec(3 * g.Wh);
-  b->total = off;
-  return CNERF_OK;
-}
+#include "mlp_bf_common.hpp"
 
 namespace {
 
@@ -63,10 +38,12 @@ struct BfPackJob {
   int NTM;                 // 32-row tiles per K-step in memory (>= N/32)
   int Kp, kind;            // contracted width padded to 16; kind 0: k order of an LDS tile (16 s + 8 hh + e),
                            //                                kind 1: k order of C-layout registers (see the header)
+                           //                                kind 2: as 1 for the TRANSPOSED map (dgrad): panel row r = source
+                           //                                        column col0 + r, contracted index k = source row
   int64_t dst;             // byte offset
 };
 struct BfCopyJob { const float* src; int n; int64_t dst; };
-struct BfPackArgs { BfPackJob job[24]; BfCopyJob cp[24]; int njobs, ncopies, NP; unsigned char* out; };
+struct BfPackArgs { BfPackJob job[48]; BfCopyJob cp[24]; int njobs, ncopies, NP; unsigned char* out; };
 
 __global__ void pack_bf_k(BfPackArgs a_by_value) {
   (void)a_by_value;   // job table read in place from the kernarg segment (a by-value copy indexed by blockIdx.y lives in scratch)
@@ -85,7 +62,8 @@ __global__ void pack_bf_k(BfPackArgs a_by_value) {
     const int to = (int)((idx >> 9) % NTO), s = (int)((idx >> 9) / NTO);
     const int k = j.kind == 0 ? 16 * s + 8 * hh + e : 32 * (s >> 1) + 16 * (s & 1) + 8 * (e >> 2) + 4 * hh + (e & 3);
     const int row = 32 * to + i;
-    float w = (k < j.K && row < j.N) ? j.src[(int64_t)row * j.ld + j.col0 + k] : 0.f;
+    float w = 0.f;
+    if (k < j.K && row < j.N) w = j.kind == 2 ? j.src[(int64_t)k * j.ld + j.col0 + row] : j.src[(int64_t)row * j.ld + j.col0 + k];
     unsigned short* dst = reinterpret_cast<unsigned short*>(a.out + j.dst);
     for (int p = 0; p < NP; ++p) {
       const unsigned h = bf16_rne(w);
@@ -105,57 +83,10 @@ struct BfArgs {
   const float* dirs;
   const float* z;
   float* raw;
+  float* stash;     // training stash of cnerf_mlp_fwd (same layout: the fp32 dgrad / wgrad kernels consume it) or nullptr
   int64_t M;
   int S, rs;
   RayGenDev cam;
-};
-
-#define CN_CONST __attribute__((address_space(4)))
-
-// v_cvt_pk_bf16_f32 (RNE).  Through the compiler, NOT inline asm: a VALU write needs two wait states before an MFMA reads
-// the register on gfx950, and the hazard recognizer only inserts them (s_nop 1) for instructions it knows to be VALU.  As
-// asm the conversion could sit one instruction in front of the MFMA that consumes it: that made the shared-panel kernel
-// wrong at W = 128 / one plane (tile 0 of every encoding GEMM).  scripts/isa_hazards.py checks the ISA for this pattern.
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
-}
-
-// One register pair -> one dword of every plane (element 2q in the low half, 2q+1 in the high half).
-template <int NP, bool RELU>
-__device__ __forceinline__ void split_pair(float x0, float x1, u32x4 (&b)[NP], int q) {
-  if (RELU) {   // one v_max each (fmaxf also emits a canonicalising v_max per operand: every VALU slot counts here)
-    asm("v_max_f32 %0, 0, %1" : "=v"(x0) : "v"(x0));
-    asm("v_max_f32 %0, 0, %1" : "=v"(x1) : "v"(x1));
-  }
-  unsigned h = cvt_pk_bf16(x0, x1);
-  b[0][q] = h;
-#pragma unroll
-  for (int p = 1; p < NP; ++p) {
-    x0 = x0 - __uint_as_float(h << 16);
-    x1 = x1 - __uint_as_float(h & 0xffff0000u);
-    h = cvt_pk_bf16(x0, x1);
-    b[p][q] = h;
-  }
-}
-
-__device__ __forceinline__ f32x16 mfma_bf(const u32x4& a, const u32x4& b, const f32x16& c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-
-// the NP (NP + 1) / 2 cross terms w_i x_j with i + j < NP, smallest first
-template <int NP>
-__device__ __forceinline__ void products(f32x16& q, const u32x4 (&a)[NP], const u32x4 (&b)[NP]) {
-#pragma unroll
-  for (int sum = NP - 1; sum >= 0; --sum)
-#pragma unroll
-    for (int i = 0; i <= sum; ++i) q = mfma_bf(a[i], b[sum - i], q);
-}
-
-struct BfPanel {
-  rsrc_t rs;
-  int lane;      // (m * 2 + hh) * 16: this lane's 16 bytes inside a 1 KiB piece
 };
 
 template <int NTO, int NP, int NTM>
@@ -168,18 +99,6 @@ __device__ __forceinline__ void a_fetch(u32x4 (&A)[NTO][NP], const BfPanel& P, i
 }
 
 // accumulators <- bias (fp32): register r of tile t is feature 32t + 8(r>>2) + 4hh + (r&3)
-template <int NTO>
-__device__ __forceinline__ void bias_init(f32x16 (&Q)[NTO], const BfPanel& P, int boff, int hh) {
-#pragma unroll
-  for (int t = 0; t < NTO; ++t)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 v = buf_load(P.rs, hh * 16, boff + (32 * t + 8 * q) * 4);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) Q[t][4 * q + j] = v[j];
-    }
-}
-
 template <int NP>
 struct ASets { static constexpr int N = NP == 1 ? 4 : (NP == 2 ? 2 : 1); };
 
@@ -362,152 +281,10 @@ __global__ __launch_bounds__(64) void mlp_fwd_bf_k(BfArgs args_by_value) {
   if (hh == 0) buf_store(ors, m * 16, 0, f32x4{o[0] + brgb[0], o[1] + brgb[1], o[2] + brgb[2], sig});
 }
 
-// ======================================================================================================================
-// Shared-panel variant: the four waves of a workgroup (one per SIMD, 32 points each) consume the SAME weight stream, so
-// it crosses L2 -> CU once per 128 points instead of once per 32: the per-wave kernel above saturates at ~9.3 B/clk/wave
-// (37 B/clk/CU) of panel traffic whatever the plane count — it is L2-stream-bound, MFMA-busy 25 / 43 / 65 % at 1 / 2 / 3
-// planes.  Here a K-step of a panel (NT x NP pieces of 1 KiB) is moved HBM/L2 -> LDS by LDS-DMA (`buffer_load ... lds`, each
-// wave a quarter of the pieces) into a 4-slot ring two K-steps ahead of its use, published by ONE barrier per K-step, and
-// every wave reads its A operands from the ring with ds_read_b128 (64 lanes x 16 B contiguous: conflict-free).
-//   iteration s:  DMA(K-step s+2 -> slot (s+2)&3)   [that slot was read last in iteration s-2: two barriers ago]
-//                 MFMAs of K-step s from slot s&3
-//                 s_waitcnt vmcnt(own pieces of s+2 may stay in flight) ; barrier          -> K-step s+1 is published
-// Every GEMM has a multiple of 4 K-steps (the last one excepted), so each starts at slot 0 and hands the ring over to the
-// next panel (whose first two K-steps it prefetches) without draining it.
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ void dma1k(const i32x4& rs, unsigned lds_addr, int voff, int soff) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-               :
-               : "s"(__builtin_amdgcn_readfirstlane((int)lds_addr)), "v"(voff), "s"(rs),
-                 "s"(__builtin_amdgcn_readfirstlane(soff))
-               : "memory");
-}
-
-template <int NT, int NP>
-struct Ring {
-  static constexpr int PIECES = NT * NP;            // 1 KiB pieces per K-step
-  static constexpr int SLOT = PIECES * 1024;        // bytes per ring slot
-  static constexpr int PW = PIECES / 4;             // DMA instructions per wave and K-step
-  i32x4 rs;                                         // the packed buffer behind a buffer resource (DMA source)
-  unsigned lds0;                                    // LDS byte address of slot 0 (wave-uniform)
-  const unsigned char* ring;                        // the same, as a pointer for the ds_reads
-  int w;                                            // wave index in the workgroup (scalar)
-  int lane16;                                       // lane * 16: the DMA copies a piece lane-linearly
-  int rd16;                                         // (m * 2 + hh) * 16: this lane's A-operand bytes inside a piece
-  // this wave's quarter of K-step `s` of the panel at byte offset `poff` -> slot
-  __device__ __forceinline__ void dma(int poff, int s, int slot) const {
-#pragma unroll
-    for (int j = 0; j < PW; ++j) {
-      const int i = w + 4 * j;
-      dma1k(rs, lds0 + (unsigned)(slot * SLOT + i * 1024), lane16, poff + (s * PIECES + i) * 1024);
-    }
-  }
-  // piece j (0..PW-1) of this wave's quarter: dealt out one per tile by the register-operand GEMM (a VMEM instruction
-  // holds the in-order wave until the address unit takes it: four in a row cost 16-22 % of the kernel, measured)
-  __device__ __forceinline__ void dma_piece(int poff, int s, int slot, int j) const {
-    const int i = w + 4 * j;
-    dma1k(rs, lds0 + (unsigned)(slot * SLOT + i * 1024), lane16, poff + (s * PIECES + i) * 1024);
-  }
-  __device__ __forceinline__ u32x4 a(int slot, int t, int p) const {
-    return *reinterpret_cast<const u32x4*>(ring + slot * SLOT + (t * NP + p) * 1024 + rd16);
-  }
-  template <int OUTSTANDING>
-  __device__ __forceinline__ void publish() const {   // own DMA pieces older than the newest OUTSTANDING have landed
-    static_assert(OUTSTANDING >= 0 && OUTSTANDING < 64, "vmcnt range");
-    // nothing is scheduled across the publish: the ring's only writer is the DMA asm, which the machine scheduler does not
-    // see as a store to the LDS the next K-step's ds_reads load from
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_waitcnt(0x0f70 | (OUTSTANDING & 15) | ((OUTSTANDING >> 4) << 14));   // vmcnt only (gfx9 encoding)
-    __syncthreads();
-    __builtin_amdgcn_sched_barrier(0);
-  }
-};
-
-// Q[t] += Panel . relu?(X), panel K-steps through the ring.  On entry K-steps 0 and 1 are in flight / published (K-step 0
-// published); on exit the same holds for the NEXT panel (poff_next; -1: none follows).
-template <int NTI, int NTO, int NT, int NP, bool RELU>
-__device__ __forceinline__ void gemm_ring_reg(f32x16 (&Q)[NTO], const f32x16 (&X)[NTI], const Ring<NT, NP>& R, int poff,
-                                              int poff_next) {
-  constexpr int KS = 2 * NTI, PW = Ring<NT, NP>::PW;
-  static_assert(KS % 4 == 0, "ring slot continuity");
-  u32x4 bc[NP], bn[NP];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) split_pair<NP, RELU>(X[0][2 * q], X[0][2 * q + 1], bc, q);
-#pragma unroll
-  for (int s = 0; s < KS; ++s) {
-    u32x4 A[3][NP];       // A operands run two tiles ahead of the MFMAs that consume them (LDS latency)
-#pragma unroll
-    for (int p = 0; p < NP; ++p) A[0][p] = R.a(s & 3, 0, p);
-    if (NTO > 1) {
-#pragma unroll
-      for (int p = 0; p < NP; ++p) A[1][p] = R.a(s & 3, 1, p);
-    }
-#pragma unroll
-    for (int t = 0; t < NTO; ++t) {
-      if (t + 2 < NTO) {
-#pragma unroll
-        for (int p = 0; p < NP; ++p) A[(t + 2) % 3][p] = R.a(s & 3, t + 2, p);
-      }
-      products<NP>(Q[t], A[t % 3], bc);
-      // the DMA of K-step s+2, one piece behind each tile's MFMAs (all of them in front would delay the first LDS reads)
-#pragma unroll
-      for (int j = t; j < PW; j += NTO) {
-        if (s + 2 < KS) R.dma_piece(poff, s + 2, (s + 2) & 3, j);
-        else if (poff_next >= 0) R.dma_piece(poff_next, s + 2 - KS, (s + 2) & 3, j);
-      }
-      if (s + 1 < KS && t < 4) {
-        const int sn = s + 1;
-        split_pair<NP, RELU>(X[sn >> 1][8 * (sn & 1) + 2 * t], X[sn >> 1][8 * (sn & 1) + 2 * t + 1], bn, t);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (NTO < 4 && s + 1 < KS) {
-#pragma unroll
-      for (int q = NTO; q < 4; ++q) {
-        const int sn = s + 1;
-        split_pair<NP, RELU>(X[sn >> 1][8 * (sn & 1) + 2 * q], X[sn >> 1][8 * (sn & 1) + 2 * q + 1], bn, q);
-      }
-    }
-#pragma unroll
-    for (int p = 0; p < NP; ++p) bc[p] = bn[p];
-    if (s + 2 < KS) R.template publish<PW>();
-    else if (poff_next >= 0) R.template publish<PW>();
-    else R.template publish<0>();
-  }
-}
-
-// the same with the B operand read from the fp32 encoding tile T (KS K-steps of 16 channels: 16 s + 8 hh + e)
-template <int KS, int NTO, int NT, int NP>
-__device__ __forceinline__ void gemm_ring_lds(f32x16 (&Q)[NTO], const float* T, const Ring<NT, NP>& R, int poff, int poff_next,
-                                              int m, int hh) {
-  constexpr int PW = Ring<NT, NP>::PW;
-#pragma unroll
-  for (int s = 0; s < KS; ++s) {
-    if (s + 2 < KS) R.dma(poff, s + 2, (s + 2) & 3);
-    else if (poff_next >= 0) R.dma(poff_next, s + 2 - KS, (s + 2) & 3);
-    const f32x4 c0 = *reinterpret_cast<const f32x4*>(T + enc_off(m, 4 * s + 2 * hh));
-    const f32x4 c1 = *reinterpret_cast<const f32x4*>(T + enc_off(m, 4 * s + 2 * hh + 1));
-    u32x4 b[NP];
-    split_pair<NP, false>(c0[0], c0[1], b, 0);
-    split_pair<NP, false>(c0[2], c0[3], b, 1);
-    split_pair<NP, false>(c1[0], c1[1], b, 2);
-    split_pair<NP, false>(c1[2], c1[3], b, 3);
-#pragma unroll
-    for (int t = 0; t < NTO; ++t) {
-      u32x4 A[NP];
-#pragma unroll
-      for (int p = 0; p < NP; ++p) A[p] = R.a(s & 3, t, p);
-      products<NP>(Q[t], A, b);
-    }
-    if (s + 2 < KS || poff_next >= 0) R.template publish<PW>();
-    else R.template publish<0>();
-  }
-}
-
-template <int NT, int NP>
+template <int NT, int NP, bool TRAIN>
 __global__ __launch_bounds__(256) void mlp_fwd_bfs_k(BfArgs args_by_value) {
   constexpr int W = NT * 32, NTH = NT / 2;
+  constexpr int MD = (NT + 1) / 2, MDV = (NTH + 1) / 2;
   (void)args_by_value;
   const CN_CONST BfArgs& a = *(const CN_CONST BfArgs*)__builtin_amdgcn_kernarg_segment_ptr();
   const CN_CONST NetGeom& g = a.g;
@@ -525,6 +302,12 @@ __global__ __launch_bounds__(256) void mlp_fwd_bfs_k(BfArgs args_by_value) {
   const int64_t pc = p < a.M ? p : a.M - 1;
   const int64_t ray = pc / a.S;
   const BfPanel P{make_rsrc(a.pk, (unsigned)bg.total), (m * 2 + hh) * 16};
+  // training: this WAVE's stash tile row (32 points; tile-major, mlp_common.hpp).  Lanes of padding points — and whole waves
+  // past the last point, whose resource is empty — address out of range: the hardware drops their stores.
+  const rsrc_t srs = make_rsrc(TRAIN && nvalid > 0 ? a.stash + p0 * g.s_rows : nullptr,
+                               TRAIN && nvalid > 0 ? (unsigned)(32 * g.s_rows * 4) : 0u);
+  const int svo = p < a.M ? m * 32 + hh * 16 : TM_OOB;
+  const int smo = p < a.M ? m * 32 + hh * MD * 4 : TM_OOB;
   Ring<NT, NP> R;
   {
     const unsigned long long ba = (unsigned long long)a.pk;
@@ -559,8 +342,13 @@ __global__ __launch_bounds__(256) void mlp_fwd_bfs_k(BfArgs args_by_value) {
   }
   encode(Tx, x, g.L, g.in_ch, g.in_chp, m, hh, nullptr);
   encode(Td, v, g.Ld, g.dir_ch, g.dir_chp, m, hh, nullptr);
+  if (TRAIN) {
+    stash_tile(Tx, g.in_chp, srs, svo, g.s_enc, m, hh);
+    stash_tile(Td, g.dir_chp, srs, svo, g.s_denc, m, hh);
+  }
 
   f32x16 X[NT], Y[NT];
+  unsigned bits[MD];
   bias_init<NT>(Y, P, (int)bg.b_trunk[0], hh);
   pin<NT>(Y);                                  // (the bias loads are older than nothing the ring waits for below)
   R.template publish<Ring<NT, NP>::PW>();      // K-step 0 of layer 0 has landed everywhere
@@ -568,11 +356,18 @@ __global__ __launch_bounds__(256) void mlp_fwd_bfs_k(BfArgs args_by_value) {
   pin<NT>(Y);
   float sig = 0.f;
   auto layer = [&](f32x16 (&In)[NT], f32x16 (&Out)[NT], int l) __attribute__((always_inline)) {
+    if (TRAIN) {
+      // h_{l-1} = relu(In) in place + its sign bits (what the dgrad kernel masks with), exactly as mlp_fwd_k does
+      relu_bits<NT, true>(In, bits);
+      store_bits<MD>(srs, smo, tm_col(g.s_mask + g.s_mb[l - 1]), bits);
+    }
     if (l == g.D) {
+      if (!TRAIN) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) In[t][r] = fmaxf(In[t][r], 0.f);
+          for (int r = 0; r < 16; ++r) In[t][r] = fmaxf(In[t][r], 0.f);
+      }
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -589,7 +384,11 @@ __global__ __launch_bounds__(256) void mlp_fwd_bfs_k(BfArgs args_by_value) {
     const bool skip = l == g.skip + 1;
     // what follows this layer's register GEMM in the stream: its own gamma(x) segment, the next layer, or the view branch
     const int nxt = skip ? (int)bg.p_skip : (l + 1 < g.D ? (int)bg.p_trunk[l + 1] : (l + 1 == g.D ? (int)bg.p_feat : (int)bg.p_views));
-    gemm_ring_reg<NT, NT, NT, NP, true>(Out, In, R, (int)(l < g.D ? bg.p_trunk[l] : bg.p_feat), nxt);
+    if (TRAIN)   // (the input is rectified already; its tiles go out to the stash under this GEMM)
+      gemm_ring_reg<NT, NT, NT, NP, false, StashStores<NT>, 2>(Out, In, R, (int)(l < g.D ? bg.p_trunk[l] : bg.p_feat), nxt,
+                                                               StashStores<NT>{In, srs, svo, tm_col(g.s_h[l - 1])});
+    else
+      gemm_ring_reg<NT, NT, NT, NP, true>(Out, In, R, (int)(l < g.D ? bg.p_trunk[l] : bg.p_feat), nxt);
     if (skip) {
       pin<NT>(Out);
       gemm_ring_lds<4, NT, NT, NP>(Out, Tx, R, (int)bg.p_skip, (int)(l + 1 < g.D ? bg.p_trunk[l + 1] : bg.p_feat), m, hh);
@@ -608,9 +407,19 @@ __global__ __launch_bounds__(256) void mlp_fwd_bfs_k(BfArgs args_by_value) {
   f32x16 V[NTH];
   bias_init<NTH>(V, P, (int)bg.b_views, hh);
   pin<NTH>(V);
-  gemm_ring_reg<NT, NTH, NT, NP, false>(V, Y, R, (int)bg.p_views, (int)bg.p_viewsd);
+  if (TRAIN)   // the feature tiles (no activation: feature_linear is linear, H:118) go out under the view GEMM
+    gemm_ring_reg<NT, NTH, NT, NP, false, StashStores<NT>, 2>(V, Y, R, (int)bg.p_views, (int)bg.p_viewsd,
+                                                              StashStores<NT>{Y, srs, svo, tm_col(g.s_feat)});
+  else
+    gemm_ring_reg<NT, NTH, NT, NP, false>(V, Y, R, (int)bg.p_views, (int)bg.p_viewsd);
   pin<NTH>(V);
   gemm_ring_lds<2, NTH, NT, NP>(V, Td, R, (int)bg.p_viewsd, -1, m, hh);
+  if (TRAIN) {
+    unsigned bv[MDV];
+    relu_bits<NTH, true>(V, bv);
+    store_bits<MDV>(srs, p < a.M ? m * 32 + hh * MDV * 4 : TM_OOB, tm_col(g.s_mask + g.s_mb[g.D]), bv);
+    store_tiles<NTH>(V, srs, svo, tm_col(g.s_hv));
+  }
   float o[3] = {0.f, 0.f, 0.f};
 #pragma unroll
   for (int c = 0; c < 3; ++c)
@@ -620,7 +429,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_bfs_k(BfArgs args_by_value) {
       for (int q = 0; q < 4; ++q) {
         const f32x4 wq = buf_load(P.rs, hh * 16, (int)bg.v_rgb + (c * (W / 2) + 32 * t + 8 * q) * 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[c] = __builtin_fmaf(fmaxf(V[t][4 * q + j], 0.f), wq[j], o[c]);
+        for (int j = 0; j < 4; ++j) o[c] = __builtin_fmaf(TRAIN ? V[t][4 * q + j] : fmaxf(V[t][4 * q + j], 0.f), wq[j], o[c]);
       }
 #pragma unroll
   for (int c = 0; c < 3; ++c) o[c] += __shfl_xor(o[c], 32, 64);
@@ -629,19 +438,26 @@ __global__ __launch_bounds__(256) void mlp_fwd_bfs_k(BfArgs args_by_value) {
   if (hh == 0) buf_store(ors, m * 16, 0, f32x4{o[0] + brgb[0], o[1] + brgb[1], o[2] + brgb[2], sig});
 }
 
-template <int NT, int NP>
+template <int NT, int NP, bool TRAIN>
 int launch_bfs(const BfArgs& a, hipStream_t st) {
   const size_t lds = (size_t)4 * Ring<NT, NP>::SLOT + 4 * 16384;
   static bool attr_set[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return CNERF_E_NODEVICE;
   if (!attr_set[dev]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_bfs_k<NT, NP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_bfs_k<NT, NP, TRAIN>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
       return (int)hipGetLastError();
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((mlp_fwd_bfs_k<NT, NP>), dim3((unsigned)cn_div_up(a.M, 128)), dim3(256), lds, st, a);
+  if (TRAIN) {
+    const int64_t Mp = cn_round_up(a.M, 32);
+    if (Mp > a.M) {   // last tile row holds padding points: the kernel drops their stores, wgrad reads them
+      hipError_t e = hipMemsetAsync(a.stash + (Mp - 32) * a.g.s_rows, 0, (size_t)32 * a.g.s_rows * sizeof(float), st);
+      if (e != hipSuccess) return (int)e;
+    }
+  }
+  hipLaunchKernelGGL((mlp_fwd_bfs_k<NT, NP, TRAIN>), dim3((unsigned)cn_div_up(a.M, 128)), dim3(256), lds, st, a);
   CN_CHECK_LAUNCH();
   return CNERF_OK;
 }
@@ -651,11 +467,15 @@ int launch_bf(const BfArgs& a, int NP, hipStream_t st) {
   // shared-panel kernel by default; the per-wave one on request (CNERF_BF_PERWAVE=1: A/B measurements) or when the
   // encodings are not the 64- / 32-channel tiles its unrolled K-steps assume
   const char* e = getenv("CNERF_BF_PERWAVE");
+  if (a.stash != nullptr) {   // training: the shared-panel kernel at three planes (the fp32-equivalent arithmetic) only
+    if (NP != 3 || a.g.in_chp != 64 || a.g.dir_chp != 32) return CNERF_E_UNSUPPORTED;
+    return launch_bfs<NT, 3, true>(a, st);
+  }
   if (!(e && e[0] == '1') && a.g.in_chp == 64 && a.g.dir_chp == 32) {
     switch (NP) {
-      case 1: return launch_bfs<NT, 1>(a, st);
-      case 2: return launch_bfs<NT, 2>(a, st);
-      case 3: return launch_bfs<NT, 3>(a, st);
+      case 1: return launch_bfs<NT, 1, false>(a, st);
+      case 2: return launch_bfs<NT, 2, false>(a, st);
+      case 3: return launch_bfs<NT, 3, false>(a, st);
       default: return CNERF_E_ARG;
     }
   }
@@ -693,7 +513,9 @@ extern "C" int cnerf_pack_weights_bf(const cnerf_net* net, const cnerf_ptrs* par
   BfPackArgs a;
   a.njobs = a.ncopies = 0; a.NP = planes; a.out = static_cast<unsigned char*>(packed_bf);
   const int W = g.W, Wh = g.Wh, D = g.D;
+  bool overflow = false;
   auto panel = [&](const float* src, int ld, int col0, int N, int K, int Kp, int kind, int64_t dst) {
+    if (a.njobs >= 48) { overflow = true; return; }
     a.job[a.njobs++] = BfPackJob{src, ld, col0, N, K, g.NT, Kp, kind, dst};
   };
   auto copy = [&](const float* src, int n, int64_t dst) { a.cp[a.ncopies++] = BfCopyJob{src, n, dst}; };
@@ -717,7 +539,15 @@ extern "C" int cnerf_pack_weights_bf(const cnerf_net* net, const cnerf_ptrs* par
   copy(params->p[base + 5], 1, b.b_alpha);
   copy(params->p[base + 6], 3 * Wh, b.v_rgb);
   copy(params->p[base + 7], 3, b.b_rgb);
-  if (a.njobs > 24 || a.ncopies > 24) return CNERF_E_UNSUPPORTED;
+  if (planes == 3) {   // the transposed panels of the bf16x3 dgrad (mlp_bwd_bf.hip)
+    for (int l = 1; l < D; ++l) {
+      const bool sk = g.skip >= 0 && l == g.skip + 1;
+      panel(Wt(l), sk ? W + g.in_ch : W, sk ? g.in_ch : 0, W, W, W, 2, b.pt_trunk[l]);
+    }
+    panel(params->p[base + 2], W, 0, W, W, W, 2, b.pt_feat);
+    panel(params->p[base + 0], W + g.dir_ch, 0, W, Wh, Wh, 2, b.pt_views);
+  }
+  if (overflow || a.ncopies > 24) return CNERF_E_UNSUPPORTED;
   hipLaunchKernelGGL(pack_bf_k, dim3(64, a.njobs + a.ncopies), dim3(256), 0, cn_stream(stream), a);
   CN_CHECK_LAUNCH();
   return CNERF_OK;
@@ -735,12 +565,34 @@ extern "C" int cnerf_mlp_fwd_bf(const cnerf_net* net, const void* packed_bf, int
   if (!dirs && (!rays || ray_stride < 11)) return CNERF_E_ARG;
   if (B == 0) return CNERF_OK;
   a.pk = static_cast<const unsigned char*>(packed_bf);
-  a.pts = pts; a.rays = rays; a.dirs = dirs; a.z = z; a.raw = raw;
+  a.pts = pts; a.rays = rays; a.dirs = dirs; a.z = z; a.raw = raw; a.stash = nullptr;
   a.M = B * S; a.S = S; a.rs = ray_stride;
   a.cam = cn_no_raygen();
   switch (a.g.NT) {
     case 4: return launch_bf<4>(a, planes, cn_stream(stream));
     case 8: return launch_bf<8>(a, planes, cn_stream(stream));
+  }
+  return CNERF_E_UNSUPPORTED;
+}
+
+extern "C" int cnerf_mlp_fwd_bf_train(const cnerf_net* net, const void* packed_bf, const float* pts, const float* rays,
+                                      int ray_stride, const float* dirs, const float* z, int64_t B, int S, float* raw,
+                                      float* stash, void* stream) {
+  BfArgs a;
+  int rc = cn_make_geom(net, &a.g);
+  if (rc) return rc;
+  if ((rc = make_bf_geom(a.g, 3, &a.b))) return rc;
+  if (!packed_bf || !raw || !stash || B < 0 || S <= 0) return CNERF_E_ARG;
+  if (!pts && (!rays || !z || ray_stride < 8)) return CNERF_E_ARG;
+  if (!dirs && (!rays || ray_stride < 11)) return CNERF_E_ARG;
+  if (B == 0) return CNERF_OK;
+  a.pk = static_cast<const unsigned char*>(packed_bf);
+  a.pts = pts; a.rays = rays; a.dirs = dirs; a.z = z; a.raw = raw; a.stash = stash;
+  a.M = B * S; a.S = S; a.rs = ray_stride;
+  a.cam = cn_no_raygen();
+  switch (a.g.NT) {
+    case 4: return launch_bf<4>(a, 3, cn_stream(stream));
+    case 8: return launch_bf<8>(a, 3, cn_stream(stream));
   }
   return CNERF_E_UNSUPPORTED;
 }

@@ -212,7 +212,9 @@ __global__ __launch_bounds__(WAVES * 64) void resample_k(const float* __restrict
     // bitonic network over 256 slots (4 per lane, slot e = 64 r + lane, padding = +inf) entirely in registers: 36 compare-exchange
     // steps, 33 of them one cross-lane exchange per register (partner lane ^ j), 3 between registers of the same lane.  ~700
     // instructions per ray instead of the ~2700 of an all-pairs rank sort (which made this kernel VALU-bound: 4 waves per SIMD x
-    // 5.5 us at 4096 rays).  Values only, so equal keys need no tie rule.
+    // 5.5 us at 4096 rays).  Values only, so equal keys need no tie rule.  INPUTS MUST BE NaN-FREE: fminf / fmaxf return the
+    // non-NaN operand, so a NaN depth would be dropped and its neighbour duplicated (torch.sort keeps NaNs, last).  The depths
+    // are convex combinations of finite near / far bounds and bin edges, so a NaN here means NaN rays, which R:417-419 reports.
     float v[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = (64 * r + lane) < n ? all[64 * r + lane] : __builtin_inff();

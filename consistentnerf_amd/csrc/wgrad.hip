@@ -25,7 +25,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "mlp_common.hpp"
+#include "mlp_bf_common.hpp"
 
 namespace {
 
@@ -51,6 +51,7 @@ struct WgJob {
   int gk, an, ak;     // wave grid: wave w -> (wn, wk) = (w / gk, w % gk) owns an x ak tiles of 32x32
   int nsplit, chunk;  // this GEMM's point ranges: `nsplit` workgroups of `chunk` points (multiple of 32) each
   int first;          // linear block id of its first range (the grid is 1-D, jobs back to back, longest workgroups first)
+  int bf3;            // 1: the opt-in bf16x3 body (wgrad_body_bf3) runs this GEMM; 0: exact fp32 (wgrad_body)
 };
 
 // One network's operands.  A launch carries up to two (the coarse and the fine network of a training step, whose
@@ -335,6 +336,182 @@ __device__ __forceinline__ void wgrad_body(WgNetC& a, WgJobC& jb, float* lds) {
   }
 }
 
+// ---- OPT-IN bf16x3 body (second bench line only) -----------------------------------------------------------------------
+// The same GEMM, point ranges, LDS image, DMA and epilogue, with the products on v_mfma_f32_32x32x16_bf16: a K-step contracts 16
+// points (lane (i, hh) supplies column i of points 8 hh + e, e = 0..7: eight ds_read_b32 at immediate offsets), every fragment —
+// 32 columns x 16 points of dZ or of H, fp32 in LDS — is split into THREE bf16 planes on the VALU (mlp_bf_common.hpp split_pair)
+// and each 32x32 tile pair takes the 6 cross terms with i + j < 3 (error per product ~2^-23: fp32-equivalent, fp32 accumulate).
+// Pipeline: the planes of K-step kk+1 are produced (reads + splits, dealt out two half-fragments per tile pair) under the 6 AN AK
+// MFMAs of K-step kk; a slab (32 points = 2 K-steps) is published by ONE barrier in the MIDDLE of the previous slab's iteration,
+// right before its first reads; its DMA is issued a full iteration ahead (two buffers).
+template <int AN, int AK, bool BS>
+__device__ __forceinline__ void wgrad_body_bf3(WgNetC& a, WgJobC& jb, float* lds) {
+  constexpr int NF = AN + AK;                       // fragments per K-step: A (dZ columns) 0..AN-1, B (H columns) AN..NF-1
+  static_assert(AN * AK >= NF && NF % 2 == 0, "side work is dealt out over the tile pairs");
+  const int split = __builtin_amdgcn_readfirstlane((int)blockIdx.x - jb.first);
+  const int tid = threadIdx.x, lane = tid & 63, i31 = lane & 31, hh = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wv / jb.gk, wk = wv - wn * jb.gk;
+  const int g_rows4 = __builtin_amdgcn_readfirstlane(a.g_rows * 4), s_rows4 = __builtin_amdgcn_readfirstlane(a.s_rows * 4);
+  const int64_t m_begin0 = (int64_t)split * jb.chunk;
+  const int64_t m_begin = m_begin0 < a.Mp ? m_begin0 : a.Mp;
+  const int64_t m_end = m_begin + jb.chunk < a.Mp ? m_begin + jb.chunk : a.Mp;
+  const int nslab = __builtin_amdgcn_readfirstlane(m_end > m_begin ? (int)((m_end - m_begin) / TM) : 0);
+  const int ntn = (jb.N + 31) >> 5, ntk = (jb.K + 31) >> 5;
+  const int tn0 = __builtin_amdgcn_readfirstlane(wn * AN), tk0 = __builtin_amdgcn_readfirstlane(wk * AK);
+  const i32x4 xr = dma_rsrc(a.G + m_begin * a.g_rows + (jb.xcol >> 3) * 256, (unsigned)((m_end - m_begin) * a.g_rows * 4));
+  const i32x4 yr = dma_rsrc(a.stash + m_begin * a.s_rows + (jb.ycol >> 3) * 256, (unsigned)((m_end - m_begin) * a.s_rows * 4));
+  const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)lds);
+  const int vo = lane * 16;
+  f32x16 acc[AN][AK];
+#pragma unroll
+  for (int x = 0; x < AN; ++x)
+#pragma unroll
+    for (int y = 0; y < AK; ++y)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
+  float bsum[AN];
+#pragma unroll
+  for (int x = 0; x < AN; ++x) bsum[x] = 0.f;
+  const int xoct = __builtin_amdgcn_readfirstlane(4 * ntn), yoct = __builtin_amdgcn_readfirstlane(4 * ntk);
+  const int bufF = (xoct + yoct) * OCTF;            // two buffers (the envelope check guarantees they fit)
+  auto piece = [&](int sl, int buf, int i) __attribute__((always_inline)) {
+    const unsigned b = lds0 + (unsigned)(buf * bufF * 4);
+    const int o = wv + NWAVES * (i >> 1);
+    if (i & 1) {
+      const bool on = sl < nslab && o < yoct;
+      dma16(yr, on ? b + (xoct + o) * OCTF * 4 : lds0 + LDS_BYTES - DUMMY_BYTES, vo, on ? sl * s_rows4 * 32 + o * 1024 : 0x7ffffc00);
+    } else {
+      const bool on = sl < nslab && o < xoct;
+      dma16(xr, on ? b + o * OCTF * 4 : lds0 + LDS_BYTES - DUMMY_BYTES, vo, on ? sl * g_rows4 * 32 + o * 1024 : 0x7ffffc00);
+    }
+  };
+  auto landed = [&]() __attribute__((always_inline)) {   // this wave's DMA pieces have landed; everybody's: the barrier
+    __builtin_amdgcn_s_waitcnt(0x0f70);                  // vmcnt(0)
+    __syncthreads();
+  };
+  // LDS image (as wgrad_body): block of column octet o at o*OCTF floats, inside it point p, column c at p*8 + c.  Lane (i, hh)
+  // reads column 32x + i of points 16 ks + 8 hh + e: one per-lane base + the immediate (4x*OCTF + 128 ks + 8 e) floats; the 32
+  // lanes of a half-wave hit 32 distinct banks (the half-waves are served in separate cycles).
+  const int lbase = (i31 >> 3) * OCTF + (i31 & 7) + hh * 64;
+  u32x4 pl[2][NF][3];     // bf16 planes of the fragments: set kk & 1 feeds the MFMAs of K-step kk
+  float rw[2][8];         // raw fp32 values of the fragment being read (two in flight)
+  // fragment f of K-step ks of the slab in buffer `buf`: its eight values -> rw[f & 1]
+  auto rd = [&](int buf, int ks, int f, int half) __attribute__((always_inline)) {
+    const float* base = lds + buf * bufF + (f < AN ? 4 * (tn0 + f) : xoct + 4 * (tk0 + f - AN)) * OCTF + lbase + 128 * ks;
+#pragma unroll
+    for (int e = 4 * half; e < 4 * half + 4; ++e) rw[f & 1][e] = base[8 * e];
+  };
+  auto sp = [&](int set, int f, int half) __attribute__((always_inline)) {
+    float* v = rw[f & 1];
+    if (BS && f < AN) bsum[f] += (v[4 * half] + v[4 * half + 1]) + (v[4 * half + 2] + v[4 * half + 3]);
+    split_pair<3, false>(v[4 * half], v[4 * half + 1], pl[set][f], 2 * half);
+    split_pair<3, false>(v[4 * half + 2], v[4 * half + 3], pl[set][f], 2 * half + 1);
+  };
+  // produce all planes of one K-step with nothing to hide behind (prologue only)
+  auto produce_now = [&](int set, int buf, int ks) __attribute__((always_inline)) {
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      rd(buf, ks, f, 0); rd(buf, ks, f, 1);
+      sp(set, f, 0); sp(set, f, 1);
+    }
+  };
+  // MFMAs of the K-step whose planes are in `set`, with the production of the next K-step's planes (from buffer nbuf_, K-step
+  // nks of that slab, into set ^ 1) dealt out behind the tile pairs: slot j reads half (j & 1) of fragment j/2 + 1 and splits
+  // half (j & 1) of fragment j/2 (read two slots earlier); fragment 0 is read in front of the loop.  DMA: pieces of slab
+  // dsl -> buffer dbuf, two per slot in the first eight slots (dsl < 0: none).
+  auto phase = [&](int set, bool prod, int nbuf_, int nks, int dsl, int dbuf) __attribute__((always_inline)) {
+    if (prod) { rd(nbuf_, nks, 0, 0); rd(nbuf_, nks, 0, 1); }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int x = 0; x < AN; ++x)
+#pragma unroll
+      for (int y = 0; y < AK; ++y) {
+        const int j = x * AK + y;
+        products<3>(acc[x][y], pl[set][x], pl[set][AN + y]);
+        if (prod) {
+          if (j < 2 * NF) {
+            const int f = j >> 1, h = j & 1;
+            if (f + 1 < NF) rd(nbuf_, nks, f + 1, h);
+            sp(set ^ 1, f, h);
+          }
+        }
+        if (dsl >= 0 && j < 8) { piece(dsl, dbuf, 2 * j); piece(dsl, dbuf, 2 * j + 1); }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+  };
+  static_assert(AN * AK >= 2 * NF || true, "");
+  // prologue: slab 0 lands, slab 1 is on its way, the planes of K-step 0 are produced in the open
+#pragma unroll
+  for (int i = 0; i < 2 * TM / NWAVES; ++i) piece(0, 0, i);
+  landed();
+#pragma unroll
+  for (int i = 0; i < 2 * TM / NWAVES; ++i) piece(1, 1, i);
+  if (nslab > 0) produce_now(0, 0, 0);
+  int cur = 0;
+  for (int sl = 0; sl < nslab; ++sl) {
+    phase(0, true, cur, 1, -1, 0);                       // K-step 2 sl; planes of 2 sl + 1 from the same slab
+    landed();                                            // slab sl + 1 has landed, nobody reads slab sl any more
+    phase(1, sl + 1 < nslab, cur ^ 1, 0, sl + 2, cur);   // K-step 2 sl + 1; planes of 2 sl + 2 from slab sl + 1; DMA of slab sl + 2
+    cur ^= 1;
+  }
+  landed();   // (the no-op pieces of the last iterations)
+  // Epilogue: as wgrad_body (the accumulator layout of a 32x32 MFMA tile is the same)
+  const int N = __builtin_amdgcn_readfirstlane(jb.N), K = __builtin_amdgcn_readfirstlane(jb.K);
+  const int n_lo = __builtin_amdgcn_readfirstlane(jb.n_lo), ld4 = __builtin_amdgcn_readfirstlane(jb.ld * 4);
+  const int col0 = __builtin_amdgcn_readfirstlane(jb.col0);
+  auto uniform = [](const float* q) __attribute__((always_inline)) {
+    const unsigned long long v = (unsigned long long)q;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(v & 0xffffffffu));
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32));
+    return (const float*)(((unsigned long long)hi << 32) | lo);
+  };
+  const float* out = a.partials + (int64_t)split * a.pstride;
+  const rsrc_t wr = make_rsrc(uniform(out + a.toff[jb.tensor]), (unsigned)((N - n_lo) * ld4));
+  int kvo[AK];
+#pragma unroll
+  for (int y = 0; y < AK; ++y) {
+    const int k = 32 * (tk0 + y) + i31;
+    kvo[y] = k < K ? (col0 + k) * 4 + hh * 4 * ld4 : TM_OOB;
+  }
+#pragma unroll
+  for (int x = 0; x < AN; ++x)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n0 = 32 * (tn0 + x) + (r & 3) + 8 * (r >> 2);
+      if (n0 >= N) continue;
+      if (n0 >= n_lo && n0 + 4 < N) {
+#pragma unroll
+        for (int y = 0; y < AK; ++y)
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[x][y][r]), wr, kvo[y], (n0 - n_lo) * ld4, 0);
+      } else {
+        const int n = n0 + 4 * hh;
+#pragma unroll
+        for (int y = 0; y < AK; ++y) {
+          const int k = 32 * (tk0 + y) + i31;
+          const int vo2 = (n >= n_lo && n < N && k < K) ? ((n - n_lo) * (ld4 >> 2) + col0 + k) * 4 : TM_OOB;
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[x][y][r]), wr, vo2, 0, 0);
+        }
+      }
+    }
+  if (BS) {
+    const rsrc_t br = make_rsrc(uniform(out + a.toff[jb.bias_tensor]), (unsigned)((N - n_lo) * 4));
+#pragma unroll
+    for (int x = 0; x < AN; ++x) {
+      const float s = bsum[x] + __shfl_xor(bsum[x], 32, 64);
+      const int n = 32 * (tn0 + x) + i31;
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(s), br, (hh == 0 && n >= n_lo && n < N) ? (n - n_lo) * 4 : TM_OOB, 0, 0);
+    }
+  }
+}
+
+template <int AN, int AK>
+__device__ __forceinline__ void wgrad_disp_bf3(WgNetC& a, WgJobC& jb, float* lds) {
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (jb.bias_tensor >= 0 && wv % jb.gk == 0) wgrad_body_bf3<AN, AK, true>(a, jb, lds);
+  else wgrad_body_bf3<AN, AK, false>(a, jb, lds);
+}
+
 template <int AN, int AK>
 __device__ __forceinline__ void wgrad_disp(WgNetC& a, WgJobC& jb, float* lds) {
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -342,9 +519,11 @@ __device__ __forceinline__ void wgrad_disp(WgNetC& a, WgJobC& jb, float* lds) {
   else wgrad_body<AN, AK, false>(a, jb, lds);
 }
 
-__global__ __launch_bounds__(64 * NWAVES) void wgrad_k(WgArgs a_by_value) {
+// `wgrad_k` = the exact-fp32 kernel of the default path (its code is untouched by the opt-in arithmetic); `wgrad_mixed_k` = the
+// same grid with the bf16x3 body for the jobs flagged bf3 and the fp32 body for the rest (launched only by cnerf_mlp_wgrad_bf*).
+template <bool MIXED>
+__device__ __forceinline__ void wgrad_kernel_body() {
   extern __shared__ __attribute__((aligned(16))) float lds[];   // [2 buffers][X slab | Y slab]
-  (void)a_by_value;   // (the first and only explicit kernel argument: offset 0 of the kernarg segment)
   WgArgsC& args = *(WgArgsC*)__builtin_amdgcn_kernarg_segment_ptr();
   // 1-D grid, jobs back to back: the job of this block = the last one whose first block id is <= blockIdx.x (scalar loads
   // from the kernarg segment, <= 28 entries)
@@ -352,6 +531,14 @@ __global__ __launch_bounds__(64 * NWAVES) void wgrad_k(WgArgs a_by_value) {
   for (int i = 1; i < args.nj; ++i) ji = (int)blockIdx.x >= args.job[i].first ? i : ji;
   WgJobC& jb = args.job[ji];
   WgNetC& a = args.net[jb.net];
+  if (MIXED && jb.bf3) {           // block-uniform: the opt-in bf16x3 body (wide GEMMs only, plan in add_net_jobs)
+    switch (jb.an * 8 + jb.ak) {
+      case 4 * 8 + 4: wgrad_disp_bf3<4, 4>(a, jb, lds); return;
+      case 4 * 8 + 2: wgrad_disp_bf3<4, 2>(a, jb, lds); return;
+      case 2 * 8 + 4: wgrad_disp_bf3<2, 4>(a, jb, lds); return;
+      default: break;
+    }
+  }
   switch (jb.an * 8 + jb.ak) {     // block-uniform
     case 4 * 8 + 4: wgrad_disp<4, 4>(a, jb, lds); break;
     case 4 * 8 + 2: wgrad_disp<4, 2>(a, jb, lds); break;
@@ -363,6 +550,15 @@ __global__ __launch_bounds__(64 * NWAVES) void wgrad_k(WgArgs a_by_value) {
     case 1 * 8 + 2: wgrad_disp<1, 2>(a, jb, lds); break;
     default: wgrad_disp<1, 1>(a, jb, lds); break;
   }
+}
+
+__global__ __launch_bounds__(64 * NWAVES) void wgrad_k(WgArgs a_by_value) {
+  (void)a_by_value;   // (the first and only explicit kernel argument: offset 0 of the kernarg segment, read in place)
+  wgrad_kernel_body<false>();
+}
+__global__ __launch_bounds__(64 * NWAVES) void wgrad_mixed_k(WgArgs a_by_value) {
+  (void)a_by_value;
+  wgrad_kernel_body<true>();
 }
 
 struct RedArgs {    // entries [0, nt0) belong to the first network, [nt0, nt0 + nt1) to the second
@@ -454,7 +650,7 @@ namespace {
 
 // Appends one network's GEMMs to the job table / reduction table.  Returns false when a shape is outside the envelope.
 bool add_net_jobs(const NetGeom& g, int netidx, const float* stash, const float* G, int64_t Mp, float* partials,
-                  const cnerf_ptrs* grads, WgArgs& a, int& nj, RedArgs& r, int& nr) {
+                  const cnerf_ptrs* grads, WgArgs& a, int& nj, RedArgs& r, int& nr, bool bf3 = false) {
   cnerf_net net{g.D, g.W, g.L, g.Ld, g.viewdirs, g.out_ch, g.skip};
   WgNet& wn = a.net[netidx];
   const int nt = cnerf_num_tensors(&net);
@@ -489,8 +685,12 @@ bool add_net_jobs(const NetGeom& g, int netidx, const float* stash, const float*
       if (cost < best_cost) { best_cost = cost; best_gk = gk; best_an = an; best_ak = ak; }
     }
     if (best_gk == 0 || best_an == 3 || best_ak == 3 || ntn > 8 || ntk > 8 || nj >= MAX_WG_JOBS) { ok = false; return; }
+    // the opt-in bf16x3 body takes the wide GEMMs (>= 8 tiles per wave: 86 % of the MACs at D=8/W=256) whose two slab buffers
+    // fit the LDS; the narrow ones (heads, gamma columns) stay exact fp32 in the same grid
+    const bool wide = (best_an == 4 && best_ak == 4) || (best_an == 4 && best_ak == 2) || (best_an == 2 && best_ak == 4);
+    const bool fits = 2 * (4 * ntn + 4 * ntk) * OCTF <= LDS_FLOATS;
     a.job[nj++] = WgJob{netidx, xcol, ycol, N, K, n_lo, tensor, ld, col0, bias_tensor, best_gk ? best_gk : 2, best_an,
-                        best_ak, 1, 0, 0};
+                        best_ak, 1, 0, 0, (bf3 && wide && fits) ? 1 : 0};
     r.touched[r0 + tensor] = 1;
     if (bias_tensor >= 0) r.touched[r0 + bias_tensor] = 1;
   };
@@ -581,13 +781,13 @@ void order_jobs(const WgJob* job, int nj, const int* ns, const int64_t* slabs, i
 // capacity of each network's partial buffer in slices (cn_wgrad_nsplit).
 int cn_wgrad_launch_n(int n, const NetGeom* const* g, const float* const* stash, const float* const* G, const int64_t* Mp,
                       float* const* partials, const int* nsplit, const cnerf_ptrs* const* grads, int accumulate,
-                      hipStream_t st) {
+                      hipStream_t st, int bf3) {
   WgArgs a;
   RedArgs r;
   int nj = 0, nr = 0, r0[2] = {0, 0};
   for (int i = 0; i < n; ++i) {
     r0[i] = nr;
-    if (!add_net_jobs(*g[i], i, stash[i], G[i], Mp[i], partials[i], grads[i], a, nj, r, nr)) return CNERF_E_UNSUPPORTED;
+    if (!add_net_jobs(*g[i], i, stash[i], G[i], Mp[i], partials[i], grads[i], a, nj, r, nr, bf3 != 0)) return CNERF_E_UNSUPPORTED;
   }
   if (n == 1) a.net[1] = a.net[0];
   int dev = 0;
@@ -624,14 +824,15 @@ int cn_wgrad_launch_n(int n, const NetGeom* const* g, const float* const* stash,
   const size_t lds_bytes = LDS_BYTES;
   // the 160 KiB dynamic-LDS opt-in is a per-device function attribute: set it once per device this process launches on
   // (idempotent, so a race between two host threads only repeats the call)
-  static bool attr_set[64] = {};
-  if (!attr_set[dev]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds_bytes) != hipSuccess)
+  static bool attr_set[2][64] = {};
+  const void* kfn = bf3 ? reinterpret_cast<const void*>(wgrad_mixed_k) : reinterpret_cast<const void*>(wgrad_k);
+  if (!attr_set[bf3 ? 1 : 0][dev]) {
+    if (hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
       return (int)hipGetLastError();
-    attr_set[dev] = true;
+    attr_set[bf3 ? 1 : 0][dev] = true;
   }
-  hipLaunchKernelGGL(wgrad_k, dim3(first), dim3(64 * NWAVES), lds_bytes, st, b);
+  if (bf3) hipLaunchKernelGGL(wgrad_mixed_k, dim3(first), dim3(64 * NWAVES), lds_bytes, st, b);
+  else hipLaunchKernelGGL(wgrad_k, dim3(first), dim3(64 * NWAVES), lds_bytes, st, b);
   CN_CHECK_LAUNCH();
   r.accumulate = accumulate;
   hipLaunchKernelGGL(wgrad_reduce_k, dim3(64, nr), dim3(256), 0, st, r);
@@ -676,8 +877,8 @@ extern "C" int cnerf_debug_wgrad_plan(const cnerf_net* net0, int64_t Mp0, const 
 }
 
 int cn_wgrad_launch(const NetGeom& g, const float* stash, const float* G, int64_t M, int64_t Mp, float* partials,
-                    int nsplit, const cnerf_ptrs* grads, int accumulate, hipStream_t st) {
+                    int nsplit, const cnerf_ptrs* grads, int accumulate, hipStream_t st, int bf3) {
   (void)M;   // padding points [M, Mp) are stored as zeros by the producers: no masking here
   const NetGeom* gp = &g;
-  return cn_wgrad_launch_n(1, &gp, &stash, &G, &Mp, &partials, &nsplit, &grads, accumulate, st);
+  return cn_wgrad_launch_n(1, &gp, &stash, &G, &Mp, &partials, &nsplit, &grads, accumulate, st, bf3);
 }

@@ -57,10 +57,14 @@ class GraphedStep:
         # would leave every replay's forward on the weights as they were at capture time
         self.opt.bump_epoch()
         timing = getattr(reducer, "timing", False)
+        self._hold_before = getattr(reducer, "hold", False)
         if reducer is not None:
             reducer.timing = False                # (timed events cannot be recorded into a graph)
             reducer.hold = collective == "split"  # split: nothing leaves from inside the (recorded) backward
         self.graph = torch.cuda.CUDAGraph()
+        ok = False
+        if reducer is not None:
+            self._msgs_before, self._steps_before = reducer.messages, reducer.steps
         try:
             with torch.cuda.graph(self.graph):    # (recorded, not executed: the step counter does not move here)
                 self.static_loss = step_fn(*self.static_in)
@@ -71,12 +75,28 @@ class GraphedStep:
                 self.tail_graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.tail_graph, pool=self.graph.pool()):
                     optimizer.step(grad_scale=reducer.grad_scale)
+            ok = True
         finally:
             if reducer is not None:
                 reducer.timing = timing
+                if not ok:
+                    # a failed recording must leave the reducer as it found it: the caller's fallback is eager stepping, which
+                    # needs the in-backward issue (hold off) and none of the recorded backward's bookkeeping
+                    reducer.reset()
+                    reducer.hold = self._hold_before
         if reducer is not None and collective == "capture":
             reducer.reset()
+            # the recorded finish() counted one step and its messages: remembered so that every replay counts the same
+            self._msgs_per_replay = reducer.messages - self._msgs_before
+            reducer.messages, reducer.steps = self._msgs_before, self._steps_before     # (the recording itself sent nothing)
         torch.cuda.synchronize()
+
+    def release(self):
+        """Give the reducer back to eager stepping (split mode sets `reducer.hold`, under which nothing leaves from inside
+        loss.backward()): call before stepping eagerly again with the same GradReducer."""
+        if self.reducer is not None:
+            self.reducer.reset()
+            self.reducer.hold = self._hold_before
 
     def __call__(self, *inputs: torch.Tensor) -> torch.Tensor:
         for dst, src in zip(self.static_in, inputs):
@@ -86,6 +106,9 @@ class GraphedStep:
         if self.tail_graph is not None:
             self.reducer.finish()                 # eager: every slice of the flat gradient, on the collective's stream
             self.tail_graph.replay()
+        elif self.reducer is not None:            # capture: the recorded finish() does not run again — keep its statistics honest
+            self.reducer.steps += 1
+            self.reducer.messages += self._msgs_per_replay
         # the recorded Python ran once: tell the packed-weight caches that the weights moved (an eval render between graphed
         # steps must re-pack, not reuse the kernel-layout copy of an earlier evaluation)
         self.opt.bump_epoch()

@@ -189,6 +189,10 @@ def mlp_forward(spec: NetSpec, packed: Tensor, B: int, S: int, *, pts: Optional[
 
 
 PRECISION_PLANES = {"bf16": 1, "bf16x2": 2, "bf16x3": 3}
+# which kernels of a bf16x3 training step run in that arithmetic (ablation switches; all on by default)
+import os as _os
+DGRAD_BF3 = _os.environ.get("CNERF_BF3_DGRAD", "1") != "0"
+WGRAD_BF3 = _os.environ.get("CNERF_BF3_WGRAD", "1") != "0"
 
 
 def pack_weights_bf(spec: NetSpec, params: Sequence[Tensor], planes: int, out: Optional[Tensor] = None) -> Tensor:
@@ -218,6 +222,22 @@ def mlp_forward_bf(spec: NetSpec, packed_bf: Tensor, planes: int, B: int, S: int
     return raw
 
 
+def mlp_forward_bf_train(spec: NetSpec, packed_bf: Tensor, B: int, S: int, *, pts: Optional[Tensor] = None,
+                         rays: Optional[Tensor] = None, z: Optional[Tensor] = None, dirs: Optional[Tensor] = None):
+    """cnerf_mlp_fwd_bf_train: the OPT-IN bf16x3 training forward (three bf16 planes per operand, fp32 accumulation) ->
+    (raw, stash); the stash is the fp32 kernel's (cnerf_mlp_dgrad / cnerf_mlp_wgrad consume it unchanged)."""
+    lib, net = _lib.load(), spec.c()
+    pts, rays, z, dirs = _chk(pts, "pts"), _chk(rays, "rays"), _chk(z, "z"), _chk(dirs, "dirs")
+    dev = packed_bf.device
+    raw = torch.empty(B, S, spec.raw_ch, device=dev, dtype=torch.float32)
+    stash = torch.empty(lib.cnerf_mlp_stash_floats(C.byref(net), B * S), device=dev, dtype=torch.float32)
+    rs = rays.shape[1] if rays is not None else 0
+    with _timed("mlp_fwd_train_bf3", B * S):
+        _lib.check(lib.cnerf_mlp_fwd_bf_train(C.byref(net), _p(packed_bf), _p(pts), _p(rays), rs, _p(dirs), _p(z), B, S,
+                                              _p(raw), _p(stash), _stream()), "cnerf_mlp_fwd_bf_train")
+    return raw, stash
+
+
 def mlp_forward_embedded(spec: NetSpec, packed: Tensor, x: Tensor, want_stash: bool = False):
     """NeRF.forward on pre-embedded inputs x[M, in_ch + in_ch_views]."""
     lib, net = _lib.load(), spec.c()
@@ -234,7 +254,8 @@ def mlp_forward_embedded(spec: NetSpec, packed: Tensor, x: Tensor, want_stash: b
 
 
 def mlp_backward(spec: NetSpec, packed: Tensor, d_raw: Tensor, B: int, S: int, stash: Tensor,
-                 grads: Optional[List[Tensor]] = None, accumulate: bool = False) -> List[Tensor]:
+                 grads: Optional[List[Tensor]] = None, accumulate: bool = False, packed_bf: Optional[Tensor] = None) -> List[Tensor]:
+    """packed_bf (the three-plane buffer of pack_weights_bf): the dgrad runs in the opt-in bf16x3 arithmetic."""
     lib, net = _lib.load(), spec.c()
     d_raw = _chk(d_raw, "d_raw")
     dev = packed.device
@@ -243,20 +264,27 @@ def mlp_backward(spec: NetSpec, packed: Tensor, d_raw: Tensor, B: int, S: int, s
         accumulate = False
     ws = torch.empty(lib.cnerf_mlp_bwd_ws_floats(C.byref(net), B * S), device=dev, dtype=torch.float32)
     ptrs = _ptrs(grads)
-    with _timed("mlp_dgrad", B * S):
+    if packed_bf is not None and DGRAD_BF3:
+        with _timed("mlp_dgrad_bf3", B * S):
+            _lib.check(lib.cnerf_mlp_dgrad_bf(C.byref(net), _p(packed_bf), _p(d_raw), B, S, _p(stash), _p(ws), _stream()),
+                       "cnerf_mlp_dgrad_bf")
+    else:
+      with _timed("mlp_dgrad", B * S):
         _lib.check(lib.cnerf_mlp_dgrad(C.byref(net), _p(packed), _p(d_raw), B, S, _p(stash), _p(ws), _stream()),
                    "cnerf_mlp_dgrad")
-    with _timed("mlp_wgrad", B * S):
-        _lib.check(lib.cnerf_mlp_wgrad(C.byref(net), B, S, _p(stash), _p(ws), C.byref(ptrs), int(accumulate),
-                                       _stream()), "cnerf_mlp_wgrad")
+    bf_w = packed_bf is not None and WGRAD_BF3
+    with _timed("mlp_wgrad_bf3" if bf_w else "mlp_wgrad", B * S):
+        _lib.check((lib.cnerf_mlp_wgrad_bf if bf_w else lib.cnerf_mlp_wgrad)(C.byref(net), B, S, _p(stash), _p(ws), C.byref(ptrs),
+                                                                             int(accumulate), _stream()), "cnerf_mlp_wgrad")
     return grads
 
 
 def mlp_backward_pair(spec0: NetSpec, packed0: Tensor, d_raw0: Tensor, B0: int, S0: int, stash0: Tensor, grads0: List[Tensor],
                       spec1: NetSpec, packed1: Tensor, d_raw1: Tensor, B1: int, S1: int, stash1: Tensor, grads1: List[Tensor],
-                      accumulate: bool = False):
+                      accumulate: bool = False, packed_bf0: Optional[Tensor] = None, packed_bf1: Optional[Tensor] = None):
     """cnerf_mlp_bwd_pair: the backward of two independent networks (coarse / fine) as one dgrad grid, one wgrad grid and
-    one reduction; gradients are written (or accumulated) into grads0 / grads1."""
+    one reduction; gradients are written (or accumulated) into grads0 / grads1.  packed_bf0 AND packed_bf1: the dgrad grid runs
+    in the opt-in bf16x3 arithmetic."""
     lib = _lib.load()
     n0, n1 = spec0.c(), spec1.c()
     d_raw0, d_raw1 = _chk(d_raw0, "d_raw0"), _chk(d_raw1, "d_raw1")
@@ -264,14 +292,21 @@ def mlp_backward_pair(spec0: NetSpec, packed0: Tensor, d_raw0: Tensor, B0: int, 
     ws0 = torch.empty(lib.cnerf_mlp_bwd_ws_floats(C.byref(n0), B0 * S0), device=dev, dtype=torch.float32)
     ws1 = torch.empty(lib.cnerf_mlp_bwd_ws_floats(C.byref(n1), B1 * S1), device=dev, dtype=torch.float32)
     p0, p1 = _ptrs(grads0), _ptrs(grads1)
-    with _timed("mlp_dgrad", B0 * S0 + B1 * S1):
+    if packed_bf0 is not None and packed_bf1 is not None and DGRAD_BF3:
+        with _timed("mlp_dgrad_bf3", B0 * S0 + B1 * S1):
+            _lib.check(lib.cnerf_mlp_dgrad_bf_pair(C.byref(n0), _p(packed_bf0), _p(d_raw0), B0, S0, _p(stash0), _p(ws0),
+                                                   C.byref(n1), _p(packed_bf1), _p(d_raw1), B1, S1, _p(stash1), _p(ws1), _stream()),
+                       "cnerf_mlp_dgrad_bf_pair")
+    else:
+      with _timed("mlp_dgrad", B0 * S0 + B1 * S1):
         _lib.check(lib.cnerf_mlp_dgrad_pair(C.byref(n0), _p(packed0), _p(d_raw0), B0, S0, _p(stash0), _p(ws0),
                                             C.byref(n1), _p(packed1), _p(d_raw1), B1, S1, _p(stash1), _p(ws1), _stream()),
                    "cnerf_mlp_dgrad_pair")
-    with _timed("mlp_wgrad", B0 * S0 + B1 * S1):
-        _lib.check(lib.cnerf_mlp_wgrad_pair(C.byref(n0), B0, S0, _p(stash0), _p(ws0), C.byref(p0),
-                                            C.byref(n1), B1, S1, _p(stash1), _p(ws1), C.byref(p1), int(accumulate),
-                                            _stream()), "cnerf_mlp_wgrad_pair")
+    bf_w = packed_bf0 is not None and packed_bf1 is not None and WGRAD_BF3
+    with _timed("mlp_wgrad_bf3" if bf_w else "mlp_wgrad", B0 * S0 + B1 * S1):
+        _lib.check((lib.cnerf_mlp_wgrad_bf_pair if bf_w else lib.cnerf_mlp_wgrad_pair)(
+            C.byref(n0), B0, S0, _p(stash0), _p(ws0), C.byref(p0), C.byref(n1), B1, S1, _p(stash1), _p(ws1), C.byref(p1),
+            int(accumulate), _stream()), "cnerf_mlp_wgrad_pair")
 
 
 # ------------------------------------------------------------------------------------------ render_rays as one call

@@ -74,6 +74,29 @@ def _packed_bf(model, planes):
     return cache[1]
 
 
+# Training arithmetic: "fp32" (default: exact fp32 MFMA, the arithmetic every parity statement and the headline bench line are
+# made in) or "bf16x3" (opt-in: bf16 matrix cores, three planes per operand, fp32 accumulation — reported as a SECOND bench line
+# only).  Per model (`NeRF.training_precision`), or for the whole process with CNERF_TRAIN_PRECISION (what the GPU suite uses to
+# run every test in that arithmetic as well).
+DEFAULT_TRAINING_PRECISION = os.environ.get("CNERF_TRAIN_PRECISION", "fp32")
+
+
+def training_precision(model):
+    """An explicit `model.training_precision` is obeyed (an architecture the bf16x3 kernels are not compiled for then fails
+    loudly in the launch); the process-wide default only applies to architectures they cover (view directions, W = 128 | 256,
+    the 10 / 4-frequency encodings) and leaves every other network on the exact-fp32 path."""
+    prec = getattr(model, "training_precision", None)
+    if prec is None:
+        prec = DEFAULT_TRAINING_PRECISION
+        if prec == "bf16x3":
+            sp = model.spec()
+            if not (sp.use_viewdirs and sp.W in (128, 256) and sp.multires == 10 and sp.multires_views == 4):
+                prec = "fp32"
+    if prec not in ("fp32", "bf16x3"):
+        raise ValueError("training_precision must be 'fp32' or 'bf16x3'")
+    return prec
+
+
 def _packed_still_valid(model, gen):
     cache = model.__dict__.get("_cnerf_packed")
     return cache is not None and cache[2] - gen <= 1
@@ -209,6 +232,11 @@ class _MlpFn(torch.autograd.Function):
         train = any(ctx.needs_input_grad[8:])
         if emb is not None:      # NeRF.forward(x) on pre-embedded inputs
             raw, stash = ops.mlp_forward_embedded(spec, packed, emb, want_stash=train)
+        elif train and training_precision(model) == "bf16x3":
+            # OPT-IN second training arithmetic (never the default): the forward GEMMs on the bf16 matrix cores at three planes
+            # per operand; same stash, so the backward below is unchanged.  `packed` (fp32 panels) still feeds the dgrad.
+            ctx.packed_bf = _packed_bf(model, 3)
+            raw, stash = ops.mlp_forward_bf_train(spec, ctx.packed_bf, B, S, pts=pts, rays=rays, z=z, dirs=dirs)
         else:
             raw, stash = ops.mlp_forward(spec, packed, B, S, pts=pts, rays=rays, z=z, dirs=dirs, want_stash=train)
         if train:
@@ -238,26 +266,27 @@ class _MlpFn(torch.autograd.Function):
             if (c is not None and c.stash is not None and _direct_ok(c.needs_input_grad[8:], c.params)
                     and _ENGINE_QUERY(c)):
                 pair.parked = (ctx.spec, ctx.packed, g_raw.contiguous(), ctx.B, ctx.S, ctx.stash, [p.grad for p in params],
-                               ctx.model)
+                               ctx.model, getattr(ctx, "packed_bf", None))
                 ctx.stash = ctx.packed = ctx.params = ctx.model = None
                 return nret
         parked = None
         if pair is not None and pair.coarse() is ctx and pair.parked is not None:
             parked, pair.parked = pair.parked, None
         if parked is not None and direct:
-            fs, fp, fg, fB, fS, fst, fgr, fmodel = parked
+            fs, fp, fg, fB, fS, fst, fgr, fmodel, fbf = parked
             ops.mlp_backward_pair(fs, fp, fg, fB, fS, fst, fgr, ctx.spec, ctx.packed, g_raw.contiguous(), ctx.B, ctx.S,
-                                  ctx.stash, [p.grad for p in params], accumulate=True)
+                                  ctx.stash, [p.grad for p in params], accumulate=True, packed_bf0=fbf,
+                                  packed_bf1=getattr(ctx, "packed_bf", None))
             _report_ready_pair(fmodel, ctx.model)
             ctx.stash = ctx.packed = ctx.params = ctx.model = None
             return nret
         if parked is not None:        # (cannot happen — the fine node checked this node's route — but never drop a gradient)
-            fs, fp, fg, fB, fS, fst, fgr, fmodel = parked
-            ops.mlp_backward(fs, fp, fg, fB, fS, fst, grads=fgr, accumulate=True)
+            fs, fp, fg, fB, fS, fst, fgr, fmodel, fbf = parked
+            ops.mlp_backward(fs, fp, fg, fB, fS, fst, grads=fgr, accumulate=True, packed_bf=fbf)
             _report_ready(fmodel, True)
         out = [p.grad for p in params] if direct else None
         grads = ops.mlp_backward(ctx.spec, ctx.packed, g_raw.contiguous(), ctx.B, ctx.S, ctx.stash, grads=out,
-                                 accumulate=direct)
+                                 accumulate=direct, packed_bf=getattr(ctx, "packed_bf", None))
         _report_ready(ctx.model, direct)
         ctx.stash = ctx.packed = ctx.params = ctx.model = None
         return nret if direct else (None,) * 8 + tuple(grads)
@@ -353,11 +382,20 @@ def _rows_of_global(draw, rows, cols, global_rows):
     return draw(int(total), cols)[int(off):int(off) + rows].contiguous()
 
 
+def _pytest_rows(rows, cols, device, global_rows):
+    """The reference's deterministic stream (np.random.seed(0); np.random.rand) for this call's rows — of the WHOLE batch when the
+    rays are a shard of it, so that the shards see the rows the unsharded call sees."""
+    if global_rows is None:
+        return pytest_uniform((rows, cols), device)
+    off, total = global_rows
+    return pytest_uniform((int(total), cols), device)[int(off):int(off) + rows].contiguous()
+
+
 def _density_noise(shape, raw_noise_std, pytest, device, global_rows=None):
     if not raw_noise_std > 0.:
         return None
     if pytest:   # R:290-294: uniform in pytest mode
-        return pytest_uniform(tuple(shape), device) * raw_noise_std
+        return _pytest_rows(shape[0], shape[1], device, global_rows) * raw_noise_std
     return _rows_of_global(lambda n, c: torch.randn(n, c, device=device), shape[0], shape[1], global_rows) * raw_noise_std
 
 
@@ -365,6 +403,11 @@ def batchify_rays(rays_flat, chunk=1024 * 32, **kwargs):
     """R:55-67."""
     all_ret = {}
     gr = kwargs.pop("_global_rows", None)
+    if gr is not None and rays_flat.shape[0] > chunk:
+        # every chunk would draw the whole batch's stream afresh, while the unsharded call draws one stream PER CHUNK: the
+        # "N-rank step sees the 1-rank step's random numbers row for row" guarantee holds for shards that fit one chunk
+        # (the training case: N_rand <= chunk)
+        raise ops.CnerfError(f"_global_rows needs the shard ({rays_flat.shape[0]} rays) to fit one chunk ({chunk})")
     for i in range(0, rays_flat.shape[0], chunk):
         if gr is not None:     # this chunk's rows of the global batch
             kwargs["_global_rows"] = (gr[0] + i, gr[1])
@@ -651,7 +694,7 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
     viewdirs = rays[:, -3:] if rays.shape[-1] > 8 else None
     t_rand = None
     if perturb > 0.:
-        t_rand = (pytest_uniform((N_rays, N_samples), dev) if pytest else
+        t_rand = (_pytest_rows(N_rays, N_samples, dev, _global_rows) if pytest else
                   _rows_of_global(lambda n, c: torch.rand(n, c, device=dev), N_rays, N_samples, _global_rows))
     z_vals = ops.coarse_z(rays, N_samples, t_rand, lindisp)
     raw = network_query_fn(RayPoints(rays, z_vals), viewdirs, network_fn)
@@ -660,8 +703,9 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
     z_coarse = z_vals
     if N_importance > 0:
         rgb_map_0, disp_map_0, acc_map_0, depth_map_0 = rgb_map, disp_map, acc_map, depth_map
-        if _global_rows is not None and not pytest and perturb != 0.:
-            u = _rows_of_global(lambda n, c: torch.rand(n, c, device=dev), N_rays, N_importance, _global_rows)
+        if _global_rows is not None and perturb != 0.:
+            u = (_pytest_rows(N_rays, N_importance, dev, _global_rows) if pytest else
+                 _rows_of_global(lambda n, c: torch.rand(n, c, device=dev), N_rays, N_importance, _global_rows))
         else:
             u = sample_u(N_rays, N_importance, perturb == 0., pytest, dev)
         z_vals, z_std = ops.resample(z_vals, weights, u)          # R:395-399 + R:415, no gradient (R:397)

@@ -101,6 +101,27 @@ int64_t cnerf_packed_bf_bytes(const cnerf_net* net, int planes);
 int cnerf_pack_weights_bf(const cnerf_net* net, const cnerf_ptrs* params, int planes, void* packed_bf, void* stream);
 int cnerf_mlp_fwd_bf(const cnerf_net* net, const void* packed_bf, int planes, const float* pts, const float* rays,
                      int ray_stride, const float* dirs, const float* z, int64_t B, int S, float* raw, void* stream);
+/* OPT-IN "bf16x3" TRAINING forward (second bench line only; the default training path is exact fp32): cnerf_mlp_fwd with its
+ * GEMMs on the bf16 matrix cores at three planes per operand (the 6 cross terms, error per product ~2^-23: fp32-equivalent)
+ * and the SAME training stash (fp32 activations + ReLU sign bits, cnerf_mlp_stash_floats floats) — cnerf_mlp_dgrad /
+ * cnerf_mlp_wgrad (and their _pair forms) consume it unchanged.  packed_bf = cnerf_pack_weights_bf(net, params, 3, ...). */
+int cnerf_mlp_fwd_bf_train(const cnerf_net* net, const void* packed_bf, const float* pts, const float* rays, int ray_stride,
+                           const float* dirs, const float* z, int64_t B, int S, float* raw, float* stash, void* stream);
+/* OPT-IN "bf16x3" dgrad: cnerf_mlp_dgrad (/ _pair) in the same three-plane arithmetic; reads the stash's sign bits, writes the
+ * same gradient workspace (cnerf_mlp_bwd_ws_floats floats) that cnerf_mlp_wgrad (/ _pair) consumes.  packed_bf as above (its
+ * three-plane form also carries the transposed panels). */
+int cnerf_mlp_dgrad_bf(const cnerf_net* net, const void* packed_bf, const float* d_raw, int64_t B, int S, const float* stash,
+                       float* workspace, void* stream);
+/* OPT-IN "bf16x3" weight gradients: cnerf_mlp_wgrad (/ _pair) with the wide GEMMs (>= 8 32x32 tiles per wave) in the three-plane
+ * arithmetic, the narrow ones (heads, encoding columns) exact fp32 in the same grid; same operands, workspace and reduction. */
+int cnerf_mlp_wgrad_bf(const cnerf_net* net, int64_t B, int S, const float* stash, float* workspace, const cnerf_ptrs* grads,
+                       int accumulate, void* stream);
+int cnerf_mlp_wgrad_bf_pair(const cnerf_net* net0, int64_t B0, int S0, const float* stash0, float* workspace0,
+                            const cnerf_ptrs* grads0, const cnerf_net* net1, int64_t B1, int S1, const float* stash1,
+                            float* workspace1, const cnerf_ptrs* grads1, int accumulate, void* stream);
+int cnerf_mlp_dgrad_bf_pair(const cnerf_net* net0, const void* packed_bf0, const float* d_raw0, int64_t B0, int S0,
+                            const float* stash0, float* workspace0, const cnerf_net* net1, const void* packed_bf1,
+                            const float* d_raw1, int64_t B1, int S1, const float* stash1, float* workspace1, void* stream);
 
 /* Backward of the above (autograd of R:37-52 / H:107-130): d_raw[M,C] -> gradients of every parameter
  * tensor.  `grads` holds device pointers laid out like `params`; accumulate!=0 adds into them.
@@ -154,7 +175,11 @@ int cnerf_composite_bwd(const float* raw, int raw_ch, const float* z, const floa
  * inds[B,Nf] int64 (searchsorted right=True result, the bit-exact parity target) optional.
  * The pdf normaliser sum(weights + 1e-5) (H:213) is associated exactly as ATen's CPU `sum` kernel does it (8-float vectors, four
  * interleaved accumulators, tail, lanes in order) and the CDF scan is carried in fp64 like ATen's `cumsum`: the indices equal the
- * reference's CPU run bit for bit, CDF ties (the u = 1.0 sample of the deterministic test-time stream) included. */
+ * reference's CPU run bit for bit, CDF ties (the u = 1.0 sample of the deterministic test-time stream) included.
+ * PLATFORM OF THAT GUARANTEE: the reference run on the CPU with ATen's AVX2 / AVX-512 sum kernels (x86-64; what torch 2.x
+ * dispatches to on the hosts this was checked on).  A reference run on a GPU, or on a CPU whose ATen associates `sum`
+ * differently (NEON, ATEN_CPU_CAPABILITY=default), differs from it — and from this library — by one ulp of the normaliser,
+ * which moves the index of samples sitting exactly on a CDF tie; away from ties the indices are association-independent. */
 int cnerf_sample_pdf(const float* bins, const float* weights, const float* u, int64_t u_row_stride,
                      int64_t B, int Nb, int Nf, float* samples, int64_t* inds, void* stream);
 /* a8+a9 fused for render_rays (R:395-399,415): z_mid, sample_pdf(z_mid, weights[:,1:-1]), sort of the

@@ -29,6 +29,13 @@ def timeit(fn, reps=REPS):
     return e0.elapsed_time(e1) / reps
 
 
+def spec_g_floats(lib, net, Mp):
+    """floats of the dZ part of the backward workspace (g_rows * Mp): the split partials follow it"""
+    import ctypes as C
+    a, b = lib.cnerf_mlp_bwd_ws_floats(C.byref(net), 32 * 4096), lib.cnerf_mlp_bwd_ws_floats(C.byref(net), 32 * 4096 + 32)
+    return (b - a) * (Mp // 32)        # (the partial slices do not grow between these two sizes)
+
+
 def main():
     from consistentnerf_amd.run_nerf import _packed
     sd = I.nerf_state_dict(8, 256, 10, 4, 5, True, seed=21)
@@ -67,6 +74,41 @@ def main():
             print(f"          fwd bf16 x{planes} (inference, opt-in) {t_bf:7.3f} ms = {tf('fwd', t_bf):7.1f} TFLOP/s fp32-equivalent, "
                   f"{t_inf / t_bf:5.2f}x the fp32 kernel  (per-wave panel streaming instead of the shared LDS ring: {t_pw:7.3f} ms)",
                   flush=True)
+        # the opt-in bf16x3 TRAINING forward (same stash): time, and its stash / raw against the fp32 kernel's
+        pk3 = ops.pack_weights_bf(spec, m.kernel_tensors(), 3)
+        raw3, stash3 = ops.mlp_forward_bf_train(spec, pk3, B, S, rays=rays, z=z)
+        t_tr3 = timeit(lambda: ops.mlp_forward_bf_train(spec, pk3, B, S, rays=rays, z=z))
+        torch.cuda.synchronize()
+        d_raw3 = float((raw3 - raw).abs().max() / raw.abs().max())
+        d_st3 = float((stash3 - stash).abs().max())
+        print(f"          fwd bf16x3 TRAINING (opt-in, stash written) {t_tr3:7.3f} ms = {tf('fwd', t_tr3):7.1f} TFLOP/s fp32-equivalent, "
+              f"{t_tr / t_tr3:5.2f}x the fp32 training forward; raw vs fp32 kernel {d_raw3:.2e} of max, stash max|d| {d_st3:.2e} "
+              f"(activations + sign-bit words reinterpreted as floats)", flush=True)
+        del raw3, stash3
+        # the opt-in bf16x3 dgrad: time, and its gradient workspace against the fp32 kernel's (same stash, same d_raw)
+        lib.cnerf_mlp_dgrad(C.byref(net), ops._p(packed), ops._p(d_raw), B, S, ops._p(stash), ops._p(ws), st())
+        Mp = (M + 31) // 32 * 32
+        ws3 = torch.zeros_like(ws)
+        rc = lib.cnerf_mlp_dgrad_bf(C.byref(net), ops._p(pk3), ops._p(d_raw), B, S, ops._p(stash), ops._p(ws3), st())
+        torch.cuda.synchronize()
+        t_dg3 = timeit(lambda: lib.cnerf_mlp_dgrad_bf(C.byref(net), ops._p(pk3), ops._p(d_raw), B, S, ops._p(stash), ops._p(ws3), st()))
+        ng = spec_g_floats(lib, net, Mp)
+        dG = float((ws3[:ng] - ws[:ng]).abs().max() / ws[:ng].abs().max())
+        print(f"          dgrad bf16x3 (opt-in) rc={rc} {t_dg3:7.3f} ms = {tf('dgrad', t_dg3):7.1f} TFLOP/s fp32-equivalent, {t_dg / t_dg3:5.2f}x "
+              f"the fp32 dgrad; gradient workspace vs fp32 kernel: max|d| {dG:.2e} of max", flush=True)
+        del ws3
+        # the opt-in bf16x3 wgrad (wide GEMMs on the bf16 cores, narrow ones fp32) on the SAME workspace: time + gradients vs fp32
+        lib.cnerf_mlp_dgrad(C.byref(net), ops._p(packed), ops._p(d_raw), B, S, ops._p(stash), ops._p(ws), st())
+        lib.cnerf_mlp_wgrad(C.byref(net), B, S, ops._p(stash), ops._p(ws), C.byref(ptrs), 0, st())
+        grads3 = [torch.zeros_like(g_) for g_ in grads]
+        ptrs3 = ops._ptrs(grads3)
+        rc = lib.cnerf_mlp_wgrad_bf(C.byref(net), B, S, ops._p(stash), ops._p(ws), C.byref(ptrs3), 0, st())
+        torch.cuda.synchronize()
+        t_wg3 = timeit(lambda: lib.cnerf_mlp_wgrad_bf(C.byref(net), B, S, ops._p(stash), ops._p(ws), C.byref(ptrs3), 0, st()))
+        worst = max(float((a_ - b_).abs().max() / b_.abs().max().clamp(min=1e-30)) for a_, b_ in zip(grads3, grads) if b_.numel())
+        print(f"          wgrad bf16x3 (opt-in) rc={rc} {t_wg3:7.3f} ms = {tf('wgrad', t_wg3):7.1f} TFLOP/s fp32-equivalent, {t_wg / t_wg3:5.2f}x "
+              f"the fp32 wgrad; gradients vs fp32 kernel: worst tensor max|d| {worst:.2e} of its max", flush=True)
+        del grads3
         if S == 192:
             keep = (spec, packed, d_raw, B, S, stash)
         else:                                   # both levels are around: the paired backward (one dgrad + one wgrad grid)

@@ -28,6 +28,12 @@ from oracle import nerf_oracle as O
 
 pytestmark = pytest.mark.gpu
 
+# `CNERF_TRAIN_PRECISION=bf16x3 pytest -m gpu` runs this whole suite with the opt-in bf16x3 training arithmetic as the default of
+# every network it covers (run_nerf.training_precision) — at the SAME tolerances.  The few tests that pin the exact-fp32 kernels
+# by NAME, or bit-identity between the Python surface and the exact-fp32 single-call C path, only make sense for the default.
+BF3 = os.environ.get("CNERF_TRAIN_PRECISION", "fp32") == "bf16x3"
+fp32_only = pytest.mark.skipif(BF3, reason="pins the exact-fp32 kernels by name / bit-identity with the fp32 single-call C path")
+
 
 @pytest.fixture(scope="module")
 def dev():
@@ -512,6 +518,40 @@ def test_render_rays_golden(dev, tag, D, W, Nc, Nf, perturb, white, noise, lindi
         check_param_grads(fine, g, "gf.", "gf.", rtol=2e-1, l2tol=1e-1)
     else:
         check_param_grads(coarse, g, "gc.", "gc.", rtol=2e-3, l2tol=1e-3)
+
+
+def _trained_models(g, dev=None):
+    from consistentnerf_amd.run_nerf_helpers import NeRF
+    out = []
+    for tag in ("c.", "f."):
+        m = NeRF(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
+        m.load_state_dict({k[len(tag):]: T(g[k]) for k in g if k.startswith(tag)}, strict=True)
+        out.append(m.to(dev) if dev is not None else m)
+    return out
+
+
+def test_render_rays_trained_network_free_running(dev):
+    """a3 END TO END, FREE-RUNNING, on a well-conditioned network.  Fixture `render_rays_trained` = the
+    reference itself trained the C2 networks 200 steps on the analytic scene (make_golden.py::fx_trained; the weights are inputs
+    here) and rendered 1024 held-out rays through its own render_rays, with perturb = 1 (pytest streams) and test-time (perturb =
+    0).  The HIP path renders the same rays from the same weights with NOTHING teacher-forced — its own coarse pass, its own
+    resampled depths, its own fine pass — and must match the reference's maps to 1e-5 (rgb, acc), 1e-5 * far (depth).  (On the
+    random-init fixtures this comparison is bounded at 5e-3 by conditioning; a trained network does not amplify.)"""
+    from consistentnerf_amd import run_nerf_view as V
+    g = golden("render_rays_trained")
+    coarse, fine = _trained_models(g, dev)
+    rays = T(g["rays"], dev)
+    far = float(g["near_far"][1])
+    for tag, perturb in (("p1.", 1.0), ("p0.", 0.0)):
+        with torch.no_grad():
+            ret = V.render_rays(rays, pytest=True, **_kwargs(coarse, fine, 64, 128, perturb, False, 0.0, False))
+        print(f"  perturb = {perturb}:")
+        for k, tol in (("rgb0", 5e-6), ("acc0", 5e-6), ("depth0", 5e-6 * far), ("rgb_map", 1e-5), ("acc_map", 1e-5),
+                       ("depth_map", 1e-5 * far), ("z_std", 3e-5 * far)):       # measured 1e-6 / 5e-7 / 5e-5
+            check(ret[k], g[tag + k], tol, k)
+        mse = float(((ret["rgb_map"].cpu() - T(g[tag + "rgb_map"])) ** 2).mean())
+        print(f"  PSNR-equivalent of the rgb difference: {-10 * np.log10(max(mse, 1e-30)):.1f} dB")
+        assert mse <= 1e-10            # >= 100 dB
 
 
 def test_render_full_image_and_rays(dev):
@@ -1166,6 +1206,7 @@ def test_in_loop_consistency_golden(dev):
         check_param_grads(coarse, g, tag + ".gc.__full__", tag + ".gc.", rtol=2e-1, l2tol=1e-1)
 
 
+@fp32_only
 @pytest.mark.parametrize("Nf,vd,perturb", [(128, True, 1.0), (0, True, 1.0), (32, False, 0.0)])
 def test_render_fwd_bwd_single_call_equals_python_surface(dev, Nf, vd, perturb):
     """cnerf_render_fwd / cnerf_render_bwd (render_rays and its autograd as one C call each) against the
@@ -1311,6 +1352,7 @@ def test_wgrad_beyond_128_point_ranges(dev):
         assert float((w.double() - ref).abs().max()) <= 2e-5 * scale, f"tensor {i}"
 
 
+@fp32_only
 def test_inference_runs_the_inference_kernel(dev):
     """Under torch.no_grad() (render_path, evaluation) the forward must be the stash-free kernel: a Function sees
     needs_input_grad = True for parameters even when grad mode is off, which once made every inference pass write a
@@ -1335,6 +1377,7 @@ def test_inference_runs_the_inference_kernel(dev):
     assert torch.equal(a["rgb_map"], b["rgb_map"].detach())
 
 
+@fp32_only
 def test_autograd_usage_patterns(dev):
     """Host-side plumbing under less common autograd uses: a frozen coarse network (inference kernel for it, gradients only
     for the fine one), two forward passes before one backward (gradients add up; each pass keeps its own packed weights and
@@ -2016,6 +2059,7 @@ def test_bf16_plane_inference_forward(dev, D, W, tag):
     assert errs["bf16"] > 10 * errs["bf16x2"] and (errs["bf16x2"] > 10 * errs["bf16x3"] or errs["bf16x3"] < 5e-6)
 
 
+@fp32_only
 def test_bf16_plane_inference_is_opt_in_and_never_trains(dev):
     """NeRF.inference_precision routes ONLY graph-free forwards to the bf16 kernel: the default is the exact path, a
     forward that may need gradients stays fp32, render() under no_grad uses it for both levels (ragged chunk, rays from

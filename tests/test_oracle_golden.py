@@ -346,3 +346,25 @@ def test_patch_sampler_and_depth_term_golden():
         gr, = torch.autograd.grad(loss, dp)
         assert torch.equal(loss.detach(), torch.from_numpy(g[f"term_{tag}_loss"]))
         assert np.array_equal(gr.numpy(), g[f"term_{tag}_grad"], equal_nan=True)
+
+
+def test_render_rays_trained_network():
+    """The oracle on a TRAINED network (fixture `render_rays_trained`: the reference trained the C2 networks 200 steps and rendered
+    1024 held-out rays free-running, make_golden.py::fx_trained): 256 of those rays, both perturb settings.  A trained network
+    does not amplify depth differences, so the free-running oracle matches the reference's maps to 1e-5."""
+    g = golden("render_rays_trained")
+    sdc = {k[2:]: T(g[k]) for k in g if k.startswith("c.")}
+    sdf = {k[2:]: T(g[k]) for k in g if k.startswith("f.")}
+    rays, far = T(g["rays"])[::4], float(g["near_far"][1])
+    net = O.NetCfg(8, 256, output_ch=5)
+    for tag, perturb in (("p1.", 1.0), ("p0.", 0.0)):
+        with torch.no_grad():
+            # (the pytest streams are drawn for the fixture's 1024 rays and subsampled like the rays)
+            t_rand = O.pytest_uniform((1024, 64))[::4] if perturb > 0 else None
+            u = O.pytest_uniform((1024, 128))[::4] if perturb > 0 else torch.from_numpy(
+                np.broadcast_to(np.linspace(0., 1., 128), (256, 128)).astype(np.float32).copy())
+            out = O.render_rays(rays, sdc, sdf, net, O.RenderCfg(64, 128, perturb), t_rand, u)
+        for k, tol in (("rgb0", 1e-5), ("depth0", 1e-5 * far), ("rgb_map", 1e-5), ("acc_map", 1e-5), ("depth_map", 1e-5 * far),
+                       ("z_std", 1e-5 * far)):
+            d = float((out[k] - T(g[tag + k])[::4]).abs().max())
+            assert d <= tol, (tag, k, d)
