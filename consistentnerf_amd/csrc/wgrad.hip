@@ -347,7 +347,7 @@ __device__ __forceinline__ void wgrad_body(WgNetC& a, WgJobC& jb, float* lds) {
 template <int AN, int AK, bool BS>
 __device__ __forceinline__ void wgrad_body_bf3(WgNetC& a, WgJobC& jb, float* lds) {
   constexpr int NF = AN + AK;                       // fragments per K-step: A (dZ columns) 0..AN-1, B (H columns) AN..NF-1
-  static_assert(AN * AK >= NF && NF % 2 == 0, "side work is dealt out over the tile pairs");
+  static_assert(AN * AK >= NF, "side work is dealt out over the tile pairs");
   const int split = __builtin_amdgcn_readfirstlane((int)blockIdx.x - jb.first);
   const int tid = threadIdx.x, lane = tid & 63, i31 = lane & 31, hh = lane >> 5;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -417,8 +417,8 @@ __device__ __forceinline__ void wgrad_body_bf3(WgNetC& a, WgJobC& jb, float* lds
     }
   };
   // MFMAs of the K-step whose planes are in `set`, with the production of the next K-step's planes (from buffer nbuf_, K-step
-  // nks of that slab, into set ^ 1) dealt out behind the tile pairs: slot j reads half (j & 1) of fragment j/2 + 1 and splits
-  // half (j & 1) of fragment j/2 (read two slots earlier); fragment 0 is read in front of the loop.  DMA: pieces of slab
+  // nks of that slab, into set ^ 1) dealt out behind the tile pairs as half-fragment items: item h reads half (h & 1) of fragment
+  // h/2 + 1 and splits half (h & 1) of fragment h/2 (read one fragment earlier); fragment 0 is read in front of the loop.  DMA: pieces of slab
   // dsl -> buffer dbuf, two per slot in the first eight slots (dsl < 0: none).
   auto phase = [&](int set, bool prod, int nbuf_, int nks, int dsl, int dbuf) __attribute__((always_inline)) {
     if (prod) { rd(nbuf_, nks, 0, 0); rd(nbuf_, nks, 0, 1); }
@@ -430,17 +430,19 @@ __device__ __forceinline__ void wgrad_body_bf3(WgNetC& a, WgJobC& jb, float* lds
         const int j = x * AK + y;
         products<3>(acc[x][y], pl[set][x], pl[set][AN + y]);
         if (prod) {
-          if (j < 2 * NF) {
-            const int f = j >> 1, h = j & 1;
-            if (f + 1 < NF) rd(nbuf_, nks, f + 1, h);
-            sp(set ^ 1, f, h);
+          // half-fragment items h = 0 .. 2 NF - 1 (fragment h / 2, half h & 1), HPS of them behind every tile pair
+          constexpr int HPS = (2 * NF + AN * AK - 1) / (AN * AK);
+#pragma unroll
+          for (int h = j * HPS; h < (j + 1) * HPS && h < 2 * NF; ++h) {
+            const int f = h >> 1, hf = h & 1;
+            if (f + 1 < NF) rd(nbuf_, nks, f + 1, hf);
+            sp(set ^ 1, f, hf);
           }
         }
         if (dsl >= 0 && j < 8) { piece(dsl, dbuf, 2 * j); piece(dsl, dbuf, 2 * j + 1); }
         __builtin_amdgcn_sched_barrier(0);
       }
   };
-  static_assert(AN * AK >= 2 * NF || true, "");
   // prologue: slab 0 lands, slab 1 is on its way, the planes of K-step 0 are produced in the open
 #pragma unroll
   for (int i = 0; i < 2 * TM / NWAVES; ++i) piece(0, 0, i);
