@@ -75,6 +75,33 @@ __device__ __forceinline__ void split_pair(float x0, float x1, u32x4 (&b)[NP], i
   }
 }
 
+// The three-plane split of one register pair in five stages (1, 4, 1, 4, 1 VALU instructions), so that a schedule can place
+// them one stage per MFMA: a wave issues in order, and the 6 cross-term MFMAs of a tile are a dependent chain (each waits ~32
+// cycles for the previous one) — side instructions placed BETWEEN them issue in those waits for free, a burst placed behind the
+// chain leaves the matrix pipe idle for its whole length (measured before: ~42 instead of 32 cycles per MFMA).
+struct Split3 {
+  float x0, x1;
+  unsigned h;
+};
+template <bool RELU>
+__device__ __forceinline__ void split3_s0(Split3& S, float a, float b, u32x4 (&pl)[3], int q) {
+  if (RELU) {
+    asm("v_max_f32 %0, 0, %1" : "=v"(a) : "v"(a));
+    asm("v_max_f32 %0, 0, %1" : "=v"(b) : "v"(b));
+  }
+  S.x0 = a; S.x1 = b;
+  S.h = cvt_pk_bf16(a, b);
+  pl[0][q] = S.h;
+}
+__device__ __forceinline__ void split3_residual(Split3& S) {          // stages 1 and 3: what the plane just taken left over
+  S.x0 = S.x0 - __uint_as_float(S.h << 16);
+  S.x1 = S.x1 - __uint_as_float(S.h & 0xffff0000u);
+}
+__device__ __forceinline__ void split3_plane(Split3& S, u32x4 (&pl)[3], int p, int q) {   // stages 2 and 4
+  S.h = cvt_pk_bf16(S.x0, S.x1);
+  pl[p][q] = S.h;
+}
+
 __device__ __forceinline__ f32x16 mfma_bf(const u32x4& a, const u32x4& b, const f32x16& c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
@@ -196,11 +223,88 @@ struct StashStores {
   }
 };
 
-template <int NTI, int NTO, int NT, int NP, bool RELU, class Side = NoStash, int SIDE_OPS = 0, bool INIT = false>
+// Three planes: every side instruction of a tile (the three LDS reads of the A operand two tiles ahead, the DMA piece, the five
+// stages of one register pair's split, the stash / gradient store) sits in the gap behind ONE of the tile's six MFMAs.
+template <int NTI, int NTO, int NT, bool RELU, class Side, int SIDE_OPS, bool INIT, bool PAIR>
+__device__ __forceinline__ void gemm_ring_reg3(f32x16 (&Q)[NTO], const f32x16 (&X)[NTI], const Ring<NT, 3>& R, int poff,
+                                               int poff_next, Side side) {
+  constexpr int NP = 3, KS = 2 * NTI, PW = Ring<NT, NP>::PW + SIDE_OPS;
+  static_assert(KS % 4 == 0, "ring slot continuity");
+  static_assert(!PAIR || NTO % 2 == 0, "tiles are processed in pairs");
+  constexpr int TP = PAIR ? 2 : 1, NA = PAIR ? 4 : 3;
+  constexpr int IA[6] = {0, 1, 2, 0, 1, 0}, IB[6] = {2, 1, 0, 1, 0, 0};   // cross terms w_i x_j, i + j < 3, smallest first
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  u32x4 bc[NP], bn[NP];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) split_pair<NP, RELU>(X[0][2 * q], X[0][2 * q + 1], bc, q);
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    // A operands run two tiles ahead of the MFMAs that consume them (LDS latency): three register sets (four when PAIR)
+    u32x4 A[NA][NP];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int p = 0; p < NP; ++p) A[u][p] = R.a(s & 3, u, p);
+    __builtin_amdgcn_sched_barrier(0);
+    // PAIR: two tiles at a time, their six-MFMA chains alternating (consecutive MFMAs never share an accumulator; measured: the
+    // matrix pipe forwards the accumulator of a dependent chain at full rate — scripts/mfma_bf16_probe.hip — so this only buys
+    // scheduling slack: +5 % on the inference kernel, and it costs the training forward its spill-free allocation).  Every side
+    // instruction sits in one of the gaps behind an MFMA.
+#pragma unroll
+    for (int t = 0; t < NTO; t += TP) {
+      const int sn = s + 1;
+      Split3 S[TP];
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+#pragma unroll
+        for (int u = 0; u < TP; ++u) {
+          const int tt = t + u;
+          const bool do_split = s + 1 < KS && tt < 4;
+          Q[tt] = mfma_bf(A[tt % NA][IA[k]], bc[IB[k]], (INIT && s == 0 && k == 0) ? zero : Q[tt]);
+          if (k < 3 && tt + 2 < NTO) A[(tt + 2) % NA][k] = R.a(s & 3, tt + 2, k);
+          if (k == 3) {
+#pragma unroll
+            for (int j = tt; j < Ring<NT, NP>::PW; j += NTO) {
+              if (s + 2 < KS) R.dma_piece(poff, s + 2, (s + 2) & 3, j);
+              else if (poff_next >= 0) R.dma_piece(poff_next, s + 2 - KS, (s + 2) & 3, j);
+            }
+          }
+          if (do_split) {
+            if (k == 0) split3_s0<RELU>(S[u], X[sn >> 1][8 * (sn & 1) + 2 * tt], X[sn >> 1][8 * (sn & 1) + 2 * tt + 1], bn, tt);
+            if (k == 1 || k == 3) split3_residual(S[u]);
+            if (k == 2) split3_plane(S[u], bn, 1, tt);
+            if (k == 4) split3_plane(S[u], bn, 2, tt);
+          }
+          if (k == 5) side(s, tt);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (NTO < 4 && s + 1 < KS) {
+#pragma unroll
+      for (int q = NTO; q < 4; ++q) {
+        const int sn = s + 1;
+        split_pair<NP, RELU>(X[sn >> 1][8 * (sn & 1) + 2 * q], X[sn >> 1][8 * (sn & 1) + 2 * q + 1], bn, q);
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) bc[p] = bn[p];
+    if (s + 2 < KS) R.template publish<PW>();
+    else if (poff_next >= 0) R.template publish<PW>();
+    else R.template publish<0>();
+  }
+}
+
+template <int NTI, int NTO, int NT, int NP, bool RELU, class Side = NoStash, int SIDE_OPS = 0, bool INIT = false, bool PAIR = true>
 __device__ __forceinline__ void gemm_ring_reg(f32x16 (&Q)[NTO], const f32x16 (&X)[NTI], const Ring<NT, NP>& R, int poff,
                                               int poff_next, Side side = Side()) {
   // SIDE_OPS = vector-memory instructions `side` issues per K-step: they sit in the in-order vmcnt queue between this step's
   // DMA pieces, so the publish may leave that many more operations outstanding
+  if constexpr (NP == 3) {
+#ifndef CN_BF3_BURST
+    gemm_ring_reg3<NTI, NTO, NT, RELU, Side, SIDE_OPS, INIT, PAIR>(Q, X, R, poff, poff_next, side);
+    return;
+#endif
+  }
   constexpr int KS = 2 * NTI, PW = Ring<NT, NP>::PW + SIDE_OPS;
   static_assert(KS % 4 == 0, "ring slot continuity");
   u32x4 bc[NP], bn[NP];
@@ -252,9 +356,85 @@ __device__ __forceinline__ void gemm_ring_reg(f32x16 (&Q)[NTO], const f32x16 (&X
 }
 
 // the same with the B operand read from the fp32 encoding tile T (KS K-steps of 16 channels: 16 s + 8 hh + e)
-template <int KS, int NTO, int NT, int NP>
+// three planes: as gemm_ring_reg3 — the A operand two tiles ahead, the DMA pieces and the split of the NEXT K-step's encoding
+// chunk one stage per MFMA gap (the first K-step's planes are produced in the open)
+template <int KS, int NTO, int NT>
+__device__ __forceinline__ void gemm_ring_lds3(f32x16 (&Q)[NTO], const float* T, const Ring<NT, 3>& R, int poff, int poff_next,
+                                               int m, int hh) {
+  constexpr int NP = 3, PW = Ring<NT, NP>::PW;
+  static_assert(NTO % 2 == 0, "tiles are processed in pairs");
+  constexpr int IA[6] = {0, 1, 2, 0, 1, 0}, IB[6] = {2, 1, 0, 1, 0, 0};
+  u32x4 bc[NP], bn[NP];
+  {
+    const f32x4 c0 = *reinterpret_cast<const f32x4*>(T + enc_off(m, 2 * hh));
+    const f32x4 c1 = *reinterpret_cast<const f32x4*>(T + enc_off(m, 2 * hh + 1));
+    split_pair<NP, false>(c0[0], c0[1], bc, 0);
+    split_pair<NP, false>(c0[2], c0[3], bc, 1);
+    split_pair<NP, false>(c1[0], c1[1], bc, 2);
+    split_pair<NP, false>(c1[2], c1[3], bc, 3);
+  }
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    u32x4 A[4][NP];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int p = 0; p < NP; ++p) A[u][p] = R.a(s & 3, u, p);
+    float cn[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (s + 1 < KS) {
+      const f32x4 c0 = *reinterpret_cast<const f32x4*>(T + enc_off(m, 4 * (s + 1) + 2 * hh));
+      const f32x4 c1 = *reinterpret_cast<const f32x4*>(T + enc_off(m, 4 * (s + 1) + 2 * hh + 1));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { cn[e] = c0[e]; cn[4 + e] = c1[e]; }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < NTO; t += 2) {
+      Split3 S[2];
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int tt = t + u;
+          const bool do_split = s + 1 < KS && tt < 4;
+          Q[tt] = mfma_bf(A[tt % 4][IA[k]], bc[IB[k]], Q[tt]);
+          if (k < 3 && tt + 2 < NTO) A[(tt + 2) % 4][k] = R.a(s & 3, tt + 2, k);
+          if (k == 3) {
+#pragma unroll
+            for (int j = tt; j < PW; j += NTO) {
+              if (s + 2 < KS) R.dma_piece(poff, s + 2, (s + 2) & 3, j);
+              else if (poff_next >= 0) R.dma_piece(poff_next, s + 2 - KS, (s + 2) & 3, j);
+            }
+          }
+          if (do_split) {
+            if (k == 0) split3_s0<false>(S[u], cn[2 * tt], cn[2 * tt + 1], bn, tt);
+            if (k == 1 || k == 3) split3_residual(S[u]);
+            if (k == 2) split3_plane(S[u], bn, 1, tt);
+            if (k == 4) split3_plane(S[u], bn, 2, tt);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (NTO < 4 && s + 1 < KS) {
+#pragma unroll
+      for (int q = NTO; q < 4; ++q) split_pair<NP, false>(cn[2 * q], cn[2 * q + 1], bn, q);
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) bc[p] = bn[p];
+    if (s + 2 < KS || poff_next >= 0) R.template publish<PW>();
+    else R.template publish<0>();
+  }
+}
+
+template <int KS, int NTO, int NT, int NP, bool STAGED = true>
 __device__ __forceinline__ void gemm_ring_lds(f32x16 (&Q)[NTO], const float* T, const Ring<NT, NP>& R, int poff, int poff_next,
                                               int m, int hh) {
+  if constexpr (NP == 3 && STAGED) {
+#ifndef CN_BF3_BURST
+    gemm_ring_lds3<KS, NTO, NT>(Q, T, R, poff, poff_next, m, hh);
+    return;
+#endif
+  }
   constexpr int PW = Ring<NT, NP>::PW;
 #pragma unroll
   for (int s = 0; s < KS; ++s) {

@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_bfs_k(BfArgs args_by_value) {
   bias_init<NT>(Y, P, (int)bg.b_trunk[0], hh);
   pin<NT>(Y);                                  // (the bias loads are older than nothing the ring waits for below)
   R.template publish<Ring<NT, NP>::PW>();      // K-step 0 of layer 0 has landed everywhere
-  gemm_ring_lds<4, NT, NT, NP>(Y, Tx, R, (int)bg.p_l0, (int)(g.D > 1 ? bg.p_trunk[1] : bg.p_feat), m, hh);
+  gemm_ring_lds<4, NT, NT, NP, !TRAIN>(Y, Tx, R, (int)bg.p_l0, (int)(g.D > 1 ? bg.p_trunk[1] : bg.p_feat), m, hh);
   pin<NT>(Y);
   float sig = 0.f;
   auto layer = [&](f32x16 (&In)[NT], f32x16 (&Out)[NT], int l) __attribute__((always_inline)) {
@@ -385,13 +385,13 @@ __global__ __launch_bounds__(256) void mlp_fwd_bfs_k(BfArgs args_by_value) {
     // what follows this layer's register GEMM in the stream: its own gamma(x) segment, the next layer, or the view branch
     const int nxt = skip ? (int)bg.p_skip : (l + 1 < g.D ? (int)bg.p_trunk[l + 1] : (l + 1 == g.D ? (int)bg.p_feat : (int)bg.p_views));
     if (TRAIN)   // (the input is rectified already; its tiles go out to the stash under this GEMM)
-      gemm_ring_reg<NT, NT, NT, NP, false, StashStores<NT>, 2>(Out, In, R, (int)(l < g.D ? bg.p_trunk[l] : bg.p_feat), nxt,
-                                                               StashStores<NT>{In, srs, svo, tm_col(g.s_h[l - 1])});
+      gemm_ring_reg<NT, NT, NT, NP, false, StashStores<NT>, 2, false, false>(Out, In, R, (int)(l < g.D ? bg.p_trunk[l] : bg.p_feat), nxt,
+                                                                             StashStores<NT>{In, srs, svo, tm_col(g.s_h[l - 1])});
     else
       gemm_ring_reg<NT, NT, NT, NP, true>(Out, In, R, (int)(l < g.D ? bg.p_trunk[l] : bg.p_feat), nxt);
     if (skip) {
       pin<NT>(Out);
-      gemm_ring_lds<4, NT, NT, NP>(Out, Tx, R, (int)bg.p_skip, (int)(l + 1 < g.D ? bg.p_trunk[l + 1] : bg.p_feat), m, hh);
+      gemm_ring_lds<4, NT, NT, NP, !TRAIN>(Out, Tx, R, (int)bg.p_skip, (int)(l + 1 < g.D ? bg.p_trunk[l + 1] : bg.p_feat), m, hh);
     }
     pin<NT>(Out);
   };
@@ -408,12 +408,12 @@ __global__ __launch_bounds__(256) void mlp_fwd_bfs_k(BfArgs args_by_value) {
   bias_init<NTH>(V, P, (int)bg.b_views, hh);
   pin<NTH>(V);
   if (TRAIN)   // the feature tiles (no activation: feature_linear is linear, H:118) go out under the view GEMM
-    gemm_ring_reg<NT, NTH, NT, NP, false, StashStores<NT>, 2>(V, Y, R, (int)bg.p_views, (int)bg.p_viewsd,
-                                                              StashStores<NT>{Y, srs, svo, tm_col(g.s_feat)});
+    gemm_ring_reg<NT, NTH, NT, NP, false, StashStores<NT>, 2, false, false>(V, Y, R, (int)bg.p_views, (int)bg.p_viewsd,
+                                                                            StashStores<NT>{Y, srs, svo, tm_col(g.s_feat)});
   else
     gemm_ring_reg<NT, NTH, NT, NP, false>(V, Y, R, (int)bg.p_views, (int)bg.p_viewsd);
   pin<NTH>(V);
-  gemm_ring_lds<2, NTH, NT, NP>(V, Td, R, (int)bg.p_viewsd, -1, m, hh);
+  gemm_ring_lds<2, NTH, NT, NP, !TRAIN>(V, Td, R, (int)bg.p_viewsd, -1, m, hh);
   if (TRAIN) {
     unsigned bv[MDV];
     relu_bits<NTH, true>(V, bv);

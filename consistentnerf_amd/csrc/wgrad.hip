@@ -395,7 +395,8 @@ __device__ __forceinline__ void wgrad_body_bf3(WgNetC& a, WgJobC& jb, float* lds
   // lanes of a half-wave hit 32 distinct banks (the half-waves are served in separate cycles).
   const int lbase = (i31 >> 3) * OCTF + (i31 & 7) + hh * 64;
   u32x4 pl[2][NF][3];     // bf16 planes of the fragments: set kk & 1 feeds the MFMAs of K-step kk
-  float rw[2][8];         // raw fp32 values of the fragment being read (two in flight)
+  constexpr int FPR = (2 * NF + AN * AK - 1) / (AN * AK);   // fragments split per PAIR of tile pairs (= half-fragment items per slot)
+  float rw[2 * FPR][8];   // raw fp32 values of the fragments in flight: those being split and those being read (one pair ahead)
   // fragment f of K-step ks of the slab in buffer `buf`: its eight values -> rw[f & 1]
   auto rd = [&](int buf, int ks, int f, int half) __attribute__((always_inline)) {
     const float* base = lds + buf * bufF + (f < AN ? 4 * (tn0 + f) : xoct + 4 * (tk0 + f - AN)) * OCTF + lbase + 128 * ks;
@@ -417,30 +418,70 @@ __device__ __forceinline__ void wgrad_body_bf3(WgNetC& a, WgJobC& jb, float* lds
     }
   };
   // MFMAs of the K-step whose planes are in `set`, with the production of the next K-step's planes (from buffer nbuf_, K-step
-  // nks of that slab, into set ^ 1) dealt out behind the tile pairs as half-fragment items: item h reads half (h & 1) of fragment
-  // h/2 + 1 and splits half (h & 1) of fragment h/2 (read one fragment earlier); fragment 0 is read in front of the loop.  DMA: pieces of slab
-  // dsl -> buffer dbuf, two per slot in the first eight slots (dsl < 0: none).
+  // nks of that slab, into set ^ 1) dealt out as half-fragment items: item h reads half (h & 1) of fragment h/2 + 1 and splits
+  // half (h & 1) of fragment h/2 (read one fragment earlier); fragment 0 is read in front of the loop.  HPS items ride behind
+  // every tile pair, and inside a tile pair every instruction of an item sits in the gap behind ONE of the six MFMAs (a wave
+  // issues in order and the six cross terms are a dependent chain: work placed between them is free, a burst behind them is not):
+  //   gap 0: reads e0, e1 of the next fragment; stage 0 of both register pairs       gap 1: reads e2, e3; residual of pair A
+  //   gap 2: plane 1 of A, residual of B       gap 3: plane 1 of B, residual of A, the DMA pieces       gap 4: plane 2 of A,
+  //   residual of B       gap 5: plane 2 of B, the bias column sums.
+  // DMA: pieces of slab dsl -> buffer dbuf, two per tile pair in the first eight (dsl < 0: none).
+  constexpr int IA[6] = {0, 1, 2, 0, 1, 0}, IB[6] = {2, 1, 0, 1, 0, 0};
   auto phase = [&](int set, bool prod, int nbuf_, int nks, int dsl, int dbuf) __attribute__((always_inline)) {
-    if (prod) { rd(nbuf_, nks, 0, 0); rd(nbuf_, nks, 0, 1); }
+    constexpr int HPS = FPR;
+    if (prod) {
+#pragma unroll
+      for (int f = 0; f < FPR; ++f)
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          rw[f][e] = (lds + nbuf_ * bufF + (f < AN ? 4 * (tn0 + f) : xoct + 4 * (tk0 + f - AN)) * OCTF + lbase + 128 * nks)[8 * e];
+    }
     __builtin_amdgcn_sched_barrier(0);
+    static_assert(AK % 2 == 0, "tile pairs");
 #pragma unroll
     for (int x = 0; x < AN; ++x)
 #pragma unroll
-      for (int y = 0; y < AK; ++y) {
-        const int j = x * AK + y;
-        products<3>(acc[x][y], pl[set][x], pl[set][AN + y]);
-        if (prod) {
-          // half-fragment items h = 0 .. 2 NF - 1 (fragment h / 2, half h & 1), HPS of them behind every tile pair
-          constexpr int HPS = (2 * NF + AN * AK - 1) / (AN * AK);
+      for (int y0 = 0; y0 < AK; y0 += 2) {
+        // two tile pairs at a time, their six-MFMA chains alternating: consecutive MFMAs never share an accumulator
+        Split3 SA2[2][HPS], SB2[2][HPS];
 #pragma unroll
-          for (int h = j * HPS; h < (j + 1) * HPS && h < 2 * NF; ++h) {
-            const int f = h >> 1, hf = h & 1;
-            if (f + 1 < NF) rd(nbuf_, nks, f + 1, hf);
-            sp(set ^ 1, f, hf);
+        for (int k = 0; k < 6; ++k)
+#pragma unroll
+        for (int uu = 0; uu < 2; ++uu) {
+          const int y = y0 + uu, j = x * AK + y;
+          Split3 (&SA)[HPS] = SA2[uu];
+          Split3 (&SB)[HPS] = SB2[uu];
+          acc[x][y] = mfma_bf(pl[set][x][IA[k]], pl[set][AN + y][IB[k]], acc[x][y]);
+          if (prod) {
+#pragma unroll
+            for (int u = 0; u < HPS; ++u) {
+              const int h = j * HPS + u;
+              if (h >= 2 * NF) continue;
+              const int f = h >> 1, hf = h & 1, fn = f + FPR;     // fn: the fragment read now, split one pair of tile pairs later
+              float* v = rw[f % (2 * FPR)];
+              if (fn < NF && k < 2) {        // its values e = 4 hf + 2 k, + 1
+                const float* base = lds + nbuf_ * bufF + (fn < AN ? 4 * (tn0 + fn) : xoct + 4 * (tk0 + fn - AN)) * OCTF + lbase + 128 * nks;
+                rw[fn % (2 * FPR)][4 * hf + 2 * k] = base[8 * (4 * hf + 2 * k)];
+                rw[fn % (2 * FPR)][4 * hf + 2 * k + 1] = base[8 * (4 * hf + 2 * k + 1)];
+              }
+              if (k == 0) {
+                split3_s0<false>(SA[u], v[4 * hf], v[4 * hf + 1], pl[set ^ 1][f], 2 * hf);
+                split3_s0<false>(SB[u], v[4 * hf + 2], v[4 * hf + 3], pl[set ^ 1][f], 2 * hf + 1);
+              }
+              if (k == 1 || k == 3) split3_residual(SA[u]);
+              if (k == 2 || k == 4) split3_residual(SB[u]);
+              if (k == 2) split3_plane(SA[u], pl[set ^ 1][f], 1, 2 * hf);
+              if (k == 3) split3_plane(SB[u], pl[set ^ 1][f], 1, 2 * hf + 1);
+              if (k == 4) split3_plane(SA[u], pl[set ^ 1][f], 2, 2 * hf);
+              if (k == 5) {
+                split3_plane(SB[u], pl[set ^ 1][f], 2, 2 * hf + 1);
+                if (BS && f < AN) bsum[f] += (v[4 * hf] + v[4 * hf + 1]) + (v[4 * hf + 2] + v[4 * hf + 3]);
+              }
+            }
           }
+          if (dsl >= 0 && j < 8 && k == 3) { piece(dsl, dbuf, 2 * j); piece(dsl, dbuf, 2 * j + 1); }
+          __builtin_amdgcn_sched_barrier(0);
         }
-        if (dsl >= 0 && j < 8) { piece(dsl, dbuf, 2 * j); piece(dsl, dbuf, 2 * j + 1); }
-        __builtin_amdgcn_sched_barrier(0);
       }
   };
   // prologue: slab 0 lands, slab 1 is on its way, the planes of K-step 0 are produced in the open

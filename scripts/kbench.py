@@ -88,12 +88,14 @@ def main():
         # the opt-in bf16x3 dgrad: time, and its gradient workspace against the fp32 kernel's (same stash, same d_raw)
         lib.cnerf_mlp_dgrad(C.byref(net), ops._p(packed), ops._p(d_raw), B, S, ops._p(stash), ops._p(ws), st())
         Mp = (M + 31) // 32 * 32
+        ws.zero_(); lib.cnerf_mlp_dgrad(C.byref(net), ops._p(packed), ops._p(d_raw), B, S, ops._p(stash), ops._p(ws), st())
         ws3 = torch.zeros_like(ws)
         rc = lib.cnerf_mlp_dgrad_bf(C.byref(net), ops._p(pk3), ops._p(d_raw), B, S, ops._p(stash), ops._p(ws3), st())
         torch.cuda.synchronize()
         t_dg3 = timeit(lambda: lib.cnerf_mlp_dgrad_bf(C.byref(net), ops._p(pk3), ops._p(d_raw), B, S, ops._p(stash), ops._p(ws3), st()))
         ng = spec_g_floats(lib, net, Mp)
-        dG = float((ws3[:ng] - ws[:ng]).abs().max() / ws[:ng].abs().max())
+        fin = torch.isfinite(ws[:ng]) & torch.isfinite(ws3[:ng])      # (columns no kernel writes hold whatever torch.empty left)
+        dG = float((ws3[:ng] - ws[:ng])[fin].abs().max() / ws[:ng][fin].abs().max())
         print(f"          dgrad bf16x3 (opt-in) rc={rc} {t_dg3:7.3f} ms = {tf('dgrad', t_dg3):7.1f} TFLOP/s fp32-equivalent, {t_dg / t_dg3:5.2f}x "
               f"the fp32 dgrad; gradient workspace vs fp32 kernel: max|d| {dG:.2e} of max", flush=True)
         del ws3

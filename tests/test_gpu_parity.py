@@ -1809,12 +1809,13 @@ def test_training_step_merges_the_two_levels_backward(dev):
         return opt.flat_grad.clone(), kinds
     g_sep, k_sep = run(False)
     g_mrg, k_mrg = run(True)
-    assert k_sep.count("mlp_dgrad") == 2 and k_sep.count("mlp_wgrad") == 2
-    assert k_mrg.count("mlp_dgrad") == 1 and k_mrg.count("mlp_wgrad") == 1
+    DG, WG = ("mlp_dgrad_bf3", "mlp_wgrad_bf3") if BF3 else ("mlp_dgrad", "mlp_wgrad")   # (W = 128, viewdirs: covered by bf16x3)
+    assert k_sep.count(DG) == 2 and k_sep.count(WG) == 2
+    assert k_mrg.count(DG) == 1 and k_mrg.count(WG) == 1
     assert torch.equal(g_sep, g_mrg) and float(g_mrg.abs().max()) > 0
     g1, k1 = run(True, both=False)            # the coarse node does not run: the fine node must not park
     g2, k2 = run(False, both=False)
-    assert k1.count("mlp_dgrad") == 1 and torch.equal(g1, g2)
+    assert k1.count(DG) == 1 and torch.equal(g1, g2)
     n_c = sum(p.numel() for p in coarse.parameters())
     assert float(g1[:n_c].abs().max()) == 0.0 and float(g1[n_c:].abs().max()) > 0
     params = [p for m in (coarse, fine) for p in m.kernel_tensors()]
@@ -2379,7 +2380,9 @@ for collective in (("split",) if MODE == "gloo2" else ("split", "capture")):
     if world == 1:      # one rank: the exchange is an identity, the graphed sharded step IS the eager step, bit for bit
         assert l_s == l_1 and dmax == 0.0, (collective, l_s, l_1, dmax)
     else:               # summation order differs: the tolerance of test_two_ranks_product_step_on_one_gpu
-        assert rel_l < 1e-4, (l_s, l_1)
+        # (7 Adam steps of two differently-sharded runs: a trajectory comparison, measured 1e-4 in fp32 and 1.2e-4 in the
+        #  bf16x3 arithmetic, whose point-range sums round differently per shard size)
+        assert rel_l < (2e-4 if os.environ.get("CNERF_TRAIN_PRECISION", "fp32") == "bf16x3" else 1e-4), (l_s, l_1)
         assert dmax < 3e-3 and frac < 0.15, (dmax, frac)     # (7 Adam steps; measured 4.7e-4 / 0.066)
     res[collective] = (rel_l, dmax, frac)
 D.barrier()
@@ -2549,7 +2552,7 @@ def test_c2_full_size_backward_exact(dev, monkeypatch):
     orig = ops.mlp_backward_pair
 
     def spy(*a, **k):
-        seen["args"] = a
+        seen["args"], seen["kw"] = a, k
         return orig(*a, **k)
     monkeypatch.setattr(ops, "mlp_backward_pair", spy)
     torch.manual_seed(11)
@@ -2580,8 +2583,8 @@ def test_c2_full_size_backward_exact(dev, monkeypatch):
     for n, d in worst.items():
         assert d <= 1e-5, f"{n}: rel max diff {d:.3e} vs the fp64 replay"
     # merged == two separate launches, bit for bit, at this size
-    sep_f = ops.mlp_backward(fs, fp, fg, fB, fS, fst)
-    sep_c = ops.mlp_backward(cs, cp, cg, cB, cS, cst)
+    sep_f = ops.mlp_backward(fs, fp, fg, fB, fS, fst, packed_bf=seen["kw"].get("packed_bf0"))     # (None: exact fp32; else the
+    sep_c = ops.mlp_backward(cs, cp, cg, cB, cS, cst, packed_bf=seen["kw"].get("packed_bf1"))     #  same bf16x3 kernels, unmerged)
     for a, b in zip(list(fgr) + list(cgr), sep_f + sep_c):
         assert torch.equal(a, b.reshape(a.shape)), "merged backward differs from the separate launches"
     # forward of the SAME launch, a 512-ray sub-slice, against the CPU oracle
