@@ -22,6 +22,7 @@
 // the packing bound at M = 786 432); split partials are reduced in a fixed order by a second kernel (bit-reproducible
 // run to run).
 #include <math.h>
+#include <type_traits>
 #include <stdlib.h>
 #include <string.h>
 
@@ -387,8 +388,12 @@ __device__ __forceinline__ void wgrad_body_bf3(WgNetC& a, WgJobC& jb, float* lds
     }
   };
   auto landed = [&]() __attribute__((always_inline)) {   // this wave's DMA pieces have landed; everybody's: the barrier
+#ifndef CN_ABL_NOWAIT                                    // (ablation builds, timings only: -DCN_ABL_NOWAIT / NOSPLIT / NOREAD / NOBAR)
     __builtin_amdgcn_s_waitcnt(0x0f70);                  // vmcnt(0)
+#endif
+#ifndef CN_ABL_NOBAR
     __syncthreads();
+#endif
   };
   // LDS image (as wgrad_body): block of column octet o at o*OCTF floats, inside it point p, column c at p*8 + c.  Lane (i, hh)
   // reads column 32x + i of points 16 ks + 8 hh + e: one per-lane base + the immediate (4x*OCTF + 128 ks + 8 e) floats; the 32
@@ -427,7 +432,10 @@ __device__ __forceinline__ void wgrad_body_bf3(WgNetC& a, WgJobC& jb, float* lds
   //   residual of B       gap 5: plane 2 of B, the bias column sums.
   // DMA: pieces of slab dsl -> buffer dbuf, two per tile pair in the first eight (dsl < 0: none).
   constexpr int IA[6] = {0, 1, 2, 0, 1, 0}, IB[6] = {2, 1, 0, 1, 0, 0};
-  auto phase = [&](int set, bool prod, int nbuf_, int nks, int dsl, int dbuf) __attribute__((always_inline)) {
+  // (prod / dma are COMPILE-TIME flags — std::integral_constant arguments — so that the two phases of the slab loop are
+  //  straight-line code: with run-time flags the compiler cut the loop into dozens of basic blocks of a few MFMAs each)
+  auto phase = [&](int set, auto prod_c, int nbuf_, int nks, auto dma_c, int dsl, int dbuf) __attribute__((always_inline)) {
+    constexpr bool prod = decltype(prod_c)::value, dma = decltype(dma_c)::value;
     constexpr int HPS = FPR;
     if (prod) {
 #pragma unroll
@@ -459,27 +467,39 @@ __device__ __forceinline__ void wgrad_body_bf3(WgNetC& a, WgJobC& jb, float* lds
               if (h >= 2 * NF) continue;
               const int f = h >> 1, hf = h & 1, fn = f + FPR;     // fn: the fragment read now, split one pair of tile pairs later
               float* v = rw[f % (2 * FPR)];
+#ifdef CN_ABL_NOREAD
+              if (false) {
+#else
               if (fn < NF && k < 2) {        // its values e = 4 hf + 2 k, + 1
+#endif
                 const float* base = lds + nbuf_ * bufF + (fn < AN ? 4 * (tn0 + fn) : xoct + 4 * (tk0 + fn - AN)) * OCTF + lbase + 128 * nks;
                 rw[fn % (2 * FPR)][4 * hf + 2 * k] = base[8 * (4 * hf + 2 * k)];
                 rw[fn % (2 * FPR)][4 * hf + 2 * k + 1] = base[8 * (4 * hf + 2 * k + 1)];
               }
+#ifdef CN_ABL_NOSPLIT
+              if (k == 0 && false) {
+#else
               if (k == 0) {
+#endif
                 split3_s0<false>(SA[u], v[4 * hf], v[4 * hf + 1], pl[set ^ 1][f], 2 * hf);
                 split3_s0<false>(SB[u], v[4 * hf + 2], v[4 * hf + 3], pl[set ^ 1][f], 2 * hf + 1);
               }
+#ifndef CN_ABL_NOSPLIT
               if (k == 1 || k == 3) split3_residual(SA[u]);
               if (k == 2 || k == 4) split3_residual(SB[u]);
               if (k == 2) split3_plane(SA[u], pl[set ^ 1][f], 1, 2 * hf);
               if (k == 3) split3_plane(SB[u], pl[set ^ 1][f], 1, 2 * hf + 1);
               if (k == 4) split3_plane(SA[u], pl[set ^ 1][f], 2, 2 * hf);
+#endif
               if (k == 5) {
+#ifndef CN_ABL_NOSPLIT
                 split3_plane(SB[u], pl[set ^ 1][f], 2, 2 * hf + 1);
+#endif
                 if (BS && f < AN) bsum[f] += (v[4 * hf] + v[4 * hf + 1]) + (v[4 * hf + 2] + v[4 * hf + 3]);
               }
             }
           }
-          if (dsl >= 0 && j < 8 && k == 3) { piece(dsl, dbuf, 2 * j); piece(dsl, dbuf, 2 * j + 1); }
+          if (dma && j < 8 && k == 3) { piece(dsl, dbuf, 2 * j); piece(dsl, dbuf, 2 * j + 1); }
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -492,13 +512,19 @@ __device__ __forceinline__ void wgrad_body_bf3(WgNetC& a, WgJobC& jb, float* lds
   for (int i = 0; i < 2 * TM / NWAVES; ++i) piece(1, 1, i);
   if (nslab > 0) produce_now(0, 0, 0);
   int cur = 0;
-  for (int sl = 0; sl < nslab; ++sl) {
-    phase(0, true, cur, 1, -1, 0);                       // K-step 2 sl; planes of 2 sl + 1 from the same slab
+  const std::true_type yes{};
+  const std::false_type no{};
+  for (int sl = 0; sl + 1 < nslab; ++sl) {
+    phase(0, yes, cur, 1, no, 0, 0);                     // K-step 2 sl; planes of 2 sl + 1 from the same slab
     landed();                                            // slab sl + 1 has landed, nobody reads slab sl any more
-    phase(1, sl + 1 < nslab, cur ^ 1, 0, sl + 2, cur);   // K-step 2 sl + 1; planes of 2 sl + 2 from slab sl + 1; DMA of slab sl + 2
+    phase(1, yes, cur ^ 1, 0, yes, sl + 2, cur);         // K-step 2 sl + 1; planes of 2 sl + 2 from slab sl + 1; DMA of slab sl + 2
     cur ^= 1;
   }
-  landed();   // (the no-op pieces of the last iterations)
+  if (nslab > 0) {                                       // the last slab: nothing follows
+    phase(0, yes, cur, 1, no, 0, 0);
+    landed();
+    phase(1, no, cur, 0, no, 0, 0);
+  }
   // Epilogue: as wgrad_body (the accumulator layout of a 32x32 MFMA tile is the same)
   const int N = __builtin_amdgcn_readfirstlane(jb.N), K = __builtin_amdgcn_readfirstlane(jb.K);
   const int n_lo = __builtin_amdgcn_readfirstlane(jb.n_lo), ld4 = __builtin_amdgcn_readfirstlane(jb.ld * 4);
