@@ -1,6 +1,7 @@
-// OPT-IN reduced-precision INFERENCE forward of the fused encoding + MLP (never the default, never the training path, never
-// the headline benchmark): the GEMMs of R:37-52 / H:107-130 on v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate) with the
-// operands split into NP bf16 "planes" and fp32 accumulation:
+// OPT-IN bf16-plane forward of the fused encoding + MLP (never the default, never the headline benchmark): inference at 1 / 2 / 3
+// planes, and — three planes only, TRAIN = true — the training forward of the opt-in "bf16x3" training arithmetic, which writes
+// the same stash as mlp_fwd_k (second bench line).  The GEMMs of R:37-52 / H:107-130 on v_mfma_f32_32x32x16_bf16
+// (16x the fp32 MFMA rate nominally) with the operands split into NP bf16 "planes" and fp32 accumulation:
 //     x = x0 + x1 + x2 (each plane the bf16 rounding of what the previous ones left), likewise w
 //     NP = 1  plain bf16:      w0 x0                                             rel. error per product ~2^-9
 //     NP = 2  "bf16x2":        w0 x0 + w0 x1 + w1 x0                             ~2^-16

@@ -489,3 +489,25 @@ def test_psnr_twins_permutation_statistics_have_size_and_power():
     alt = P.twins_statistics(table(2.0, 0), ms, n_perm=3000)
     assert not alt["criterion_D_pass"] and max(alt["T_bias"]["p_two_sided"]) < 0.0125
     assert min(alt["T_pair"]["p_one_sided"]) >= 1.0 / 16 and alt["T_pair"]["smallest_attainable_p"] == 1.0 / 16
+
+
+def test_training_precision_selection(monkeypatch):
+    """run_nerf.training_precision: "fp32" unless opted in; an explicit per-model setting is obeyed as is (an uncovered architecture
+    then fails loudly in the launch); the process-wide default (CNERF_TRAIN_PRECISION) only applies to architectures the bf16x3
+    kernels cover and leaves every other network on the exact-fp32 path."""
+    from consistentnerf_amd import run_nerf as R
+    from consistentnerf_amd.run_nerf_helpers import NeRF
+    big = NeRF(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
+    novd = NeRF(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=0, use_viewdirs=False)
+    small = NeRF(D=2, W=64, input_ch=63, output_ch=4, skips=[4], input_ch_views=27, use_viewdirs=True)
+    monkeypatch.setattr(R, "DEFAULT_TRAINING_PRECISION", "fp32")
+    assert [R.training_precision(m) for m in (big, novd, small)] == ["fp32"] * 3
+    monkeypatch.setattr(R, "DEFAULT_TRAINING_PRECISION", "bf16x3")
+    assert [R.training_precision(m) for m in (big, novd, small)] == ["bf16x3", "fp32", "fp32"]
+    novd.training_precision = "bf16x3"
+    assert R.training_precision(novd) == "bf16x3"          # explicit: obeyed (the launch reports the unsupported architecture)
+    big.training_precision = "fp32"
+    assert R.training_precision(big) == "fp32"
+    big.training_precision = "fp8"
+    with pytest.raises(ValueError):
+        R.training_precision(big)
