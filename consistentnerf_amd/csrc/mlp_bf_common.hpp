@@ -7,7 +7,7 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct BfGeom {                 // byte offsets into the packed buffer of cnerf_pack_weights_bf
-  int64_t p_l0, p_trunk[16], p_skip, p_feat, p_views, p_viewsd;   // bf16 panels [K/16][N/32][NP][32 lanes][2][8]
+  int64_t p_l0, p_trunk[16], p_skip, p_feat, p_views, p_viewsd;   // bf16 panels [K/16][N/32][NP][2 half-waves][32 lanes][8]
   int64_t pt_trunk[16], pt_feat, pt_views;                        // TRANSPOSED panels of the bf16x3 dgrad (NP == 3 only; else -1)
   int64_t b_trunk[16], b_feat, b_views, b_alpha, b_rgb;           // fp32 biases
   int64_t v_alpha, v_rgb;                                         // fp32 head weights [W], [3][W/2]
@@ -126,7 +126,7 @@ __device__ __forceinline__ void products_init(f32x16& q, const u32x4 (&a)[NP], c
 
 struct BfPanel {
   rsrc_t rs;
-  int lane;      // (m * 2 + hh) * 16: this lane's 16 bytes inside a 1 KiB piece
+  int lane;      // lane * 16 = (32 hh + m) * 16: this lane's 16 bytes inside a 1 KiB piece (layout [hh][m][8 bf16])
 };
 
 template <int NTO>
@@ -173,7 +173,7 @@ struct Ring {
   const unsigned char* ring;                        // the same, as a pointer for the ds_reads
   int w;                                            // wave index in the workgroup (scalar)
   int lane16;                                       // lane * 16: the DMA copies a piece lane-linearly
-  int rd16;                                         // (m * 2 + hh) * 16: this lane's A-operand bytes inside a piece
+  int rd16;                                         // lane * 16: this lane's A-operand bytes inside a piece (conflict-free b128)
   // this wave's quarter of K-step `s` of the panel at byte offset `poff` -> slot
   __device__ __forceinline__ void dma(int poff, int s, int slot) const {
 #pragma unroll
@@ -197,8 +197,12 @@ struct Ring {
     // nothing is scheduled across the publish: the ring's only writer is the DMA asm, which the machine scheduler does not
     // see as a store to the LDS the next K-step's ds_reads load from
     __builtin_amdgcn_sched_barrier(0);
+#ifndef CN_ABL_R_NODMA
     __builtin_amdgcn_s_waitcnt(0x0f70 | (OUTSTANDING & 15) | ((OUTSTANDING >> 4) << 14));   // vmcnt only (gfx9 encoding)
+#endif
+#ifndef CN_ABL_R_NOBAR
     __syncthreads();
+#endif
     __builtin_amdgcn_sched_barrier(0);
   }
 };
@@ -228,28 +232,36 @@ struct StashStores {
 template <int NTI, int NTO, int NT, bool RELU, class Side, int SIDE_OPS, bool INIT, bool PAIR>
 __device__ __forceinline__ void gemm_ring_reg3(f32x16 (&Q)[NTO], const f32x16 (&X)[NTI], const Ring<NT, 3>& R, int poff,
                                                int poff_next, Side side) {
-  constexpr int NP = 3, KS = 2 * NTI, PW = Ring<NT, NP>::PW + SIDE_OPS;
+  constexpr int NP = 3, KS = 2 * NTI;
   static_assert(KS % 4 == 0, "ring slot continuity");
   static_assert(!PAIR || NTO % 2 == 0, "tiles are processed in pairs");
-  constexpr int TP = PAIR ? 2 : 1, NA = PAIR ? 4 : 3;
+  static_assert(NTO >= 4, "the publish sits behind tile NTO / 2 - 1, the cross-step prefetch in the last two tiles");
+  constexpr int TP = PAIR ? 2 : 1, NA = 4;
   constexpr int IA[6] = {0, 1, 2, 0, 1, 0}, IB[6] = {2, 1, 0, 1, 0, 0};   // cross terms w_i x_j, i + j < 3, smallest first
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // K-step s + 1 is published in the MIDDLE of K-step s (behind tile NTO/2 - 1), not at its end: the A operands of its first two
+  // tiles are then read in the gaps of the LAST two tiles of K-step s, so that no K-step starts with the four waves' first LDS reads
+  // queued behind one another right after a barrier (ablation: the LDS reads are the largest single cost of these kernels, -23 %
+  // without them).  The DMA of K-step s + 2 still goes out during K-step s: its slot was last read in K-step s - 2.
+  // vector-memory operations this wave has issued in a K-step when it reaches the publish: the DMA pieces dealt to tiles
+  // [0, NTO/2) and the side stores (tiles 0 and 1) — the publish may leave exactly those outstanding.
+  constexpr int MID = NTO / 2;
+  constexpr int PIECES_BEFORE = [] { int n = 0; for (int j = 0; j < Ring<NT, NP>::PW; ++j) n += (j % NTO) < MID; return n; }();
+  constexpr int OUT = PIECES_BEFORE + SIDE_OPS;
   u32x4 bc[NP], bn[NP];
 #pragma unroll
   for (int q = 0; q < 4; ++q) split_pair<NP, RELU>(X[0][2 * q], X[0][2 * q + 1], bc, q);
+  u32x4 A[NA][NP];      // tile g = s NTO + t of the GEMM lives in set g % 4 (NTO is a multiple of 4): reads run two tiles ahead
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int p = 0; p < NP; ++p) A[u][p] = R.a(0, u, p);
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
-    // A operands run two tiles ahead of the MFMAs that consume them (LDS latency): three register sets (four when PAIR)
-    u32x4 A[NA][NP];
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int p = 0; p < NP; ++p) A[u][p] = R.a(s & 3, u, p);
-    __builtin_amdgcn_sched_barrier(0);
-    // PAIR: two tiles at a time, their six-MFMA chains alternating (consecutive MFMAs never share an accumulator; measured: the
-    // matrix pipe forwards the accumulator of a dependent chain at full rate — scripts/mfma_bf16_probe.hip — so this only buys
-    // scheduling slack: +5 % on the inference kernel, and it costs the training forward its spill-free allocation).  Every side
-    // instruction sits in one of the gaps behind an MFMA.
+    // PAIR: two tiles at a time, their six-MFMA chains alternating (the matrix pipe forwards the accumulator of a dependent
+    // chain at full rate — scripts/mfma_bf16_probe.hip — so this only buys scheduling slack: +5 % on the inference kernel).
+    // Every side instruction sits in one of the gaps behind an MFMA.
 #pragma unroll
     for (int t = 0; t < NTO; t += TP) {
       const int sn = s + 1;
@@ -261,36 +273,45 @@ __device__ __forceinline__ void gemm_ring_reg3(f32x16 (&Q)[NTO], const f32x16 (&
           const int tt = t + u;
           const bool do_split = s + 1 < KS && tt < 4;
           Q[tt] = mfma_bf(A[tt % NA][IA[k]], bc[IB[k]], (INIT && s == 0 && k == 0) ? zero : Q[tt]);
-          if (k < 3 && tt + 2 < NTO) A[(tt + 2) % NA][k] = R.a(s & 3, tt + 2, k);
+#ifndef CN_ABL_R_NOLDS      // (ablation builds, timings only: -DCN_ABL_R_NOLDS / NODMA / NOSPLIT / NOSIDE / NOBAR)
+          if (k < 3) {
+            if (tt + 2 < NTO) A[(tt + 2) % NA][k] = R.a(s & 3, tt + 2, k);
+            else if (s + 1 < KS) A[(tt + 2) % NA][k] = R.a((s + 1) & 3, tt + 2 - NTO, k);   // (published behind tile MID - 1)
+          }
+#endif
+#ifndef CN_ABL_R_NODMA
           if (k == 3) {
+#else
+          if (k == 3 && false) {
+#endif
 #pragma unroll
             for (int j = tt; j < Ring<NT, NP>::PW; j += NTO) {
               if (s + 2 < KS) R.dma_piece(poff, s + 2, (s + 2) & 3, j);
               else if (poff_next >= 0) R.dma_piece(poff_next, s + 2 - KS, (s + 2) & 3, j);
             }
           }
+#ifndef CN_ABL_R_NOSPLIT
           if (do_split) {
+#else
+          if (do_split && false) {
+#endif
             if (k == 0) split3_s0<RELU>(S[u], X[sn >> 1][8 * (sn & 1) + 2 * tt], X[sn >> 1][8 * (sn & 1) + 2 * tt + 1], bn, tt);
             if (k == 1 || k == 3) split3_residual(S[u]);
             if (k == 2) split3_plane(S[u], bn, 1, tt);
             if (k == 4) split3_plane(S[u], bn, 2, tt);
           }
+#ifndef CN_ABL_R_NOSIDE
           if (k == 5) side(s, tt);
+#endif
           __builtin_amdgcn_sched_barrier(0);
+          if (k == 5 && tt == MID - 1) {     // K-step s + 1 (or the next panel's K-step 0) is published here
+            if (s + 2 < KS || poff_next >= 0) R.template publish<OUT>();
+            else R.template publish<SIDE_OPS>();      // (no DMA was issued in this K-step: only the side stores may be in flight)
+          }
         }
-    }
-    if (NTO < 4 && s + 1 < KS) {
-#pragma unroll
-      for (int q = NTO; q < 4; ++q) {
-        const int sn = s + 1;
-        split_pair<NP, RELU>(X[sn >> 1][8 * (sn & 1) + 2 * q], X[sn >> 1][8 * (sn & 1) + 2 * q + 1], bn, q);
-      }
     }
 #pragma unroll
     for (int p = 0; p < NP; ++p) bc[p] = bn[p];
-    if (s + 2 < KS) R.template publish<PW>();
-    else if (poff_next >= 0) R.template publish<PW>();
-    else R.template publish<0>();
   }
 }
 
@@ -299,7 +320,7 @@ __device__ __forceinline__ void gemm_ring_reg(f32x16 (&Q)[NTO], const f32x16 (&X
                                               int poff_next, Side side = Side()) {
   // SIDE_OPS = vector-memory instructions `side` issues per K-step: they sit in the in-order vmcnt queue between this step's
   // DMA pieces, so the publish may leave that many more operations outstanding
-  if constexpr (NP == 3) {
+  if constexpr (NP == 3 && NTO >= 4) {       // (the two-tile view GEMM of a W = 128 network keeps the plain schedule below)
 #ifndef CN_BF3_BURST
     gemm_ring_reg3<NTI, NTO, NT, RELU, Side, SIDE_OPS, INIT, PAIR>(Q, X, R, poff, poff_next, side);
     return;

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void mlp_dgrad_bfs_k(BfBwdArgs args_by_value) 
   const int nvalid = a.M - p0 < 32 ? (a.M - p0 > 0 ? (int)(a.M - p0) : 0) : 32;
   const int64_t pc = p < a.M ? p : a.M - 1;
   const bool valid = p < a.M;
-  const BfPanel P{make_rsrc(a.pk, (unsigned)bg.total), (m * 2 + hh) * 16};
+  const BfPanel P{make_rsrc(a.pk, (unsigned)bg.total), lane * 16};
   const rsrc_t srs = make_rsrc(nvalid > 0 ? a.stash + p0 * g.s_rows : nullptr, nvalid > 0 ? (unsigned)(32 * g.s_rows * 4) : 0u);
   const rsrc_t grs = make_rsrc(nvalid > 0 ? a.G + p0 * g.g_rows : nullptr, nvalid > 0 ? (unsigned)(32 * g.g_rows * 4) : 0u);
   const int gvo = valid ? m * 32 + hh * 16 : TM_OOB;
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void mlp_dgrad_bfs_k(BfBwdArgs args_by_value) 
   R.ring = lds_raw;
   R.w = w;
   R.lane16 = lane * 16;
-  R.rd16 = (m * 2 + hh) * 16;
+  R.rd16 = lane * 16;
   // start the panel stream before anything else: K-steps 0 and 1 of views_linears^T
   R.dma((int)bg.pt_views, 0, 0);
   R.dma((int)bg.pt_views, 1, 1);

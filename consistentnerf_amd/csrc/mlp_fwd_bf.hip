@@ -68,7 +68,10 @@ __global__ void pack_bf_k(BfPackArgs a_by_value) {
     unsigned short* dst = reinterpret_cast<unsigned short*>(a.out + j.dst);
     for (int p = 0; p < NP; ++p) {
       const unsigned h = bf16_rne(w);
-      dst[((((int64_t)(s * NTO + to) * NP + p) * 32 + i) * 2 + hh) * 8 + e] = (unsigned short)h;
+      // piece layout [hh][i][e]: lane (i, hh) = lane 32 hh + i reads its 16 bytes at lane * 16 — consecutive lanes, consecutive
+      // 16-byte chunks (with [i][hh] the lanes of a half-wave sat 32 bytes apart: a 2-way LDS bank conflict on every ds_read_b128
+      // of the ring, SQ_LDS_BANK_CONFLICT = 50 % of the active LDS cycles)
+      dst[((((int64_t)(s * NTO + to) * NP + p) * 2 + hh) * 32 + i) * 8 + e] = (unsigned short)h;
       w = w - __uint_as_float(h << 16);                          // exact: what this plane left over
     }
   }
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(64) void mlp_fwd_bf_k(BfArgs args_by_value) {
   const int nvalid = a.M - p0 < 32 ? (int)(a.M - p0) : 32;
   const int64_t pc = p < a.M ? p : a.M - 1;
   const int64_t ray = pc / a.S;
-  const BfPanel P{make_rsrc(a.pk, (unsigned)bg.total), (m * 2 + hh) * 16};
+  const BfPanel P{make_rsrc(a.pk, (unsigned)bg.total), lane * 16};
 
   float x[3] = {0.f, 0.f, 0.f}, v[3] = {0.f, 0.f, 0.f};
   if (a.pts != nullptr) {
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_bfs_k(BfArgs args_by_value) {
   const int nvalid = a.M - p0 < 32 ? (a.M - p0 > 0 ? (int)(a.M - p0) : 0) : 32;
   const int64_t pc = p < a.M ? p : a.M - 1;
   const int64_t ray = pc / a.S;
-  const BfPanel P{make_rsrc(a.pk, (unsigned)bg.total), (m * 2 + hh) * 16};
+  const BfPanel P{make_rsrc(a.pk, (unsigned)bg.total), lane * 16};
   // training: this WAVE's stash tile row (32 points; tile-major, mlp_common.hpp).  Lanes of padding points — and whole waves
   // past the last point, whose resource is empty — address out of range: the hardware drops their stores.
   const rsrc_t srs = make_rsrc(TRAIN && nvalid > 0 ? a.stash + p0 * g.s_rows : nullptr,
@@ -319,7 +322,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_bfs_k(BfArgs args_by_value) {
   R.ring = lds_raw;
   R.w = w;
   R.lane16 = lane * 16;
-  R.rd16 = (m * 2 + hh) * 16;
+  R.rd16 = lane * 16;
   // start the panel stream before anything else: K-steps 0 and 1 of layer 0
   R.dma((int)bg.p_l0, 0, 0);
   R.dma((int)bg.p_l0, 1, 1);
