@@ -235,8 +235,17 @@ __device__ __forceinline__ void gemm_ring_reg3(f32x16 (&Q)[NTO], const f32x16 (&
   constexpr int NP = 3, KS = 2 * NTI;
   static_assert(KS % 4 == 0, "ring slot continuity");
   static_assert(!PAIR || NTO % 2 == 0, "tiles are processed in pairs");
-  static_assert(NTO >= 4, "the publish sits behind tile NTO / 2 - 1, the cross-step prefetch in the last two tiles");
-  constexpr int TP = PAIR ? 2 : 1, NA = 4;
+  static_assert(NTO >= 4, "the publish sits behind tile NTO / 2 - 1, the cross-step prefetch in the last tiles");
+#ifdef CN_R_NOPAIR
+  constexpr int TP = 1;
+#else
+  constexpr int TP = PAIR ? 2 : 1;
+#endif
+#ifndef CN_R_AHEAD
+#define CN_R_AHEAD 2
+#endif
+  constexpr int NA = 4, AH = (TP == 1) ? CN_R_AHEAD : 2;     // tiles the A reads run ahead of the MFMAs (TP + AH <= NA + ... sets)
+  static_assert(AH + TP <= NA + (TP == 1 ? 0 : 0) && AH >= 2, "register sets");
   constexpr int IA[6] = {0, 1, 2, 0, 1, 0}, IB[6] = {2, 1, 0, 1, 0, 0};   // cross terms w_i x_j, i + j < 3, smallest first
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   // K-step s + 1 is published in the MIDDLE of K-step s (behind tile NTO/2 - 1), not at its end: the A operands of its first two
@@ -253,7 +262,7 @@ __device__ __forceinline__ void gemm_ring_reg3(f32x16 (&Q)[NTO], const f32x16 (&
   for (int q = 0; q < 4; ++q) split_pair<NP, RELU>(X[0][2 * q], X[0][2 * q + 1], bc, q);
   u32x4 A[NA][NP];      // tile g = s NTO + t of the GEMM lives in set g % 4 (NTO is a multiple of 4): reads run two tiles ahead
 #pragma unroll
-  for (int u = 0; u < 2; ++u)
+  for (int u = 0; u < AH; ++u)
 #pragma unroll
     for (int p = 0; p < NP; ++p) A[u][p] = R.a(0, u, p);
   __builtin_amdgcn_sched_barrier(0);
@@ -275,8 +284,8 @@ __device__ __forceinline__ void gemm_ring_reg3(f32x16 (&Q)[NTO], const f32x16 (&
           Q[tt] = mfma_bf(A[tt % NA][IA[k]], bc[IB[k]], (INIT && s == 0 && k == 0) ? zero : Q[tt]);
 #ifndef CN_ABL_R_NOLDS      // (ablation builds, timings only: -DCN_ABL_R_NOLDS / NODMA / NOSPLIT / NOSIDE / NOBAR)
           if (k < 3) {
-            if (tt + 2 < NTO) A[(tt + 2) % NA][k] = R.a(s & 3, tt + 2, k);
-            else if (s + 1 < KS) A[(tt + 2) % NA][k] = R.a((s + 1) & 3, tt + 2 - NTO, k);   // (published behind tile MID - 1)
+            if (tt + AH < NTO) A[(tt + AH) % NA][k] = R.a(s & 3, tt + AH, k);
+            else if (s + 1 < KS) A[(tt + AH) % NA][k] = R.a((s + 1) & 3, tt + AH - NTO, k);   // (published behind tile MID - 1)
           }
 #endif
 #ifndef CN_ABL_R_NODMA
@@ -301,7 +310,14 @@ __device__ __forceinline__ void gemm_ring_reg3(f32x16 (&Q)[NTO], const f32x16 (&
             if (k == 4) split3_plane(S[u], bn, 2, tt);
           }
 #ifndef CN_ABL_R_NOSIDE
+          // the side stores go out behind the LAST two tiles: vmcnt retires in order, so a store issued in front of this K-step's
+          // DMA pieces would have to be acknowledged by HBM before the next publish may pass (it waits for those pieces); behind
+          // them it has a whole K-step more
+#ifdef CN_R_SIDE_FIRST
           if (k == 5) side(s, tt);
+#else
+          if (k == 5 && tt >= NTO - 2) side(s, tt - (NTO - 2));
+#endif
 #endif
           __builtin_amdgcn_sched_barrier(0);
           if (k == 5 && tt == MID - 1) {     // K-step s + 1 (or the next panel's K-step 0) is published here
