@@ -310,13 +310,13 @@ __device__ __forceinline__ void gemm_ring_reg3(f32x16 (&Q)[NTO], const f32x16 (&
             if (k == 4) split3_plane(S[u], bn, 2, tt);
           }
 #ifndef CN_ABL_R_NOSIDE
-          // the side stores go out behind the LAST two tiles: vmcnt retires in order, so a store issued in front of this K-step's
-          // DMA pieces would have to be acknowledged by HBM before the next publish may pass (it waits for those pieces); behind
-          // them it has a whole K-step more
-#ifdef CN_R_SIDE_FIRST
-          if (k == 5) side(s, tt);
-#else
+          // the side stores ride behind tiles 0 and 1.  (Behind the LAST two tiles — younger than this K-step's DMA pieces in the
+          // in-order vmcnt queue, so that no publish ever waits for an HBM store acknowledgement — measured level on the dgrad
+          // and 10 % slower on the training forward: -DCN_R_SIDE_LAST.)
+#ifdef CN_R_SIDE_LAST
           if (k == 5 && tt >= NTO - 2) side(s, tt - (NTO - 2));
+#else
+          if (k == 5) side(s, tt);
 #endif
 #endif
           __builtin_amdgcn_sched_barrier(0);
