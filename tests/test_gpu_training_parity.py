@@ -16,8 +16,10 @@ sign bits applied instead of its own (z > 0) (`masks` of O.query), and with the 
 own sigma_last is on the other side of 0 or inside the 1e-7 spike zone — every such substitution / pattern difference is counted and
 must sit within round-off of the discontinuity.
 
-The step is evaluated twice: in float64 (g_exact: the exact gradient of the reference's step map on that branch) and in fp32
-(g_ref32: the reference arithmetic itself — ATen / MKL sgemm sum ~10^6 signed products per weight in fp32).
+The step is evaluated twice: in float64 (g_exact: the exact gradient of the reference's step map on that branch; the oracle's own
+torch code run through stock ATen float64 kernels ON THE GPU — exactness does not depend on where it is computed, and it takes 2 s
+instead of 30 s per snapshot) and in fp32 ON THE CPU (g_ref32: the reference arithmetic itself — ATen / MKL sgemm sum ~10^6 signed
+products per weight in fp32).
 
 Stated bounds:
   loss                       |d| <= 1e-6 relative, vs g_ref32's loss, vs the float64 loss, and vs the oracle running FREE
@@ -91,7 +93,25 @@ def _adam_first_order_bound(dg, g, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8):
 EPS32 = 2.0 ** -24      # unit round-off of fp32
 
 
-def _oracle_step(dtype, w0, names, rays, tgt, z_c, z_f, masks_c, masks_f, raw_k, ncfg, want_abs=False):
+def _oracle_step(dtype, w0, names, rays, tgt, z_c, z_f, masks_c, masks_f, raw_k, ncfg, want_abs=False, device=None):
+    """`device`: where the oracle's torch ops are evaluated.  None = the CPU (the reference arithmetic: what g_ref32 must be).  The
+    float64 evaluation — whose only role is to be EXACT — may run the same oracle code on the GPU through stock ATen float64 kernels
+    (30 s -> 2 s per snapshot); results come back on the CPU."""
+    if device is not None:
+        mv = lambda t: t.to(device)   # noqa: E731
+        with torch.device(device):
+            out = _oracle_step(dtype, [{k: mv(v) for k, v in d.items()} for d in w0], names, mv(rays), mv(tgt), mv(z_c), mv(z_f),
+                               [mv(m) for m in masks_c], [mv(m) for m in masks_f], tuple(mv(r) for r in raw_k), ncfg, want_abs)
+        torch.cuda.synchronize()
+        res = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in out.items()}
+        res["d_raw"] = {k: v.cpu() for k, v in out["d_raw"].items()}
+        del out
+        torch.cuda.empty_cache()
+        return res
+    return _oracle_step_impl(dtype, w0, names, rays, tgt, z_c, z_f, masks_c, masks_f, raw_k, ncfg, want_abs)
+
+
+def _oracle_step_impl(dtype, w0, names, rays, tgt, z_c, z_f, masks_c, masks_f, raw_k, ncfg, want_abs=False):
     """The oracle's training step on the KERNEL'S BRANCH (module docstring) in `dtype`: O.query -> O.composite on both levels ->
     mse + mse -> autograd.  raw_k = the kernel's (coarse, fine) raw outputs (fp32, CPU) for the tail-branch substitution.
     -> dict(loss, grad flat [dtype], flips, tail, A) with A = sum over samples of |dZ| |h| per gradient element (float64 runs)."""
@@ -209,7 +229,7 @@ def test_c2_teacher_forced_training_steps(dev, monkeypatch):
         m1_hip, v1_hip = opt.exp_avg.cpu().clone(), opt.exp_avg_sq.cpu().clone()
         rays_c, tgt_c = bank[lo:hi], target[lo:hi]
         common = (w0, names, rays_c, tgt_c, z_c, z_f, masks_c, masks_f, raw_k, ncfg)
-        ex = _oracle_step(torch.float64, *common, want_abs=True)
+        ex = _oracle_step(torch.float64, *common, want_abs=True, device=dev)
         r32 = _oracle_step(torch.float32, *common)
         del masks_c, masks_f
         with torch.no_grad():      # the oracle running free: its own depths, ReLU patterns, tail signs
