@@ -621,6 +621,9 @@ class Workload:
         for k_ in ("network_fn", "network_fine"):     # (the headline line is "fp32" = exact fp32 MFMA; "bf16x3" = the opt-in leg)
             self.kw[k_].training_precision = precision
         self.K, self.bank, self.targets = build_ray_bank(dev)
+        # render() takes (rays_o, rays_d) (R:70-137): kept as two contiguous banks, so that a batch is two row slices (no
+        # stack / cat launch per step; the reference slices its pre-shuffled rays_rgb the same way, R:720-729)
+        self.bank_o, self.bank_d = self.bank[:, 0:3].contiguous(), self.bank[:, 3:6].contiguous()
         torch.manual_seed(99 + rank)                  # per-rank jitter streams (RegNeRF/train.py:364-365 precedent)
         # the step's gradient exchange: per-network slices of the flat fp32 gradient, all-reduced (RCCL) as _MlpFn.backward
         # reports them final, the 1/world folded into the Adam kernel; a no-op without a process group
@@ -634,9 +637,9 @@ class Workload:
         self.global_rows = (self.rank * per_rank, per_rank * self.world) if (strong and self.world > 1) else None
         torch.manual_seed(99 if self.global_rows is not None else 99 + self.rank)
 
-    def fwd_bwd(self, rays, tgt):
+    def fwd_bwd(self, rays_o, rays_d, tgt):
         R = self.R
-        rays_od = torch.stack([rays[:, 0:3], rays[:, 3:6]], 0)
+        rays_od = (rays_o, rays_d)    # origins / directions of this batch: two contiguous [B, 3] row blocks of the pre-split bank
         extra_kw = {} if getattr(self, "global_rows", None) is None else {"_global_rows": self.global_rows}
         rgb, disp, acc, extras = R.render(H_IMG, W_IMG, self.K, chunk=32768, rays=rays_od, retraw=True, **self.kw, **extra_kw)
         self.opt.zero_grad()
@@ -644,8 +647,8 @@ class Workload:
         loss.backward()
         return loss
 
-    def body(self, rays, tgt):
-        loss = self.fwd_bwd(rays, tgt)
+    def body(self, rays_o, rays_d, tgt):
+        loss = self.fwd_bwd(rays_o, rays_d, tgt)
         self.reducer.finish()
         self.opt.step(grad_scale=self.reducer.grad_scale)
         return loss
@@ -654,11 +657,11 @@ class Workload:
         """rank's contiguous slice of global batch i (every rank holds the identical, identically shuffled bank)"""
         gstep = per_rank * self.world
         lo = (i * gstep + self.rank * per_rank) % (self.bank.shape[0] - per_rank)
-        return self.bank[lo:lo + per_rank], self.targets[lo:lo + per_rank]
+        return self.bank_o[lo:lo + per_rank], self.bank_d[lo:lo + per_rank], self.targets[lo:lo + per_rank]
 
     def graphed(self, per_rank, collective):
         from consistentnerf_amd.graph import GraphedStep
-        ex = (self.bank[0:per_rank], self.targets[0:per_rank])
+        ex = (self.bank_o[0:per_rank], self.bank_d[0:per_rank], self.targets[0:per_rank])
         if self.world == 1 and not self.reducer_active():
             return GraphedStep(self.body, self.opt, ex, warmup=3)
         return GraphedStep(self.fwd_bwd, self.opt, ex, warmup=3, reducer=self.reducer, collective=collective)
@@ -674,8 +677,8 @@ class Workload:
         import torch.distributed as dist
 
         def step(i):
-            rays, tgt = self.batch(i, per_rank)
-            loss = graphed(rays, tgt) if graphed is not None else self.body(rays, tgt)
+            b = self.batch(i, per_rank)
+            loss = graphed(*b) if graphed is not None else self.body(*b)
             lr = 5e-4 * (0.1 ** (i / (250 * 1000)))
             for pg in self.opt.param_groups:
                 pg['lr'] = lr
@@ -706,10 +709,10 @@ class Workload:
         GPU drained before and after so that the host never waits on it inside."""
         ts = []
         for i in range(n):
-            rays, tgt = self.batch(i, per_rank)
+            b = self.batch(i, per_rank)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            self.body(rays, tgt)
+            self.body(*b)
             ts.append(time.perf_counter() - t0)
         torch.cuda.synchronize()
         ts.sort()

@@ -340,7 +340,11 @@ def run_network(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk=1024 * 64
         if embeddirs_fn is not None and getattr(embeddirs_fn, "out_dim", 3) != fn.input_ch_views:
             raise ValueError("embeddirs_fn width does not match the network input_ch_views")
     B, S = inputs.shape[0], inputs.shape[1]
-    dirs = viewdirs.contiguous() if (viewdirs is not None and spec.use_viewdirs) else None
+    dirs = viewdirs if (viewdirs is not None and spec.use_viewdirs) else None
+    if dirs is not None and isinstance(inputs, RayPoints) and _is_viewdir_columns(dirs, inputs.rays):
+        dirs = None      # the kernel reads the view directions from the last three columns of the ray rows (R:350): no copy
+    elif dirs is not None:
+        dirs = dirs.contiguous()
     params = fn.kernel_tensors()
     prec = getattr(fn, "inference_precision", "fp32")
     if prec != "fp32" and not (torch.is_grad_enabled() and any(p.requires_grad for p in params)):
@@ -361,6 +365,24 @@ def run_network(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk=1024 * 64
         return _MlpFn.apply(fn, B, S, None, inputs.rays, inputs.z_vals, dirs, None, *params)
     pts = inputs.reshape(-1, 3).contiguous()
     return _MlpFn.apply(fn, B, S, pts, None, None, dirs, None, *params)
+
+
+def _is_viewdir_columns(viewdirs, rays):
+    """True when `viewdirs` IS rays[:, -3:] (same storage): what render_rays passes (R:350)."""
+    return (rays.dim() == 2 and rays.shape[1] >= 11 and viewdirs.dim() == 2 and viewdirs.shape == (rays.shape[0], 3)
+            and viewdirs.dtype == rays.dtype and rays.is_contiguous() and viewdirs.stride() == (rays.shape[1], 1)
+            and viewdirs.data_ptr() == rays.data_ptr() + 4 * (rays.shape[1] - 3))
+
+
+def _jitter_and_u(rows, Nc, Nf, dev, global_rows):
+    """The stratified-jitter stream t_rand [rows, Nc] (R:376) and the resampling stream u [rows, Nf] (H:227) of one render_rays
+    call from ONE generator call: a flat draw cut into two contiguous blocks (one launch instead of two; with `global_rows` the
+    draw is for the whole batch and this call's rows are sliced, _rows_of_global)."""
+    off, total = (0, rows) if global_rows is None else (int(global_rows[0]), int(global_rows[1]))
+    r = torch.rand(total * (Nc + Nf), device=dev)
+    t_rand = r[:total * Nc].view(total, Nc)[off:off + rows]
+    u = r[total * Nc:].view(total, Nf)[off:off + rows] if Nf > 0 else None
+    return t_rand, u
 
 
 def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0, white_bkgd=False, pytest=False):
@@ -514,11 +536,15 @@ def _render_camera(H, W, K, chunk, c2w, ndc, near, far, use_viewdirs, with_depth
     end = H * W if count is None else min(H * W, first0 + count)
     for first in range(first0, end, chunk):
         B = min(chunk, end - first)
-        t_rand = None
+        t_rand = u = None
         if perturb > 0.:
-            t_rand = pytest_uniform((B, Nc), dev) if pytest else torch.rand(B, Nc, device=dev)
+            if pytest:
+                t_rand = pytest_uniform((B, Nc), dev)
+            else:
+                t_rand, u = _jitter_and_u(B, Nc, Nf, dev, None)     # (the same draw as render_rays: bit-identical paths)
         noise0 = _density_noise((B, Nc), std, pytest, dev)
-        u = sample_u(B, Nf, perturb == 0., pytest, dev) if Nf > 0 else None
+        if u is None:
+            u = sample_u(B, Nf, perturb == 0., pytest, dev) if Nf > 0 else None
         noise1 = _density_noise((B, Nc + Nf), std, pytest, dev) if Nf > 0 else None
         o = ops.render_forward_cam(net.spec(), _packed(net), fine.spec() if two_nets else None,
                                    _packed(fine) if two_nets else None, H, W, K, c2w, near, far, use_viewdirs, ndc, coef, first,
@@ -692,10 +718,12 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
                 ret['depth0'] = e(0)
         return ret
     viewdirs = rays[:, -3:] if rays.shape[-1] > 8 else None
-    t_rand = None
+    t_rand = u_drawn = None
     if perturb > 0.:
-        t_rand = (_pytest_rows(N_rays, N_samples, dev, _global_rows) if pytest else
-                  _rows_of_global(lambda n, c: torch.rand(n, c, device=dev), N_rays, N_samples, _global_rows))
+        if pytest:
+            t_rand = _pytest_rows(N_rays, N_samples, dev, _global_rows)
+        else:
+            t_rand, u_drawn = _jitter_and_u(N_rays, N_samples, N_importance, dev, _global_rows)
     z_vals = ops.coarse_z(rays, N_samples, t_rand, lindisp)
     raw = network_query_fn(RayPoints(rays, z_vals), viewdirs, network_fn)
     noise = _density_noise((N_rays, N_samples), raw_noise_std, pytest, dev, _global_rows)
@@ -703,9 +731,10 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
     z_coarse = z_vals
     if N_importance > 0:
         rgb_map_0, disp_map_0, acc_map_0, depth_map_0 = rgb_map, disp_map, acc_map, depth_map
-        if _global_rows is not None and perturb != 0.:
-            u = (_pytest_rows(N_rays, N_importance, dev, _global_rows) if pytest else
-                 _rows_of_global(lambda n, c: torch.rand(n, c, device=dev), N_rays, N_importance, _global_rows))
+        if u_drawn is not None:
+            u = u_drawn                                  # drawn together with the jitter above (one generator call)
+        elif _global_rows is not None and perturb != 0.:
+            u = _pytest_rows(N_rays, N_importance, dev, _global_rows)
         else:
             u = sample_u(N_rays, N_importance, perturb == 0., pytest, dev)
         z_vals, z_std = ops.resample(z_vals, weights, u)          # R:395-399 + R:415, no gradient (R:397)
