@@ -61,6 +61,7 @@ SIGNATURES = {
     "cnerf_tensor_shape": (_i, [_NetP, _i, C.POINTER(_i64), C.POINTER(_i64)]),
     "cnerf_packed_floats": (_i64, [_NetP]),
     "cnerf_pack_weights": (_i, [_NetP, _PtrsP, _vp, _vp]),
+    "cnerf_pack_weights_pair": (_i, [_NetP, _PtrsP, _vp, _NetP, _PtrsP, _vp, _vp]),
     "cnerf_coarse_z": (_i, [_vp, _i, _i64, _i, _vp, _vp, _i, _vp, _vp]),
     "cnerf_embed": (_i, [_vp, _i64, _i, _vp, _vp]),
     "cnerf_mlp_stash_floats": (_i64, [_NetP, _i64]),

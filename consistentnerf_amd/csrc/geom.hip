@@ -153,12 +153,12 @@ struct PackJob {
   int mode;
   int rows_p;         // padded row count of the panel (N rounded to 32 for PANEL; K rounded to 32 for PANEL_T)
   int groups;         // number of 8-wide groups along the contracted index
-  int64_t dst;
+  float* out;         // where the panel goes (the packed buffer + the panel's offset)
   const float* bias;  // JOB_PANEL only: extra group `groups` with P[groups][n][0] = bias[n] (the bias MFMA step)
   int zero_bias;      // JOB_PANEL with bias == nullptr: still write the extra group, as zeros
 };
 constexpr int MAX_JOBS = 56;
-struct PackArgs { PackJob job[MAX_JOBS]; float* packed; };
+struct PackArgs { PackJob job[MAX_JOBS]; };   // (56 x 64 B: inside the 4 KiB kernarg segment)
 
 // (the job table is read in place from the kernarg segment: taken by value and indexed with blockIdx.y the compiler copies the
 // whole 3.6 KB struct to scratch in every thread first — measured 26 us per network instead of ~6)
@@ -186,13 +186,14 @@ __global__ void pack_k(PackArgs a_by_value) {
         if (nn < j.N && row < j.K) v = j.src[(int64_t)nn * j.ld + j.col0 + row];
       }
     }
-    a.packed[j.dst + i] = v;
+    j.out[i] = v;
   }
 }
 
 }  // namespace
 
-extern "C" int cnerf_pack_weights(const cnerf_net* net, const cnerf_ptrs* params, float* packed, void* stream) {
+// Appends one network's panels to the job table (a.job[nj...]); CNERF_E_UNSUPPORTED when the table is full.
+static int add_pack_jobs(const cnerf_net* net, const cnerf_ptrs* params, float* packed, PackArgs& a, int& nj) {
   NetGeom g;
   int rc = cn_make_geom(net, &g);
   if (rc) return rc;
@@ -200,22 +201,23 @@ extern "C" int cnerf_pack_weights(const cnerf_net* net, const cnerf_ptrs* params
   const int nt = cnerf_num_tensors(net);
   for (int i = 0; i < nt; ++i)
     if (!params->p[i] && !(i >= 2 * g.D && i < 2 * g.D + 2 && !g.viewdirs)) return CNERF_E_ARG;
-  PackArgs a;
-  a.packed = packed;
-  int nj = 0;
+  bool full = false;
   const int W = g.W, Wh = g.Wh, D = g.D;
   // contracted width padded to a multiple of 32 (4 K-groups of 8: the GEMM pipelines peel / unroll by that)
   auto panel = [&](const float* src, int ld, int col0, int N, int K, int64_t dst, const float* bias = nullptr,
                    int zero_bias = 0) {
-    a.job[nj++] = PackJob{src, ld, col0, N, K, JOB_PANEL, (int)cn_round_up(N, 32), (int)cn_round_up(K, 32) / 8, dst,
+    if (nj >= MAX_JOBS) { full = true; return; }
+    a.job[nj++] = PackJob{src, ld, col0, N, K, JOB_PANEL, (int)cn_round_up(N, 32), (int)cn_round_up(K, 32) / 8, packed + dst,
                           bias, zero_bias};
   };
   auto panel_t = [&](const float* src, int ld, int col0, int N, int K, int64_t dst) {
-    a.job[nj++] = PackJob{src, ld, col0, N, K, JOB_PANEL_T, (int)cn_round_up(K, 32), (int)cn_div_up(N, 8), dst,
+    if (nj >= MAX_JOBS) { full = true; return; }
+    a.job[nj++] = PackJob{src, ld, col0, N, K, JOB_PANEL_T, (int)cn_round_up(K, 32), (int)cn_div_up(N, 8), packed + dst,
                           nullptr, 0};
   };
   auto copy = [&](const float* src, int N, int K, int64_t dst) {
-    a.job[nj++] = PackJob{src, K, 0, N, K, JOB_COPY, 0, 0, dst, nullptr, 0};
+    if (nj >= MAX_JOBS) { full = true; return; }
+    a.job[nj++] = PackJob{src, K, 0, N, K, JOB_COPY, 0, 0, packed + dst, nullptr, 0};
   };
   auto Wt = [&](int l) { return params->p[2 * l]; };
   auto Bt = [&](int l) { return params->p[2 * l + 1]; };
@@ -244,7 +246,35 @@ extern "C" int cnerf_pack_weights(const cnerf_net* net, const cnerf_ptrs* params
     copy(params->p[base + 2], g.out_ch, W, g.v_out);
     copy(params->p[base + 3], 1, g.out_ch, g.b_out);
   }
-  if (nj > MAX_JOBS) return CNERF_E_UNSUPPORTED;
+  return full ? CNERF_E_UNSUPPORTED : CNERF_OK;
+}
+
+extern "C" int cnerf_pack_weights(const cnerf_net* net, const cnerf_ptrs* params, float* packed, void* stream) {
+  PackArgs a;
+  int nj = 0;
+  const int rc = add_pack_jobs(net, params, packed, a, nj);
+  if (rc) return rc;
+  hipLaunchKernelGGL(pack_k, dim3(64, nj), dim3(256), 0, cn_stream(stream), a);
+  CN_CHECK_LAUNCH();
+  return CNERF_OK;
+}
+
+// Both networks of a render_rays call in ONE launch (the coarse and the fine network are re-packed together after every optimizer
+// step); two launches when their panels do not fit one job table.
+extern "C" int cnerf_pack_weights_pair(const cnerf_net* net0, const cnerf_ptrs* params0, float* packed0, const cnerf_net* net1,
+                                       const cnerf_ptrs* params1, float* packed1, void* stream) {
+  PackArgs a;
+  int nj = 0;
+  int rc = add_pack_jobs(net0, params0, packed0, a, nj);
+  if (rc) return rc;
+  const int n0 = nj;
+  rc = add_pack_jobs(net1, params1, packed1, a, nj);
+  if (rc == CNERF_E_UNSUPPORTED) {      // table full: the first network now, the second on its own
+    hipLaunchKernelGGL(pack_k, dim3(64, n0), dim3(256), 0, cn_stream(stream), a);
+    CN_CHECK_LAUNCH();
+    return cnerf_pack_weights(net1, params1, packed1, stream);
+  }
+  if (rc) return rc;
   hipLaunchKernelGGL(pack_k, dim3(64, nj), dim3(256), 0, cn_stream(stream), a);
   CN_CHECK_LAUNCH();
   return CNERF_OK;

@@ -212,6 +212,9 @@ struct Ring {
 // Training: the input tiles X (already rectified, fp32) go out to the stash while they are the B operand — the two register
 // quads of K-step s (tile s >> 1, quads 2 (s & 1), + 1) behind tiles 0 and 1 of that step: one 16-byte store per lane each, a
 // wave writes 1 KiB contiguous (mlp_common.hpp TileStores, dealt out for the 16-feature K-steps of this kernel).
+#ifndef CN_STASH_AUX
+#define CN_STASH_AUX 0   // cache-policy bits of the stash / gradient stores (experiment knob: sc0 = 1, nt = 2, sc1 = 16)
+#endif
 struct NoStash {
   __device__ __forceinline__ void operator()(int, int) const {}
 };
@@ -223,7 +226,12 @@ struct StashStores {
   __device__ __forceinline__ void operator()(int s, int t) const {
     if (t > 1) return;       // (behind tiles 0 and 1: every GEMM has at least two output tiles)
     const int tt = s >> 1, q = 2 * (s & 1) + t;
-    buf_store(rs, voff, soff + (4 * tt + q) * 1024, f32x4{X[tt][4 * q], X[tt][4 * q + 1], X[tt][4 * q + 2], X[tt][4 * q + 3]});
+    const f32x4 v = {X[tt][4 * q], X[tt][4 * q + 1], X[tt][4 * q + 2], X[tt][4 * q + 3]};
+    #ifdef CN_ABL_R_OOBSTORE   // (timing only: the store is issued, its data read, and dropped by the bounds check)
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, voff | 0x40000000, soff + (4 * tt + q) * 1024, CN_STASH_AUX);
+#else
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, voff, soff + (4 * tt + q) * 1024, CN_STASH_AUX);
+#endif
   }
 };
 
@@ -321,7 +329,11 @@ __device__ __forceinline__ void gemm_ring_reg3(f32x16 (&Q)[NTO], const f32x16 (&
 #endif
           __builtin_amdgcn_sched_barrier(0);
           if (k == 5 && tt == MID - 1) {     // K-step s + 1 (or the next panel's K-step 0) is published here
+#ifdef CN_ABL_R_WAITSLACK   // (timing only, results race: the publish leaves the previous K-step's stores and later pieces in flight)
+            if (s + 2 < KS || poff_next >= 0) R.template publish<OUT + (SIDE_OPS ? CN_ABL_R_WAITSLACK : 0)>();
+#else
             if (s + 2 < KS || poff_next >= 0) R.template publish<OUT>();
+#endif
             else R.template publish<SIDE_OPS>();      // (no DMA was issued in this K-step: only the side stores may be in flight)
           }
         }

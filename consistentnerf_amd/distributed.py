@@ -163,6 +163,8 @@ class GradReducer:
     def finish(self):
         rest = [m for m in self.modules if id(m) not in self._done]
         if rest:
+            if hasattr(self.opt, "materialize_grad"):
+                self.opt.materialize_grad()  # (a network without a backward in this step contributes zeros, not a dropped buffer)
             self._issue(*rest)
         for m in self.modules:
             m._cnerf_pending = 0

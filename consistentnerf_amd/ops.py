@@ -113,6 +113,24 @@ def pack_weights(spec: NetSpec, params: Sequence[Tensor], out: Optional[Tensor] 
     return out
 
 
+def pack_weights_pair(spec0: NetSpec, params0: Sequence[Tensor], out0: Optional[Tensor], spec1: NetSpec, params1: Sequence[Tensor],
+                      out1: Optional[Tensor]):
+    """cnerf_pack_weights_pair: both networks of a render_rays call re-packed by one launch -> (packed0, packed1)."""
+    lib, n0, n1 = _lib.load(), spec0.c(), spec1.c()
+    params0 = [_chk(p, f"param0[{i}]") for i, p in enumerate(params0)]
+    params1 = [_chk(p, f"param1[{i}]") for i, p in enumerate(params1)]
+    outs = []
+    for net, spec, out, ps in ((n0, spec0, out0, params0), (n1, spec1, out1, params1)):
+        n = lib.cnerf_packed_floats(C.byref(net))
+        if n < 0:
+            raise CnerfError(f"unsupported network {spec}")
+        outs.append(out if out is not None else torch.empty(n, device=ps[0].device, dtype=torch.float32))
+    p0, p1 = _ptrs(params0), _ptrs(params1)
+    _lib.check(lib.cnerf_pack_weights_pair(C.byref(n0), C.byref(p0), _p(outs[0]), C.byref(n1), C.byref(p1), _p(outs[1]),
+                                           _stream()), "cnerf_pack_weights_pair")
+    return outs[0], outs[1]
+
+
 # ------------------------------------------------------------------------------------------ sampling
 _TVALS = {}
 

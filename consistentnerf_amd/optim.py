@@ -14,6 +14,25 @@ import torch
 from . import ops
 
 
+# What a FusedAdam-owned parameter's view of the flat gradient holds: zeros nothing has written since / a gradient / a gradient
+# that zero_grad() dropped (stale values the next writer must overwrite, or zero first).
+GRAD_ZERO, GRAD_LIVE, GRAD_DROPPED = 0, 1, 2
+
+
+def _materialize_on_tensor_route(p):
+    """Hook of a FusedAdam-owned parameter: autograd computed a per-tensor gradient for it (AccumulateGrad is about to ADD it to
+    the .grad view) — a view whose contents zero_grad() dropped has to be zero first."""
+    def hook(g):
+        if g is None:        # (the direct route hands autograd no gradient; the engine still runs the hook of the leaf)
+            return None
+        if p._cnerf_grad_state == GRAD_DROPPED:
+            with torch.no_grad():
+                p.grad.zero_()
+        p._cnerf_grad_state = GRAD_LIVE
+        return None
+    return hook
+
+
 class FusedAdam:
     def __init__(self, params: Iterable[torch.nn.Parameter], lr=5e-4, betas=(0.9, 0.999), eps=1e-8,
                  clip_value: float = 0.0):
@@ -42,6 +61,8 @@ class FusedAdam:
                 p.data = self.flat_param[o:o + n].view(p.shape)
                 p.grad = self.flat_grad[o:o + n].view(p.shape)
                 p._cnerf_direct_grad = True     # _MlpFn.backward accumulates into this view directly
+                p._cnerf_grad_state = GRAD_ZERO
+                p.register_hook(_materialize_on_tensor_route(p))
 
     def slice_of(self, params):
         """[lo, hi) of the flat buffers covered by `params` (e.g. one network's parameters); they must be contiguous in it."""
@@ -51,17 +72,44 @@ class FusedAdam:
         return self._offsets[idx[0]], self._offsets[idx[-1] + 1]
 
     # -- torch.optim surface -------------------------------------------------------------------
-    def zero_grad(self, set_to_none: bool = False):
-        """Zeroes the flat gradient in place (the per-parameter .grad views stay attached)."""
-        self.flat_grad.zero_()
+    def zero_grad(self, set_to_none: bool = True):
+        """set_to_none=True (torch.optim's own default): the gradient is DROPPED, not cleared — no fill launch.  The per-parameter
+        .grad views stay attached (the direct-accumulate route needs them) but the contents of those a backward wrote are
+        undefined until the next backward, whose wgrad reduction then overwrites the flat buffer instead of adding to it
+        (run_nerf._MlpFn.backward); whatever else needs defined values first — the tensor route (a hook on every parameter),
+        step() without a backward, the GradReducer's all-reduce of a network that had none — goes through materialize_grad().
+        Views nothing has written since they were last zero (parameters no loss reaches) stay zero at no cost.
+        set_to_none=False: zero now."""
         for p, o in zip(self.params, self._offsets):
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
                 p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
+        if set_to_none:
+            for p in self.params:
+                if p._cnerf_grad_state == GRAD_LIVE:
+                    p._cnerf_grad_state = GRAD_DROPPED
+        else:
+            self.flat_grad.zero_()
+            for p in self.params:
+                p._cnerf_grad_state = GRAD_ZERO
+
+    def materialize_grad(self):
+        """Gradients dropped by zero_grad() and not overwritten by a backward since become zeros (one fill per contiguous run)."""
+        runs = []
+        for p, o in zip(self.params, self._offsets):
+            if p._cnerf_grad_state == GRAD_DROPPED:
+                p._cnerf_grad_state = GRAD_ZERO
+                if runs and runs[-1][1] == o:
+                    runs[-1][1] = o + p.numel()
+                else:
+                    runs.append([o, o + p.numel()])
+        for lo, hi in runs:
+            self.flat_grad[lo:hi].zero_()
 
     def step(self, grad_scale: float = 1.0):
         """One Adam step over the flat buffers.  `grad_scale` multiplies the gradient inside the kernel BEFORE the clip (the
         1/world of a summed data-parallel gradient rides here for free: distributed.GradReducer(fold_scale=True))."""
         g = self.param_groups[0]
+        self.materialize_grad()
         if self._hyp_ring is not None:
             # graph-capturable form (graph.GraphedStep): the scalars of the step live in device memory.  Eagerly, advance()
             # uploads them (stream-ordered, from a ring of pinned buffers) right before the kernel; under capture only the

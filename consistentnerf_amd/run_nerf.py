@@ -61,6 +61,32 @@ def _packed(model):
     return _packed_gen(model)[0]
 
 
+def _prepack_pair(model_a, model_b):
+    """render_rays is about to query both networks: when BOTH kernel-layout copies are stale (every training step: the optimizer
+    just wrote both) re-pack them with one launch instead of one each.  Same cache protocol as _packed_gen."""
+    if model_a is None or model_b is None or model_a is model_b:
+        return
+    st = []
+    for m in (model_a, model_b):
+        if not hasattr(m, "kernel_tensors"):
+            return
+        ts = m.kernel_tensors()
+        key = tuple((t.data_ptr(), t._version, getattr(t, "_cnerf_epoch", 0)) for t in ts)
+        cache = m.__dict__.get("_cnerf_packed")
+        if cache is not None and cache[0] == key:
+            return                               # (at most one is stale: its own query re-packs it)
+        gen = 0 if cache is None else cache[2] + 1
+        bufs = [None, None] if cache is None else cache[3]
+        st.append((m, ts, key, gen, bufs))
+    if st[0][1][0].device != st[1][1][0].device or not st[0][1][0].is_cuda:
+        return
+    (ma, tsa, ka, ga, ba), (mb, tsb, kb, gb, bb) = st
+    with torch.no_grad():
+        ba[ga & 1], bb[gb & 1] = ops.pack_weights_pair(ma.spec(), tsa, ba[ga & 1], mb.spec(), tsb, bb[gb & 1])
+    ma.__dict__["_cnerf_packed"] = (ka, ba[ga & 1], ga, ba)
+    mb.__dict__["_cnerf_packed"] = (kb, bb[gb & 1], gb, bb)
+
+
 def _packed_bf(model, planes):
     """bf16-plane panels of `model` for the opt-in reduced-precision inference forward, re-packed when a parameter changed."""
     ts = model.kernel_tensors()
@@ -193,6 +219,20 @@ def _direct_ok(needs, params):
                               for p in params)
 
 
+def _take_dropped(*param_lists):
+    """The direct route is about to write these parameters' views of FusedAdam's flat gradient.  True when none of them holds a
+    live gradient (all dropped by zero_grad(), or still zero): the wgrad reduction then OVERWRITES (accumulate=0) and the fill
+    launch of an eager zero_grad never happens.  In a mixed state the dropped views are zeroed here and the reduction adds."""
+    from .optim import GRAD_DROPPED, GRAD_LIVE
+    ps = [p for params in param_lists for p in params]
+    fresh = all(p._cnerf_grad_state != GRAD_LIVE for p in ps)
+    for p in ps:
+        if not fresh and p._cnerf_grad_state == GRAD_DROPPED:
+            p.grad.zero_()
+        p._cnerf_grad_state = GRAD_LIVE
+    return fresh
+
+
 def _report_ready(model, direct):
     """One backward node of `model` has accumulated into the flat gradient: tell the GradReducer when it was the last."""
     if hasattr(model, "_cnerf_pending"):
@@ -266,27 +306,27 @@ class _MlpFn(torch.autograd.Function):
             if (c is not None and c.stash is not None and _direct_ok(c.needs_input_grad[8:], c.params)
                     and _ENGINE_QUERY(c)):
                 pair.parked = (ctx.spec, ctx.packed, g_raw.contiguous(), ctx.B, ctx.S, ctx.stash, [p.grad for p in params],
-                               ctx.model, getattr(ctx, "packed_bf", None))
+                               ctx.model, getattr(ctx, "packed_bf", None), params)
                 ctx.stash = ctx.packed = ctx.params = ctx.model = None
                 return nret
         parked = None
         if pair is not None and pair.coarse() is ctx and pair.parked is not None:
             parked, pair.parked = pair.parked, None
         if parked is not None and direct:
-            fs, fp, fg, fB, fS, fst, fgr, fmodel, fbf = parked
+            fs, fp, fg, fB, fS, fst, fgr, fmodel, fbf, fparams = parked
             ops.mlp_backward_pair(fs, fp, fg, fB, fS, fst, fgr, ctx.spec, ctx.packed, g_raw.contiguous(), ctx.B, ctx.S,
-                                  ctx.stash, [p.grad for p in params], accumulate=True, packed_bf0=fbf,
+                                  ctx.stash, [p.grad for p in params], accumulate=not _take_dropped(fparams, params), packed_bf0=fbf,
                                   packed_bf1=getattr(ctx, "packed_bf", None))
             _report_ready_pair(fmodel, ctx.model)
             ctx.stash = ctx.packed = ctx.params = ctx.model = None
             return nret
         if parked is not None:        # (cannot happen — the fine node checked this node's route — but never drop a gradient)
-            fs, fp, fg, fB, fS, fst, fgr, fmodel, fbf = parked
-            ops.mlp_backward(fs, fp, fg, fB, fS, fst, grads=fgr, accumulate=True, packed_bf=fbf)
+            fs, fp, fg, fB, fS, fst, fgr, fmodel, fbf, fparams = parked
+            ops.mlp_backward(fs, fp, fg, fB, fS, fst, grads=fgr, accumulate=not _take_dropped(fparams), packed_bf=fbf)
             _report_ready(fmodel, True)
         out = [p.grad for p in params] if direct else None
         grads = ops.mlp_backward(ctx.spec, ctx.packed, g_raw.contiguous(), ctx.B, ctx.S, ctx.stash, grads=out,
-                                 accumulate=direct, packed_bf=getattr(ctx, "packed_bf", None))
+                                 accumulate=direct and not _take_dropped(params), packed_bf=getattr(ctx, "packed_bf", None))
         _report_ready(ctx.model, direct)
         ctx.stash = ctx.packed = ctx.params = ctx.model = None
         return nret if direct else (None,) * 8 + tuple(grads)
@@ -546,6 +586,8 @@ def _render_camera(H, W, K, chunk, c2w, ndc, near, far, use_viewdirs, with_depth
         if u is None:
             u = sample_u(B, Nf, perturb == 0., pytest, dev) if Nf > 0 else None
         noise1 = _density_noise((B, Nc + Nf), std, pytest, dev) if Nf > 0 else None
+        if two_nets:
+            _prepack_pair(net, fine)
         o = ops.render_forward_cam(net.spec(), _packed(net), fine.spec() if two_nets else None,
                                    _packed(fine) if two_nets else None, H, W, K, c2w, near, far, use_viewdirs, ndc, coef, first,
                                    B, Nc, Nf, t_rand, u, noise0, noise1, bool(kwargs.get("lindisp", False)),
@@ -725,6 +767,8 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
         else:
             t_rand, u_drawn = _jitter_and_u(N_rays, N_samples, N_importance, dev, _global_rows)
     z_vals = ops.coarse_z(rays, N_samples, t_rand, lindisp)
+    if N_importance > 0:
+        _prepack_pair(network_fn, network_fine)
     raw = network_query_fn(RayPoints(rays, z_vals), viewdirs, network_fn)
     noise = _density_noise((N_rays, N_samples), raw_noise_std, pytest, dev, _global_rows)
     rgb_map, disp_map, acc_map, weights, depth_map = _CompositeFn.apply(raw, z_vals, rays, noise, bool(white_bkgd))

@@ -62,6 +62,10 @@ int64_t cnerf_packed_floats(const cnerf_net* net);
 /* Re-pack the parameter tensors (device pointers, state-dict order above) into `packed`.  Called once
  * per optimiser step (replaces nothing in the reference; it is the price of the MFMA operand layout). */
 int cnerf_pack_weights(const cnerf_net* net, const cnerf_ptrs* params, float* packed, void* stream);
+/* The same for the two networks of one render_rays call (coarse R:362 + fine R:402) in ONE launch: after every optimiser step both
+ * are stale together. */
+int cnerf_pack_weights_pair(const cnerf_net* net0, const cnerf_ptrs* params0, float* packed0, const cnerf_net* net1,
+                            const cnerf_ptrs* params1, float* packed1, void* stream);
 
 /* ---- a3: sample placement  (render_rays R:355-382) --------------------------------------------- */
 /* z[B,Nc] from near/far in rays[:,6:8]; t_vals[Nc] = linspace(0,1,Nc) supplied by the host so both

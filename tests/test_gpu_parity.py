@@ -836,7 +836,28 @@ def test_direct_accumulation_into_flat_grads(dev):
     run()
     got2 = torch.cat([p.grad.reshape(-1) for m in (coarse, fine) for p in m.kernel_tensors()])
     assert (got2 - 2 * ref).abs().max().item() <= 1e-6 * ref.abs().max().item()
+    # zero_grad() DROPS the gradient (torch's set_to_none=True default; no fill launch): the next backward overwrites it
     opt.zero_grad()
+    assert float(opt.flat_grad.abs().max()) > 0.0
+    run()
+    got3 = torch.cat([p.grad.reshape(-1) for m in (coarse, fine) for p in m.kernel_tensors()])
+    assert torch.equal(got3, ref)
+    # only the coarse network gets a gradient: its views are overwritten, the fine network's dropped ones read as zeros by the
+    # time the optimizer (or anything else that goes through materialize_grad) looks at them
+    opt.zero_grad()
+    kw0 = _kwargs(coarse, None, 64, 0, 0.0, False, 0.0, False)
+    ((V.render_rays(rays, **kw0)["rgb_map"] - tgt) ** 2).sum().backward()
+    opt.materialize_grad()
+    lo, hi = opt.slice_of(list(fine.parameters()))
+    assert float(opt.flat_grad[lo:hi].abs().max()) == 0.0
+    lo, hi = opt.slice_of(list(coarse.parameters()))
+    assert float(opt.flat_grad[lo:hi].abs().max()) > 0.0
+    # the tensor route (autograd's AccumulateGrad adds into the view) zeroes a dropped view first
+    opt.zero_grad()
+    w = coarse.pts_linears[0].weight
+    (w * 2.0).sum().backward()
+    assert torch.equal(w.grad, torch.full_like(w, 2.0))
+    opt.zero_grad(set_to_none=False)
     assert float(opt.flat_grad.abs().max()) == 0.0
 
 
@@ -1806,6 +1827,7 @@ def test_training_step_merges_the_two_levels_backward(dev):
             kinds = [n for n, *_ in ops.PROFILE]
         finally:
             ops.PROFILE, R.MERGE_BWD = None, old
+        opt.materialize_grad()       # (a network whose backward did not run: its dropped gradient reads as zeros)
         return opt.flat_grad.clone(), kinds
     g_sep, k_sep = run(False)
     g_mrg, k_mrg = run(True)
@@ -1819,7 +1841,7 @@ def test_training_step_merges_the_two_levels_backward(dev):
     n_c = sum(p.numel() for p in coarse.parameters())
     assert float(g1[:n_c].abs().max()) == 0.0 and float(g1[n_c:].abs().max()) > 0
     params = [p for m in (coarse, fine) for p in m.kernel_tensors()]
-    opt.zero_grad()
+    opt.zero_grad(set_to_none=False)
     out = R.render_rays(rays, **kw)
     gs = torch.autograd.grad(R.img2mse(out["rgb_map"], tgt) + R.img2mse(out["rgb0"], tgt), params)
     assert all(g is not None for g in gs) and float(opt.flat_grad.abs().max()) == 0.0
