@@ -4,6 +4,7 @@ mkdir -p gpurun_out/final gpurun_out/prof gpurun_out/prof512 gpurun_out/prof_bf3
 export TMPDIR=/tmp
 timeout 2400 python -m pytest tests -m gpu -q --timeout=2000 --tb=short -p no:cacheprovider -rA > gpurun_out/final/test_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/final/test_gpu.log
 grep -E "passed|failed|rc=" gpurun_out/final/test_gpu.log | tail -2
+cp gpurun_out/teacher_forced_c2.json gpurun_out/final/teacher_forced_c2.json
 CNERF_TRAIN_PRECISION=bf16x3 timeout 2400 python -m pytest tests -m gpu -q --timeout=2000 --tb=short -p no:cacheprovider -rA > gpurun_out/final/test_gpu_bf16x3.log 2>&1; echo "pytest rc=$?" >> gpurun_out/final/test_gpu_bf16x3.log
 grep -E "passed|failed|rc=" gpurun_out/final/test_gpu_bf16x3.log | tail -2
 cp gpurun_out/teacher_forced_c2.json gpurun_out/final/teacher_forced_c2_bf16x3.json
