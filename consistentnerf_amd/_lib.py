@@ -99,6 +99,8 @@ SIGNATURES = {
     "cnerf_hard_mask_pair": (_i, [_i, _i, _f, _f, _f, _f, C.POINTER(_f), C.POINTER(_f), _vp, _vp, _f, _i, _vp,
                                   _vp, _vp]),
     "cnerf_mse": (_i, [_vp, _vp, _i64, _vp, _vp, _vp]),
+    "cnerf_mse_ws_floats": (_i64, [_i64]),
+    "cnerf_mse_ws": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "cnerf_loss_ws_floats": (_i64, []),
     "cnerf_masked_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
     "cnerf_patch_depth_loss": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp, _vp]),

@@ -191,6 +191,49 @@ extern "C" int cnerf_mse(const float* x, const float* y, int64_t n, float* loss,
   return CNERF_OK;
 }
 
+// Large inputs (whole images: img2mse of a rendered 756 x 1008 frame is 2.3 M elements): one workgroup per MSE_CHUNK elements writes
+// its fp64 partial, a second single-workgroup stage sums the partials in index order — the value does not depend on the grid the
+// first stage ran on or on the order its workgroups finished in.
+namespace {
+constexpr int64_t MSE_CHUNK = 16384;
+__global__ __launch_bounds__(T) void mse_part_k(const float* __restrict__ x, const float* __restrict__ y, int64_t n,
+                                                double* __restrict__ part, float* __restrict__ d_x) {
+  __shared__ double sh[T / 64];
+  const int64_t lo = (int64_t)blockIdx.x * MSE_CHUNK, hi = lo + MSE_CHUNK < n ? lo + MSE_CHUNK : n;
+  const float w = (float)(2.0 / (double)n);
+  double s = 0;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += T) {
+    const float d = x[i] - y[i];
+    s += (double)(d * d);
+    if (d_x) d_x[i] = w * d;
+  }
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(T) void mse_fin_k(const double* __restrict__ part, int64_t nparts, int64_t n, float* __restrict__ loss) {
+  __shared__ double sh[T / 64];
+  double s = 0;
+  for (int64_t i = threadIdx.x; i < nparts; i += T) s += part[i];
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) loss[0] = (float)(s / (double)n);
+}
+}  // namespace
+
+extern "C" int64_t cnerf_mse_ws_floats(int64_t n) { return n <= 0 ? 0 : 2 * ((n + MSE_CHUNK - 1) / MSE_CHUNK); }
+
+extern "C" int cnerf_mse_ws(const float* x, const float* y, int64_t n, float* loss, float* d_x, float* workspace, void* stream) {
+  if (!x || !y || !loss || n <= 0) return CNERF_E_ARG;
+  if (!workspace || n <= MSE_CHUNK) return cnerf_mse(x, y, n, loss, d_x, stream);
+  if (((uintptr_t)workspace & 7) != 0) return CNERF_E_ARG;      // fp64 partials
+  const int64_t nparts = (n + MSE_CHUNK - 1) / MSE_CHUNK;
+  hipLaunchKernelGGL(mse_part_k, dim3((unsigned)nparts), dim3(T), 0, cn_stream(stream), x, y, n, reinterpret_cast<double*>(workspace),
+                     d_x);
+  CN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(mse_fin_k, dim3(1), dim3(T), 0, cn_stream(stream), reinterpret_cast<const double*>(workspace), nparts, n, loss);
+  CN_CHECK_LAUNCH();
+  return CNERF_OK;
+}
+
 extern "C" int64_t cnerf_loss_ws_floats(void) { return 0; }
 
 extern "C" int cnerf_masked_loss(const float* rgb, const float* target, const float* depth, const float* prior,

@@ -522,12 +522,20 @@ def masked_loss(rgb, target, depth, prior, mask, far: float, coef: float, counts
     return loss, d_rgb, d_depth
 
 
+MSE_SINGLE_WORKGROUP = 65536    # elements up to which cnerf_mse's one workgroup is the faster form (launch-bound)
+
+
 def mse(x: Tensor, y: Tensor, want_grad: bool = True):
     """cnerf_mse: (mean((x - y)^2) as a 0-d tensor, d loss / d x | None)."""
     x, y = _chk(x, "x"), _chk(y, "y")
     loss = torch.empty(1, device=x.device)
     d_x = torch.empty_like(x) if want_grad else None
-    _lib.check(_lib.load().cnerf_mse(_p(x), _p(y), x.numel(), _p(loss), _p(d_x), _stream()), "cnerf_mse")
+    lib, n = _lib.load(), x.numel()
+    if n > MSE_SINGLE_WORKGROUP:     # whole images: one workgroup per 16384 elements + a fixed-order second stage
+        ws = torch.empty(lib.cnerf_mse_ws_floats(n) // 2, device=x.device, dtype=torch.float64)
+        _lib.check(lib.cnerf_mse_ws(_p(x), _p(y), n, _p(loss), _p(d_x), _p(ws), _stream()), "cnerf_mse_ws")
+    else:
+        _lib.check(lib.cnerf_mse(_p(x), _p(y), n, _p(loss), _p(d_x), _stream()), "cnerf_mse")
     return loss[0], d_x
 
 

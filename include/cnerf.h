@@ -285,6 +285,10 @@ int cnerf_hard_mask_pair(int H, int W, float fx, float fy, float cx, float cy, c
 /* img2mse (run_nerf_helpers.py:9): loss[0] = mean((x - y)^2) over n elements; d_x (nullable) = 2 (x - y) / n, the
  * gradient of the loss w.r.t. x.  One launch, fixed summation order. */
 int cnerf_mse(const float* x, const float* y, int64_t n, float* loss, float* d_x, void* stream);
+/* The same for whole images (H:9 on a rendered frame, R:836-845): `workspace` of cnerf_mse_ws_floats(n) floats (8-byte aligned) holds
+ * one fp64 partial per 16384 elements, summed in index order by a second stage; n <= 16384 or workspace == NULL: cnerf_mse. */
+int64_t cnerf_mse_ws_floats(int64_t n);
+int cnerf_mse_ws(const float* x, const float* y, int64_t n, float* loss, float* d_x, float* workspace, void* stream);
 
 /* ---- a14: masked photometric / depth losses  (V:1645-1648, V:1737, V:1786-1788, V:1865) --------- */
 /* loss[0] = mean_{m==1}(rgb-t)^2 + coef*mean_{m==0}(rgb-t)^2 (second term only if some m==0);

@@ -1854,7 +1854,7 @@ def test_img2mse_fused_kernel(dev):
     take the reference's expression."""
     from consistentnerf_amd import run_nerf as R
     rs = np.random.RandomState(3)
-    for shape in ((4096, 3), (4096,), (7, 5, 3), (1,)):
+    for shape in ((4096, 3), (4096,), (7, 5, 3), (1,), (378, 504, 3), (65537,)):     # (the last two: the two-stage whole-image form)
         x = T(rs.uniform(size=shape).astype(np.float32), dev).requires_grad_(True)
         y = T(rs.uniform(size=shape).astype(np.float32), dev).requires_grad_(True)
         l = R.img2mse(x, y)
