@@ -1,3 +1,4 @@
+# quick GPU check between edits: both GPU suites (fp32 and the opt-in bf16x3 arithmetic, without the long teacher-forced test) and a short bench line
 mkdir -p gpurun_out/r4; export TMPDIR=/tmp
 timeout 1500 python -m pytest tests -m gpu -q --timeout=900 --tb=short -p no:cacheprovider --deselect tests/test_gpu_training_parity.py > gpurun_out/r4/test_gpu.log 2>&1; echo "suite fp32 rc=$?"; grep -E "passed|failed" gpurun_out/r4/test_gpu.log | tail -2; grep -E "^FAILED|Error" gpurun_out/r4/test_gpu.log | head -10
 CNERF_TRAIN_PRECISION=bf16x3 timeout 1500 python -m pytest tests -m gpu -q --timeout=900 --tb=line -p no:cacheprovider --deselect tests/test_gpu_training_parity.py 2>&1 | tail -2
