@@ -511,3 +511,21 @@ def test_training_precision_selection(monkeypatch):
     big.training_precision = "fp8"
     with pytest.raises(ValueError):
         R.training_precision(big)
+
+
+def test_bench_launches_per_step_reads_the_last_full_step():
+    """bench.launches_per_step: one training step = the dispatches between two consecutive `adam_k` of the ordered dispatch list;
+    own kernels (anonymous namespace of libcnerf_hip.so) and ATen glue are told apart; fewer than two `adam_k`: nothing to report."""
+    import bench
+    own = lambda n: f"void (anonymous namespace)::{n}((anonymous namespace)::Args)"   # noqa: E731
+    aten = "void at::native::vectorized_elementwise_kernel<4, at::native::FillFunctor<float>, std::array<char*, 1ul> >(int, at::native::FillFunctor<float>, std::array<char*, 1ul>)"
+    seq = [own("pack_k"), own("adam_k"),                                                     # tail of step 0
+           own("pack_rays_k"), aten, own("mlp_fwd_k<8, true, true>"), own("wgrad_k"), own("adam_k"),     # step 1
+           own("pack_rays_k"), own("mlp_fwd_k<8, true, true>"), own("mlp_fwd_k<8, true, true>"), aten, aten, own("wgrad_k"),
+           own("wgrad_reduce_k"), own("adam_k"),                                             # step 2 (the one reported)
+           own("pack_rays_k")]                                                               # head of an unfinished step
+    d = {10 * i + 3: n for i, n in enumerate(seq)}        # dispatch ids: ordered, not dense
+    r = bench.launches_per_step(d)
+    assert r["total"] == 8 and r["own"] == 6 and r["aten_and_runtime"] == 2
+    assert r["kernels"]["mlp_fwd_k<8, true, true>"] == 2 and r["kernels"]["aten:FillFunctor"] == 2 and r["kernels"]["adam_k"] == 1
+    assert bench.launches_per_step({1: own("adam_k"), 2: own("pack_k")}) is None
