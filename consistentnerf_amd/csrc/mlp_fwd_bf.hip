@@ -25,6 +25,10 @@
 
 #include "mlp_bf_common.hpp"
 
+#ifndef CN_TRAIN_PAIR
+#define CN_TRAIN_PAIR false     // tile pairing in the TRAINING forward's register GEMMs: measured level (fine 4.94 vs 4.99 ms, coarse 1.65 vs 1.58) at 13 instead of 6 spilled registers
+#endif
+
 namespace {
 
 // ---- weight packing ------------------------------------------------------------------------------------------------
@@ -389,7 +393,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_bfs_k(BfArgs args_by_value) {
     // what follows this layer's register GEMM in the stream: its own gamma(x) segment, the next layer, or the view branch
     const int nxt = skip ? (int)bg.p_skip : (l + 1 < g.D ? (int)bg.p_trunk[l + 1] : (l + 1 == g.D ? (int)bg.p_feat : (int)bg.p_views));
     if (TRAIN)   // (the input is rectified already; its tiles go out to the stash under this GEMM)
-      gemm_ring_reg<NT, NT, NT, NP, false, StashStores<NT>, 2, false, false>(Out, In, R, (int)(l < g.D ? bg.p_trunk[l] : bg.p_feat), nxt,
+      gemm_ring_reg<NT, NT, NT, NP, false, StashStores<NT>, 2, false, CN_TRAIN_PAIR>(Out, In, R, (int)(l < g.D ? bg.p_trunk[l] : bg.p_feat), nxt,
                                                                              StashStores<NT>{In, srs, svo, tm_col(g.s_h[l - 1])});
     else
       gemm_ring_reg<NT, NT, NT, NP, true>(Out, In, R, (int)(l < g.D ? bg.p_trunk[l] : bg.p_feat), nxt);
@@ -412,7 +416,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_bfs_k(BfArgs args_by_value) {
   bias_init<NTH>(V, P, (int)bg.b_views, hh);
   pin<NTH>(V);
   if (TRAIN)   // the feature tiles (no activation: feature_linear is linear, H:118) go out under the view GEMM
-    gemm_ring_reg<NT, NTH, NT, NP, false, StashStores<NT>, 2, false, false>(V, Y, R, (int)bg.p_views, (int)bg.p_viewsd,
+    gemm_ring_reg<NT, NTH, NT, NP, false, StashStores<NT>, 2, false, CN_TRAIN_PAIR>(V, Y, R, (int)bg.p_views, (int)bg.p_viewsd,
                                                                             StashStores<NT>{Y, srs, svo, tm_col(g.s_feat)});
   else
     gemm_ring_reg<NT, NTH, NT, NP, false>(V, Y, R, (int)bg.p_views, (int)bg.p_viewsd);
