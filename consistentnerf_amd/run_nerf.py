@@ -39,14 +39,19 @@ class RayPoints:
         return self.rays[:, None, 0:3] + self.rays[:, None, 3:6] * self.z_vals[..., None]
 
 
+def _pack_state(model):
+    """(kernel tensors, their identity / version key, the cached (key, buffer, generation, [buffer 0, buffer 1]) or None)"""
+    ts = model.kernel_tensors()
+    key = tuple((t.data_ptr(), t._version, getattr(t, "_cnerf_epoch", 0)) for t in ts)
+    return ts, key, model.__dict__.get("_cnerf_packed")
+
+
 def _packed_gen(model):
     """Kernel-layout weights of `model`, re-packed only when a parameter changed (optimizer step / load).  Two buffers
     alternate, so the copy a forward pass used stays intact for its backward without a per-step clone: it is overwritten
     by the SECOND re-pack after it — two parameter updates between a forward and its backward, where the reference
     itself fails (autograd's version check on the modified weights).  Returns (buffer, generation)."""
-    ts = model.kernel_tensors()
-    key = tuple((t.data_ptr(), t._version, getattr(t, "_cnerf_epoch", 0)) for t in ts)
-    cache = model.__dict__.get("_cnerf_packed")
+    ts, key, cache = _pack_state(model)
     if cache is None or cache[0] != key:
         gen = 0 if cache is None else cache[2] + 1
         bufs = [None, None] if cache is None else cache[3]
@@ -70,9 +75,7 @@ def _prepack_pair(model_a, model_b):
     for m in (model_a, model_b):
         if not hasattr(m, "kernel_tensors"):
             return
-        ts = m.kernel_tensors()
-        key = tuple((t.data_ptr(), t._version, getattr(t, "_cnerf_epoch", 0)) for t in ts)
-        cache = m.__dict__.get("_cnerf_packed")
+        ts, key, cache = _pack_state(m)
         if cache is not None and cache[0] == key:
             return                               # (at most one is stale: its own query re-packs it)
         gen = 0 if cache is None else cache[2] + 1
