@@ -75,7 +75,7 @@ def make_model(D, W, vd, och, seed, dev):
     return m.to(dev), sd
 
 
-def check_param_grads(model, g, prefix_full, prefix_sum, rtol=5e-2, l2tol=5e-3):
+def check_param_grads(model, g, prefix_full, prefix_sum, rtol=5e-2, l2tol=5e-3, bias_tol=None):
     """Gradients vs the reference capture.  NOT a tight bound by construction: one ReLU whose pre-activation
     is within fp32 round-off of 0 gets a different mask on the CPU and on the GPU, which perturbs every
     upstream weight gradient by ~1/M of its scale.  The tight (1e-5) check of the backward kernels is
@@ -93,7 +93,11 @@ def check_param_grads(model, g, prefix_full, prefix_sum, rtol=5e-2, l2tol=5e-3):
         dmax = float(np.abs(got - ref).max()) / scale
         dl2 = float(np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-12))
         rows.append((k, dmax, dl2))
-        if dmax > rtol or dl2 > l2tol:
+        # bias_tol: a bias gradient is ONE column sum over every ray-sample of signed values; where it cancels, max|g| is far below
+        # the mass the fp32 oracle itself rounds against (its sequential CPU sum is the larger error: K_ref32 of
+        # tests/test_gpu_training_parity.py) — the seeded sweeps bound those tensors separately
+        lim = (bias_tol, bias_tol) if (bias_tol is not None and p.dim() == 1) else (rtol, l2tol)
+        if dmax > lim[0] or dl2 > lim[1]:
             bad.append(k)
     for k, dmax, dl2 in rows:
         print(f"    grad {k:28s} rel-max {dmax:.2e}  rel-L2 {dl2:.2e}")
@@ -520,6 +524,55 @@ def test_render_rays_golden(dev, tag, D, W, Nc, Nf, perturb, white, noise, lindi
         check_param_grads(coarse, g, "gc.", "gc.", rtol=2e-3, l2tol=1e-3)
 
 
+def _render_sweep_cases(n=10, seed=20260930):
+    """Seeded draws of render_rays configurations: (D, W, Nc, Nf, perturb, white_bkgd, raw_noise_std, lindisp, B, weight seed)."""
+    rs = np.random.RandomState(seed)
+    out = []
+    for i in range(n):
+        out.append((int(rs.choice([2, 4, 8])), int(rs.choice([64, 128, 256])), int(rs.choice([4, 16, 33, 64])),
+                    int(rs.choice([1, 8, 32, 100, 128])), float(rs.choice([0.0, 1.0])), bool(rs.randint(0, 2)),
+                    float(rs.choice([0.0, 1.0])), bool(rs.randint(0, 2)), int(rs.choice([1, 5, 32, 45, 96])), 300 + 2 * i))
+    return out
+
+
+@pytest.mark.parametrize("D,W,Nc,Nf,perturb,white,noise,lindisp,B,wseed", _render_sweep_cases())
+def test_random_render_rays_vs_oracle(dev, D, W, Nc, Nf, perturb, white, noise, lindisp, B, wseed):
+    """Seeded sweep of a3 (coarse pass, compositing, hierarchical resampling, fine pass) over sample counts that are not multiples
+    of anything, single rays, both backgrounds, density noise and inverse-depth spacing: the coarse level against the oracle at
+    2e-5 (its depths are bit-exact), the fine level and the parameter gradients against the oracle evaluated at the kernel's own
+    fine depths on the kernel's ReLU branch (2e-5 / 1e-5 max per tensor)."""
+    from consistentnerf_amd import run_nerf_view as V
+    far = 6.0
+    coarse, sdc_np = make_model(D, W, True, 5, wseed, dev)
+    fine, sdf_np = make_model(D, W, True, 5, wseed + 1, dev)
+    rays = T(I.ray_batch(B, seed=wseed), dev)
+    ret = V.render_rays(rays, retraw=True, pytest=True, _debug=True, **_kwargs(coarse, fine, Nc, Nf, perturb, white, noise, lindisp))
+    node_f = ret["raw"].grad_fn
+    node_c = node_f.pair.coarse()
+    sdc, sdf = O.as_tensors(sdc_np, True), O.as_tensors(sdf_np, True)
+    flips = []
+    ref = O.render_rays_pytest(rays.cpu(), sdc, sdf, O.NetCfg(D, W, output_ch=5), O.RenderCfg(Nc, Nf, perturb, lindisp, white, noise),
+                               z_fine=ret["_z_vals"].cpu(), flips=flips,
+                               masks_coarse=relu_masks(node_c.stash, B * Nc, D, W, True),
+                               masks_fine=relu_masks(node_f.stash, B * (Nc + Nf), D, W, True))
+    check_flips(flips)
+    for k, tol in (("rgb0", 2e-5), ("acc0", 2e-5), ("depth0", 2e-5 * far), ("rgb_map", 2e-5), ("acc_map", 2e-5),
+                   ("depth_map", 2e-5 * far)):
+        check(ret[k], ref[k].detach(), tol, k)
+    check(ret["raw"], ref["raw"].detach(), 3e-5 * max(1.0, float(ref["raw"].detach().abs().max())), "raw")
+    rs = np.random.RandomState(wseed)
+    tgt = T(rs.uniform(size=(B, 3)).astype(np.float32))
+    loss = V.img2mse(ret["rgb_map"], tgt.to(dev)) + V.img2mse(ret["rgb0"], tgt.to(dev)) + V.img2mse(ret["depth_map"] / far, tgt[:, 0].to(dev))
+    loss.backward()
+    rl = O.mse(ref["rgb_map"], tgt) + O.mse(ref["rgb0"], tgt) + O.mse(ref["depth_map"] / far, tgt[:, 0])
+    assert abs(float(loss.detach()) - float(rl.detach())) <= 2e-6 * max(1e-3, abs(float(rl.detach())))
+    rl.backward()
+    tg = {"gc." + k: (p_.grad if p_.grad is not None else torch.zeros_like(p_)).numpy() for k, p_ in sdc.items()}
+    tg.update({"gf." + k: (p_.grad if p_.grad is not None else torch.zeros_like(p_)).numpy() for k, p_ in sdf.items()})
+    check_param_grads(coarse, tg, "gc.", "gc.", rtol=1e-5, l2tol=1e-5, bias_tol=1e-4)
+    check_param_grads(fine, tg, "gf.", "gf.", rtol=1e-5, l2tol=1e-5, bias_tol=1e-4)
+
+
 def _trained_models(g, dev=None):
     from consistentnerf_amd.run_nerf_helpers import NeRF
     out = []
@@ -925,6 +978,46 @@ def test_envelope_corners_vs_oracle(dev, D, W, vd, och, multires, i_embed):
     # test_mlp_backward_exact_from_stash, which replays the backward from the kernel's own masks)
     deep = D >= 12
     check_param_grads(model, gref, "g.", "g.", rtol=1e-1 if deep else 5e-2, l2tol=3e-2 if deep else 5e-3)
+
+
+def _sweep_cases(n=14, seed=20260929):
+    """Seeded draws from the compiled envelope (D 1-10, W 64 | 128 | 256, view branch or not, 4 / 5 / 8 output channels, ragged
+    point counts incl. single points and non-multiples of 32): (D, W, vd, och, B, S, weight seed)."""
+    rs = np.random.RandomState(seed)
+    out = []
+    for i in range(n):
+        vd = bool(rs.randint(0, 2))
+        out.append((int(rs.randint(1, 11)), int(rs.choice([64, 128, 256])), vd, int(rs.choice([4, 5] if vd else [4, 5, 8])),
+                    int(rs.choice([1, 2, 7, 19, 33, 64])), int(rs.choice([1, 3, 8, 17, 32])), 100 + i))
+    return out
+
+
+@pytest.mark.parametrize("D,W,vd,och,B,S,wseed", _sweep_cases())
+def test_random_networks_vs_oracle(dev, D, W, vd, och, B, S, wseed):
+    """Seeded sweep over the envelope: forward (3e-5 max|raw|) and — on the kernel's own ReLU branch, every pattern difference
+    bounded at the kink — parameter gradients (1e-5 max per tensor) against the CPU oracle, explicit-points mode."""
+    from consistentnerf_amd.run_nerf import run_network
+    from consistentnerf_amd.run_nerf_helpers import get_embedder
+    model, sd_np = make_model(D, W, vd, och, wseed, dev)
+    rs = np.random.RandomState(wseed)
+    pts = rs.uniform(-2, 2, size=(B, S, 3)).astype(np.float32)
+    dirs = rs.normal(size=(B, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+    e, _ = get_embedder(10, 0)
+    ed = get_embedder(4, 0)[0] if vd else None
+    raw = run_network(T(pts, dev), T(dirs, dev) if vd else None, model, e, ed)
+    masks = relu_masks(raw.grad_fn.stash, B * S, D, W, vd)
+    sd = O.as_tensors(sd_np, True)
+    cfg = O.NetCfg(D, W, use_viewdirs=vd, output_ch=och)
+    flips = []
+    ref = O.query(sd, T(pts), T(dirs) if vd else None, cfg, masks, flips)
+    check_flips(flips)
+    check(raw, ref.detach(), 3e-5 * max(1.0, float(ref.detach().abs().max())), "raw")
+    G = T(rs.normal(size=tuple(ref.shape)).astype(np.float32))
+    (raw * G.to(dev)).sum().backward()
+    (ref * G).sum().backward()
+    tight = {"t." + k: (p_.grad if p_.grad is not None else torch.zeros_like(p_)).numpy() for k, p_ in sd.items()}
+    check_param_grads(model, tight, "t.", "t.", rtol=1e-5, l2tol=1e-5)
 
 
 # ------------------------------------------------------------------------------------------------
