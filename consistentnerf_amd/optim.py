@@ -62,7 +62,8 @@ class FusedAdam:
                 p.grad = self.flat_grad[o:o + n].view(p.shape)
                 p._cnerf_direct_grad = True     # _MlpFn.backward accumulates into this view directly
                 p._cnerf_grad_state = GRAD_ZERO
-                p.register_hook(_materialize_on_tensor_route(p))
+                if p.requires_grad:      # (a frozen parameter gets no gradient from either route)
+                    p.register_hook(_materialize_on_tensor_route(p))
 
     def slice_of(self, params):
         """[lo, hi) of the flat buffers covered by `params` (e.g. one network's parameters); they must be contiguous in it."""
