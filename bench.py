@@ -379,6 +379,9 @@ def hbm_kernels(dev, reps=20):
             "kernels": rows}
 
 
+LOSS_ENTRY = "render_loss"      # (main() records --loss-entry here for the passes this command spawns)
+
+
 def pmc_rerun(per_rank, dom_kernel):
     """--pmc: this benchmark re-run under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (one counter per pass, kernel
     trace only — MI355X_MICROARCH.md's HBM recipe; counters cannot be sampled from inside the measuring process), a few steps
@@ -400,7 +403,7 @@ def pmc_rerun(per_rank, dom_kernel):
         try:
             cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
                    sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "2", "--no-extra", "--no-cpu-baseline",
-                   "--rays-per-gpu", str(per_rank)]
+                   "--rays-per-gpu", str(per_rank), "--loss-entry", LOSS_ENTRY]
             try:
                 r = subprocess.run(cmd, capture_output=True, text=True, timeout=180, env=env, cwd="/tmp")
             except subprocess.TimeoutExpired:
@@ -609,11 +612,14 @@ def per_kernel_table(prof, elapsed_ms):
 class Workload:
     """The C2 training step on this rank's shard: model, optimizer, ray bank, exchange."""
 
-    def __init__(self, dev, rank, world, seed=1234, precision="fp32"):
+    def __init__(self, dev, rank, world, seed=1234, precision="fp32", loss_entry="render_loss"):
         import tempfile
         import torch.distributed as dist
         from consistentnerf_amd import distributed as D, run_nerf as R
         self.R, self.D, self.dev, self.rank, self.world = R, D, dev, rank, world
+        self.loss_entry = loss_entry
+        if loss_entry == "render_loss":
+            self.fwd_bwd = self.fwd_bwd_fused
         torch.manual_seed(seed)                       # identical init on every rank (replicated weights)
         with tempfile.TemporaryDirectory() as tmp:
             self.kw, _, _, self.grad_vars, self.opt = R.create_nerf(make_args(tmp))
@@ -645,6 +651,17 @@ class Workload:
         self.opt.zero_grad()
         loss = R.img2mse(rgb, tgt) + R.img2mse(extras['rgb0'], tgt)
         loss.backward()
+        return loss
+
+    def fwd_bwd_fused(self, rays_o, rays_d, tgt):
+        """The same step through run_nerf.render_loss (R:764-775 as one call: the two img2mse terms ride in the compositing launches,
+        their seeds are formed inside the compositing backward; bit-identical loss-side gradients, tests/test_gpu_fused_step.py) and
+        run_nerf.backward (no ones_like fill): 14 launches per step instead of 20."""
+        R = self.R
+        extra_kw = {} if getattr(self, "global_rows", None) is None else {"_global_rows": self.global_rows}
+        loss = R.render_loss(H_IMG, W_IMG, self.K, tgt, chunk=32768, rays=(rays_o, rays_d), retraw=True, **self.kw, **extra_kw)[0]
+        self.opt.zero_grad()
+        R.backward(loss)
         return loss
 
     def body(self, rays_o, rays_d, tgt):
@@ -819,6 +836,10 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: 4096 rays per GPU (global batch 4096 N); strong: the 4096-ray batch sharded N ways (C4)")
     ap.add_argument("--rays-per-gpu", type=int, default=0, help="override the per-GPU shard (e.g. 512 = the 8-way C4 shard)")
+    ap.add_argument("--loss-entry", choices=("render_loss", "reference_lines"), default="render_loss",
+                    help="render_loss: R:764-775 as one call (run_nerf.render_loss + run_nerf.backward, the loss folded into the "
+                         "compositing launches); reference_lines: render() + img2mse() + img2mse() + loss.backward() as the "
+                         "reference's loop writes them")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the legs that follow the timed region")
     ap.add_argument("--graph", action="store_true",
@@ -873,7 +894,9 @@ def main():
         per_rank = B_PER_GPU // world
     else:
         per_rank = B_PER_GPU
-    wl = Workload(dev, rank, world)
+    global LOSS_ENTRY
+    LOSS_ENTRY = a.loss_entry
+    wl = Workload(dev, rank, world, loss_entry=a.loss_entry)
     wl.set_sharding(per_rank, strong=(per_rank * world == B_PER_GPU and world > 1))
     graphed = wl.graphed(per_rank, a.graph_collective) if a.graph else None
     elapsed, loss, prof = wl.run(per_rank, a.steps, a.warmup, graphed=graphed)
@@ -933,6 +956,10 @@ def main():
             "config": {"workload": f"DTU scan8 3-view (synthetic 512x640 ray bank), {per_rank} rays/GPU/step (global batch "
                                    f"{per_rank * world}), coarse 64 + fine 64+128 samples, D=8 W=256 viewdirs MLPs (random init), "
                                    f"perturb=1, mse(rgb)+mse(rgb0), backward, Adam; {cfgname}",
+                       "loss_entry": ("run_nerf.render_loss + run_nerf.backward (R:764-775 as one call, loss folded into the compositing "
+                                      "launches)" if a.loss_entry == "render_loss" else
+                                      "render() + img2mse() + img2mse() + loss.backward() (the reference's lines)"),
+                       "random_streams": "generated inside coarse_z_k / resample_k (Philox4x32-10 on the torch generator's seed / offset)",
                        "rays_per_gpu": per_rank, "global_batch": per_rank * world, "ray_samples_per_ray": NC + NC + NF,
                        "device": name, "cus": cus, "parallelism": f"ray-shard dp{world}" + exch, "final_loss": final_loss},
             "roofline": roofline,

@@ -49,7 +49,13 @@ class RenderGrads(C.Structure):
                                           "g_acc0", "g_depth0")]
 
 
+class Rng(C.Structure):
+    """struct cnerf_rng"""
+    _fields_ = [("seed", C.c_uint64), ("offset", C.c_uint64), ("state_dev", C.c_void_p), ("row0", C.c_int64)]
+
+
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+_RngP = C.POINTER(Rng)
 _NetP, _PtrsP = C.POINTER(Net), C.POINTER(Ptrs)
 
 # name -> (restype, argtypes); every symbol include/cnerf.h declares
@@ -63,6 +69,12 @@ SIGNATURES = {
     "cnerf_pack_weights": (_i, [_NetP, _PtrsP, _vp, _vp]),
     "cnerf_pack_weights_pair": (_i, [_NetP, _PtrsP, _vp, _NetP, _PtrsP, _vp, _vp]),
     "cnerf_coarse_z": (_i, [_vp, _i, _i64, _i, _vp, _vp, _i, _vp, _vp]),
+    "cnerf_uniform_rng": (_i, [_RngP, _i64, _i, _vp, _vp]),
+    "cnerf_coarse_z_rng": (_i, [_vp, _i, _i64, _i, _vp, _RngP, _i, _vp, _vp]),
+    "cnerf_resample_rng": (_i, [_vp, _vp, _RngP, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "cnerf_composite_mse_ws_floats": (_i64, [_i64]),
+    "cnerf_composite_fwd_mse": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cnerf_composite_bwd_mse": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "cnerf_embed": (_i, [_vp, _i64, _i, _vp, _vp]),
     "cnerf_mlp_stash_floats": (_i64, [_NetP, _i64]),
     "cnerf_mlp_fwd": (_i, [_NetP, _vp, _vp, _vp, _i, _vp, _vp, _i64, _i, _vp, _vp, _vp]),
@@ -131,7 +143,7 @@ def load():
         except AttributeError as e:
             raise CnerfError(f"libcnerf_hip.so does not export {name}") from e
         fn.restype, fn.argtypes = res, args
-    if lib.cnerf_abi_version() != 2:
+    if lib.cnerf_abi_version() != 3:
         raise CnerfError("libcnerf_hip.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

@@ -9,6 +9,27 @@ namespace {
 
 constexpr int WAVES = 4;
 
+// img2mse(rgb_map, target) (H:9, R:769-775) folded into the compositing of a level.  Forward: every workgroup leaves the fp64 sum of
+// its rays' squared colour errors in part[blockIdx.x]; the workgroup that takes the last ticket of `counter` sums the partials IN
+// INDEX ORDER (the value does not depend on which workgroup finished last), writes loss[0] = fp32(sum / n) (+ loss_add[0]: the other
+// level's term, `img_loss + img_loss0` in fp32 like R:775) and re-arms the counter.  Backward: the seed d loss / d rgb_map =
+// (2 / n) (rgb_map - target) * g[0] is formed per ray in registers — same operations, same order as img2mse's own backward, so the
+// fused and the separate paths agree bit for bit.
+struct MseFwd {
+  const float* tgt;      // [B,3]; nullptr = no loss
+  double* part;          // [gridDim.x]
+  unsigned* counter;     // zero on entry, zero on exit
+  float* loss;           // [1]
+  const float* loss_add; // [1] or nullptr
+  double n;              // elements of the mean (3 B)
+};
+struct MseBwd {
+  const float* rgb;      // forward rgb_map [B,3]; nullptr = seeds come from g_rgb
+  const float* tgt;
+  const float* g;        // upstream gradient of the loss (device scalar) or nullptr = 1
+  float w;               // fp32(2 / n)
+};
+
 struct Sample {
   float e;      // exp(-relu(sigma)*dist)
   float alpha;  // 1 - e
@@ -80,18 +101,15 @@ __device__ __forceinline__ float ray_norm(const float* __restrict__ ray) {
   return sqrtf(dx * dx + dy * dy + dz * dz);
 }
 
+// one ray by one wave64; returns (lane 0) the squared colour error against tgt (0 without a target)
 template <int C>
-__global__ __launch_bounds__(WAVES * 64) void composite_fwd_k(const float* __restrict__ raw, int ch,
-                                                              const float* __restrict__ z,
-                                                              const float* __restrict__ rays, int rs,
-                                                              const float* __restrict__ noise, int64_t B, int S,
-                                                              int white, float* __restrict__ rgb,
-                                                              float* __restrict__ disp, float* __restrict__ acc,
-                                                              float* __restrict__ depth, float* __restrict__ weights,
-                                                              RayGenDev cam) {
+__device__ __forceinline__ double composite_ray(const float* __restrict__ raw, int ch, const float* __restrict__ z,
+                                               const float* __restrict__ rays, int rs, const float* __restrict__ noise, int64_t b,
+                                               int S, int white, float* __restrict__ rgb, float* __restrict__ disp,
+                                               float* __restrict__ acc, float* __restrict__ depth, float* __restrict__ weights,
+                                               const RayGenDev& cam, const float* __restrict__ tgt) {
   const int lane = threadIdx.x & 63;
-  const int64_t b = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
-  if (b >= B) return;
+  double err = 0.0;
   Sample sm[C];
   float T[C];
   float dn;
@@ -129,7 +147,61 @@ __global__ __launch_bounds__(WAVES * 64) void composite_fwd_k(const float* __res
       const float q = fd / fa;                          // 0/0 -> NaN propagates like torch.max (R:302)
       disp[b] = (q != q) ? q : 1.f / fmaxf(1e-10f, q);
     }
+    if (tgt) {                                          // (x - y)^2 per element in fp32, summed in fp64 like mse_k (loss.hip)
+      const float d0 = r - tgt[b * 3 + 0], d1 = g - tgt[b * 3 + 1], d2 = bl - tgt[b * 3 + 2];
+      err = (double)(d0 * d0) + (double)(d1 * d1) + (double)(d2 * d2);
+    }
   }
+  return err;
+}
+
+template <int C>
+__global__ __launch_bounds__(WAVES * 64) void composite_fwd_k(const float* __restrict__ raw, int ch,
+                                                              const float* __restrict__ z,
+                                                              const float* __restrict__ rays, int rs,
+                                                              const float* __restrict__ noise, int64_t B, int S,
+                                                              int white, float* __restrict__ rgb,
+                                                              float* __restrict__ disp, float* __restrict__ acc,
+                                                              float* __restrict__ depth, float* __restrict__ weights,
+                                                              RayGenDev cam, MseFwd mse) {
+  const int lane = threadIdx.x & 63;
+  const int64_t b = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
+  if (mse.tgt != nullptr) {
+    // loss variant: every wave reaches the workgroup reduction below (a wave past the last ray contributes 0)
+    __shared__ double sq[WAVES];
+    __shared__ int is_last;
+    double e = 0.0;
+    if (b < B) e = composite_ray<C>(raw, ch, z, rays, rs, noise, b, S, white, rgb, disp, acc, depth, weights, cam, mse.tgt);
+    if (lane == 0) sq[threadIdx.x >> 6] = e;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double s = 0.0;
+      for (int w = 0; w < WAVES; ++w) s += sq[w];
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(mse.part) + blockIdx.x, (unsigned long long)__double_as_longlong(s),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __threadfence();
+      const unsigned ticket = __hip_atomic_fetch_add(mse.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      is_last = ticket == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (is_last && threadIdx.x < 64) {
+      __threadfence();
+      double s = 0.0;
+      for (unsigned i = lane; i < gridDim.x; i += 64)
+        s += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(mse.part) + i, __ATOMIC_RELAXED,
+                                                               __HIP_MEMORY_SCOPE_AGENT));
+      s = wave_sum(s);
+      if (lane == 0) {
+        float l = (float)(s / mse.n);
+        if (mse.loss_add) l = l + mse.loss_add[0];
+        mse.loss[0] = l;
+        __hip_atomic_store(mse.counter, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    return;
+  }
+  if (b >= B) return;
+  composite_ray<C>(raw, ch, z, rays, rs, noise, b, S, white, rgb, disp, acc, depth, weights, cam, nullptr);
 }
 
 template <int C>
@@ -141,7 +213,7 @@ __global__ __launch_bounds__(WAVES * 64) void composite_bwd_k(const float* __res
                                                               const float* __restrict__ g_disp,
                                                               const float* __restrict__ g_acc,
                                                               const float* __restrict__ g_depth,
-                                                              float* __restrict__ d_raw) {
+                                                              float* __restrict__ d_raw, MseBwd mse) {
   const int lane = threadIdx.x & 63;
   const int64_t b = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
   if (b >= B) return;
@@ -152,6 +224,12 @@ __global__ __launch_bounds__(WAVES * 64) void composite_bwd_k(const float* __res
   transmittance<C>(sm, T, lane);
   float gr = 0.f, gg = 0.f, gb = 0.f, gd = 0.f, ga = 0.f;
   if (g_rgb) { gr = g_rgb[b * 3 + 0]; gg = g_rgb[b * 3 + 1]; gb = g_rgb[b * 3 + 2]; }
+  if (mse.rgb) {   // the img2mse seed of this level, formed here: (w * (x - y)) * g — the operations of mse_k then `d_x * g`
+    const float g0 = mse.g ? mse.g[0] : 1.f;
+    gr += (mse.w * (mse.rgb[b * 3 + 0] - mse.tgt[b * 3 + 0])) * g0;
+    gg += (mse.w * (mse.rgb[b * 3 + 1] - mse.tgt[b * 3 + 1])) * g0;
+    gb += (mse.w * (mse.rgb[b * 3 + 2] - mse.tgt[b * 3 + 2])) * g0;
+  }
   if (g_depth) gd = g_depth[b];
   if (g_acc) ga = g_acc[b];
   if (white) ga -= (gr + gg + gb);
@@ -231,7 +309,7 @@ extern "C" int cnerf_composite_fwd(const float* raw, int raw_ch, const float* z,
     constexpr int C = decltype(c)::value;
     hipLaunchKernelGGL((composite_fwd_k<C>), dim3((unsigned)cn_div_up(B, WAVES)), dim3(WAVES * 64), 0,
                        cn_stream(stream), raw, raw_ch, z, rays, ray_stride, noise, B, S, white_bkgd, rgb, disp, acc,
-                       depth, weights, cn_no_raygen());
+                       depth, weights, cn_no_raygen(), MseFwd{});
     CN_CHECK_LAUNCH();
     return CNERF_OK;
   });
@@ -246,7 +324,7 @@ int cn_composite_fwd_cam(const float* raw, int raw_ch, const float* z, const Ray
   return dispatch_c(S, [&](auto c) -> int {
     constexpr int C = decltype(c)::value;
     hipLaunchKernelGGL((composite_fwd_k<C>), dim3((unsigned)cn_div_up(B, WAVES)), dim3(WAVES * 64), 0, st, raw, raw_ch, z,
-                       (const float*)nullptr, 0, noise, B, S, white_bkgd, rgb, disp, acc, depth, weights, cam);
+                       (const float*)nullptr, 0, noise, B, S, white_bkgd, rgb, disp, acc, depth, weights, cam, MseFwd{});
     CN_CHECK_LAUNCH();
     return CNERF_OK;
   });
@@ -262,7 +340,45 @@ extern "C" int cnerf_composite_bwd(const float* raw, int raw_ch, const float* z,
     constexpr int C = decltype(c)::value;
     hipLaunchKernelGGL((composite_bwd_k<C>), dim3((unsigned)cn_div_up(B, WAVES)), dim3(WAVES * 64), 0,
                        cn_stream(stream), raw, raw_ch, z, rays, ray_stride, noise, B, S, white_bkgd, g_rgb, g_disp,
-                       g_acc, g_depth, d_raw);
+                       g_acc, g_depth, d_raw, MseBwd{});
+    CN_CHECK_LAUNCH();
+    return CNERF_OK;
+  });
+}
+
+// ---- compositing with img2mse(rgb_map, target) folded in (R:769-775): see MseFwd / MseBwd above ---------------------------------
+extern "C" int64_t cnerf_composite_mse_ws_floats(int64_t B) { return B <= 0 ? 0 : 2 * cn_div_up(B, WAVES) + 2; }
+
+extern "C" int cnerf_composite_fwd_mse(const float* raw, int raw_ch, const float* z, const float* rays, int ray_stride,
+                                       const float* noise, int64_t B, int S, int white_bkgd, const float* target,
+                                       const float* loss_add, float* rgb, float* disp, float* acc, float* depth, float* weights,
+                                       float* loss, float* workspace, unsigned* counter, void* stream) {
+  if (!raw || !z || !rays || !target || !rgb || !loss || !workspace || !counter || B <= 0 || S <= 0 || raw_ch < 4 ||
+      ray_stride < 6 || ((uintptr_t)workspace & 7) != 0)
+    return CNERF_E_ARG;
+  MseFwd m;
+  m.tgt = target; m.part = reinterpret_cast<double*>(workspace); m.counter = counter; m.loss = loss; m.loss_add = loss_add;
+  m.n = 3.0 * (double)B;
+  return dispatch_c(S, [&](auto c) -> int {
+    constexpr int C = decltype(c)::value;
+    hipLaunchKernelGGL((composite_fwd_k<C>), dim3((unsigned)cn_div_up(B, WAVES)), dim3(WAVES * 64), 0, cn_stream(stream), raw, raw_ch,
+                       z, rays, ray_stride, noise, B, S, white_bkgd, rgb, disp, acc, depth, weights, cn_no_raygen(), m);
+    CN_CHECK_LAUNCH();
+    return CNERF_OK;
+  });
+}
+
+extern "C" int cnerf_composite_bwd_mse(const float* raw, int raw_ch, const float* z, const float* rays, int ray_stride,
+                                       const float* noise, int64_t B, int S, int white_bkgd, const float* rgb, const float* target,
+                                       const float* g_loss, float* d_raw, void* stream) {
+  if (!raw || !z || !rays || !rgb || !target || !d_raw || B <= 0 || S <= 0 || raw_ch < 4 || ray_stride < 6) return CNERF_E_ARG;
+  MseBwd m;
+  m.rgb = rgb; m.tgt = target; m.g = g_loss; m.w = (float)(2.0 / (3.0 * (double)B));
+  return dispatch_c(S, [&](auto c) -> int {
+    constexpr int C = decltype(c)::value;
+    hipLaunchKernelGGL((composite_bwd_k<C>), dim3((unsigned)cn_div_up(B, WAVES)), dim3(WAVES * 64), 0, cn_stream(stream), raw, raw_ch,
+                       z, rays, ray_stride, noise, B, S, white_bkgd, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, d_raw, m);
     CN_CHECK_LAUNCH();
     return CNERF_OK;
   });

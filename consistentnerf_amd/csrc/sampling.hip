@@ -2,6 +2,7 @@
 // Replaces render_rays R:355-382 / R:395-399,415 and sample_pdf H:206-250 of the reference.
 // One wave64 per ray for the scan/search/sort parts; everything a ray needs lives in LDS/registers.
 #include "common.hpp"
+#include "rng.hpp"
 
 namespace {
 
@@ -16,7 +17,7 @@ __device__ __forceinline__ float zlin(float near, float far, float t, int lindis
 
 __global__ void coarse_z_k(const float* __restrict__ rays, int rs, int64_t B, int Nc,
                            const float* __restrict__ t_vals, const float* __restrict__ t_rand, int lindisp,
-                           float* __restrict__ z, float cam_near, float cam_far) {
+                           float* __restrict__ z, float cam_near, float cam_far, int use_rng, CnRngK rngk) {
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= B * Nc) return;
   int64_t b = idx / Nc;
@@ -24,13 +25,15 @@ __global__ void coarse_z_k(const float* __restrict__ rays, int rs, int64_t B, in
   // (rays == nullptr: the rays of a camera, generated in the consumers — near / far are the camera's constants)
   float near = rays ? rays[b * rs + 6] : cam_near, far = rays ? rays[b * rs + 7] : cam_far;
   float zi = zlin(near, far, t_vals[i], lindisp);
-  if (t_rand != nullptr) {
+  if (t_rand != nullptr || use_rng) {
     float lower, upper;
     if (i == 0) lower = zi;
     else lower = .5f * (zi + zlin(near, far, t_vals[i - 1], lindisp));
     if (i == Nc - 1) upper = zi;
     else upper = .5f * (zlin(near, far, t_vals[i + 1], lindisp) + zi);
-    zi = lower + (upper - lower) * t_rand[idx];
+    // (use_rng: the jitter is generated here — element (row0 + b, i) of the global [rays, Nc] stream, rng.hpp)
+    const float t = use_rng ? CnRngDev(rngk).uniform(b, Nc, i) : t_rand[idx];
+    zi = lower + (upper - lower) * t;
   }
   z[idx] = zi;
 }
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(WAVES * 64) void resample_k(const float* __restrict
                                                          const float* __restrict__ u_g, int64_t u_stride, int64_t B,
                                                          int Nc, int Nf, float* __restrict__ z_fine,
                                                          float* __restrict__ z_std, float* __restrict__ samples,
-                                                         int64_t* __restrict__ inds) {
+                                                         int64_t* __restrict__ inds, int use_rng, CnRngK rngk) {
   __shared__ ResampleLds lds;
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t b = (int64_t)blockIdx.x * WAVES + wv;
@@ -185,11 +188,13 @@ __global__ __launch_bounds__(WAVES * 64) void resample_k(const float* __restrict
             [&](int k) { return .5f * (zrow[k + 1] + zrow[k]); });
   for (int k = lane; k < Nc; k += 64) all[k] = zrow[k];
   __builtin_amdgcn_wave_barrier();
-  const float* urow = u_g + b * u_stride;
+  const float* urow = use_rng ? nullptr : u_g + b * u_stride;
+  const CnRngDev rng(rngk);
   double s1 = 0.0;
   for (int k = lane; k < Nf; k += 64) {
     int ind;
-    float s = invert_cdf(cdf, bins, Nb, urow[k], &ind);
+    // (use_rng: u is generated here — element (row0 + b, k) of the global [rays, Nf] stream, rng.hpp)
+    float s = invert_cdf(cdf, bins, Nb, use_rng ? rng.uniform(b, Nf, k) : urow[k], &ind);
     all[Nc + k] = s;
     s1 += (double)s;
     if (samples) samples[b * Nf + k] = s;
@@ -269,7 +274,7 @@ extern "C" int cnerf_coarse_z(const float* rays, int ray_stride, int64_t B, int 
   if (B == 0) return CNERF_OK;
   int64_t n = B * Nc;
   hipLaunchKernelGGL(coarse_z_k, dim3((unsigned)cn_div_up(n, 256)), dim3(256), 0, cn_stream(stream), rays, ray_stride,
-                     B, Nc, t_vals, t_rand, lindisp, z, 0.f, 0.f);
+                     B, Nc, t_vals, t_rand, lindisp, z, 0.f, 0.f, 0, CnRngK{});
   CN_CHECK_LAUNCH();
   return CNERF_OK;
 }
@@ -281,7 +286,7 @@ int cn_coarse_z_cam(float near, float far, int64_t B, int Nc, const float* t_val
   if (B == 0) return CNERF_OK;
   int64_t n = B * Nc;
   hipLaunchKernelGGL(coarse_z_k, dim3((unsigned)cn_div_up(n, 256)), dim3(256), 0, st, (const float*)nullptr, 0, B, Nc,
-                     t_vals, t_rand, lindisp, z, near, far);
+                     t_vals, t_rand, lindisp, z, near, far, 0, CnRngK{});
   CN_CHECK_LAUNCH();
   return CNERF_OK;
 }
@@ -304,7 +309,47 @@ extern "C" int cnerf_resample(const float* z, const float* weights, const float*
   if (Nc - 1 > MAX_NB || Nc + Nf > MAX_ALL) return CNERF_E_UNSUPPORTED;
   if (B == 0) return CNERF_OK;
   hipLaunchKernelGGL(resample_k, dim3((unsigned)cn_div_up(B, WAVES)), dim3(WAVES * 64), 0, cn_stream(stream), z,
-                     weights, u, u_row_stride, B, Nc, Nf, z_fine, z_std, samples, inds);
+                     weights, u, u_row_stride, B, Nc, Nf, z_fine, z_std, samples, inds, 0, CnRngK{});
+  CN_CHECK_LAUNCH();
+  return CNERF_OK;
+}
+
+// ---- the same two entry points with the uniform streams generated in-kernel (rng.hpp) -----------------------------------------
+namespace {
+__global__ void uniform_rng_k(CnRngK rngk, int64_t rows, int cols, float* __restrict__ out) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * cols) return;
+  const int64_t b = idx / cols;
+  out[idx] = CnRngDev(rngk).uniform(b, cols, (int)(idx - b * cols));
+}
+}  // namespace
+
+extern "C" int cnerf_uniform_rng(const cnerf_rng* rng, int64_t rows, int cols, float* out, void* stream) {
+  if (!rng || !out || rows < 0 || cols <= 0) return CNERF_E_ARG;
+  if (rows == 0) return CNERF_OK;
+  hipLaunchKernelGGL(uniform_rng_k, dim3((unsigned)cn_div_up(rows * cols, 256)), dim3(256), 0, cn_stream(stream), cn_rng_arg(rng),
+                     rows, cols, out);
+  CN_CHECK_LAUNCH();
+  return CNERF_OK;
+}
+
+extern "C" int cnerf_coarse_z_rng(const float* rays, int ray_stride, int64_t B, int Nc, const float* t_vals, const cnerf_rng* rng,
+                                  int lindisp, float* z, void* stream) {
+  if (!rays || !t_vals || !z || !rng || B < 0 || Nc <= 0 || ray_stride < 8) return CNERF_E_ARG;
+  if (B == 0) return CNERF_OK;
+  hipLaunchKernelGGL(coarse_z_k, dim3((unsigned)cn_div_up(B * Nc, 256)), dim3(256), 0, cn_stream(stream), rays, ray_stride, B, Nc,
+                     t_vals, (const float*)nullptr, lindisp, z, 0.f, 0.f, 1, cn_rng_arg(rng));
+  CN_CHECK_LAUNCH();
+  return CNERF_OK;
+}
+
+extern "C" int cnerf_resample_rng(const float* z, const float* weights, const cnerf_rng* rng, int64_t B, int Nc, int Nf,
+                                  float* z_fine, float* z_std, float* samples, int64_t* inds, void* stream) {
+  if (!z || !weights || !rng || !z_fine || !z_std || B < 0 || Nc < 3 || Nf <= 0) return CNERF_E_ARG;
+  if (Nc - 1 > MAX_NB || Nc + Nf > MAX_ALL) return CNERF_E_UNSUPPORTED;
+  if (B == 0) return CNERF_OK;
+  hipLaunchKernelGGL(resample_k, dim3((unsigned)cn_div_up(B, WAVES)), dim3(WAVES * 64), 0, cn_stream(stream), z, weights,
+                     (const float*)nullptr, (int64_t)0, B, Nc, Nf, z_fine, z_std, samples, inds, 1, cn_rng_arg(rng));
   CN_CHECK_LAUNCH();
   return CNERF_OK;
 }

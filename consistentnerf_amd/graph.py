@@ -7,7 +7,11 @@ recorded once and replayed with a single launch).  What changes from step to ste
     `FusedAdam.make_capturable()` moves them to device memory; `FusedAdam.advance()` uploads the step's 32 bytes from a ring of
     pinned blocks, stream-ordered ahead of every replay (the upload is NOT part of the recording: a recorded copy would read
     whatever the host has written by the time the GPU gets there);
-  * randomness: torch's CUDA generator is graph-safe (philox offsets are advanced per replay).
+  * randomness: the in-kernel jitter / resampling streams (csrc/rng.hpp) read {seed, base offset} from device memory under a
+    recording (ops.RngCapture); `__call__` uploads the device generator's current pair (16 bytes, same pinned-ring discipline as
+    Adam's scalars) and advances the generator by what one replay consumes — a replayed step sees exactly the numbers the eager
+    step in its place would have seen.  Any torch.rand left in the step is graph-safe by itself (torch advances its philox offsets
+    per replay).
 
 Data-parallel steps (a `distributed.GradReducer` is passed): the gradient exchange sits between the backward and Adam.
   collective="split"   (default) two graphs around it: [render, loss, backward] -> eager all-reduce of the flat gradient on the
@@ -21,7 +25,10 @@ the four MFMA kernels are 98.9 % of the step; at the 512 rays per GPU of the 8-w
 launches of an eager step are no longer hidden, and the graph is what keeps the step on the kernels' time."""
 from typing import Callable, Optional, Sequence
 
+import numpy as np
 import torch
+
+from . import ops
 
 
 class GraphedStep:
@@ -62,6 +69,11 @@ class GraphedStep:
             reducer.timing = False                # (timed events cannot be recorded into a graph)
             reducer.hold = collective == "split"  # split: nothing leaves from inside the (recorded) backward
         self.graph = torch.cuda.CUDAGraph()
+        ops.prepare_capture(self.static_in[0].device)
+        self._rng = ops.RngCapture(self.static_in[0].device)
+        self._rng_ring = [torch.zeros(2, dtype=torch.int64).pin_memory() for _ in range(4)]
+        self._rng_ev, self._rng_i = [None] * 4, 0
+        ops.RngCapture.active = self._rng
         ok = False
         if reducer is not None:
             self._msgs_before, self._steps_before = reducer.messages, reducer.steps
@@ -77,6 +89,7 @@ class GraphedStep:
                     optimizer.step(grad_scale=reducer.grad_scale)
             ok = True
         finally:
+            ops.RngCapture.active = None
             if reducer is not None:
                 reducer.timing = timing
                 if not ok:
@@ -91,6 +104,23 @@ class GraphedStep:
             reducer.messages, reducer.steps = self._msgs_before, self._steps_before     # (the recording itself sent nothing)
         torch.cuda.synchronize()
 
+    def _advance_rng(self):
+        """Hand the replay the device generator's current (seed, offset) and advance the generator by what a replay consumes."""
+        if self._rng.used == 0:
+            return
+        dev = self._rng.state.device
+        gen = torch.cuda.default_generators[dev.index if dev.index is not None else torch.cuda.current_device()]
+        off = gen.get_offset()
+        gen.set_offset(off + self._rng.used)
+        i = self._rng_i = (self._rng_i + 1) % len(self._rng_ring)
+        if self._rng_ev[i] is not None:
+            self._rng_ev[i].synchronize()
+        self._rng_ring[i].numpy().view(np.uint64)[:] = (gen.initial_seed() & 0xFFFFFFFFFFFFFFFF, off)
+        self._rng.state.copy_(self._rng_ring[i], non_blocking=True)
+        ev = self._rng_ev[i] or torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self._rng_ev[i] = ev
+
     def release(self):
         """Give the reducer back to eager stepping (split mode sets `reducer.hold`, under which nothing leaves from inside
         loss.backward()): call before stepping eagerly again with the same GradReducer."""
@@ -102,6 +132,7 @@ class GraphedStep:
         for dst, src in zip(self.static_in, inputs):
             dst.copy_(src)
         self.opt.advance(1.0 if self.reducer is None else self.reducer.grad_scale)
+        self._advance_rng()
         self.graph.replay()
         if self.tail_graph is not None:
             self.reducer.finish()                 # eager: every slice of the flat gradient, on the collective's stream

@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import CnerfError, Net, Ptrs, RayGen, RenderCfg, RenderGrads, RenderOut
+from ._lib import CnerfError, Net, Ptrs, RayGen, RenderCfg, RenderGrads, RenderOut, Rng
 
 Tensor = torch.Tensor
 
@@ -143,11 +143,69 @@ def _t_vals(n: int, device) -> Tensor:
     return _TVALS[key]
 
 
-def coarse_z(rays: Tensor, Nc: int, t_rand: Optional[Tensor], lindisp: bool) -> Tensor:
+# In-kernel uniform streams (csrc/rng.hpp).  A stream is named by (seed, offset): both come from torch's OWN generator of the device
+# — seed = its current seed, offset = its philox offset, which every draw advances by RNG_STRIDE (host-side integers: no launch, no
+# sync) — so torch.manual_seed() / get_rng_state() / set_rng_state() govern these streams exactly like they govern torch.rand, and
+# torch.rand calls in between keep their own numbers.  Under hipGraph capture the pair lives in device memory instead
+# (RngCapture: graph.GraphedStep uploads {seed, offset} before every replay and advances the generator by what a replay consumes).
+RNG_STRIDE = 4          # (torch's generator wants offsets in multiples of 4)
+IN_KERNEL_RNG = True    # False: render_rays draws t_rand / u with torch.rand and hands the tensors to the kernels (round-3 form)
+
+
+class RngCapture:
+    """Device-resident {seed, base offset} of the recording in progress; `used` = offsets one replay consumes."""
+    active = None
+
+    def __init__(self, device):
+        self.state = torch.zeros(2, device=device, dtype=torch.int64)
+        self.used = 0
+
+
+@dataclass
+class RngStream:
+    seed: int
+    offset: int
+    state: Optional[Tensor] = None     # device int64[2] (capture mode)
+    row0: int = 0
+
+    def c(self, offset_add: int = 0, row0: Optional[int] = None) -> Rng:
+        return Rng(self.seed & 0xFFFFFFFFFFFFFFFF, (self.offset + offset_add) & 0xFFFFFFFFFFFFFFFF,
+                   None if self.state is None else self.state.data_ptr(), self.row0 if row0 is None else row0)
+
+
+def rng_draw(device, row0: int = 0) -> RngStream:
+    """Reserve RNG_STRIDE consecutive stream offsets (one render_rays call: +0 jitter, +1 resampling) from the device's generator."""
+    cap = RngCapture.active
+    if cap is not None:
+        st = RngStream(0, cap.used, cap.state, row0)
+        cap.used += RNG_STRIDE
+        return st
+    if torch.cuda.is_current_stream_capturing():
+        raise CnerfError("in-kernel random streams inside a hipGraph recording need graph.GraphedStep (or ops.IN_KERNEL_RNG = False)")
+    gen = torch.cuda.default_generators[torch.device(device).index if torch.device(device).index is not None
+                                        else torch.cuda.current_device()]
+    off = gen.get_offset()
+    gen.set_offset(off + RNG_STRIDE)
+    return RngStream(gen.initial_seed(), off, None, row0)
+
+
+def uniform_rng(rng: RngStream, rows: int, cols: int, device, offset_add: int = 0) -> Tensor:
+    out = torch.empty(rows, cols, device=device, dtype=torch.float32)
+    r = rng.c(offset_add)
+    _lib.check(_lib.load().cnerf_uniform_rng(C.byref(r), rows, cols, _p(out), _stream()), "cnerf_uniform_rng")
+    return out
+
+
+def coarse_z(rays: Tensor, Nc: int, t_rand: Optional[Tensor], lindisp: bool, rng: Optional[RngStream] = None) -> Tensor:
     rays = _chk(rays, "rays")
     B = rays.shape[0]
     t_rand = _chk(t_rand, "t_rand")
     z = torch.empty(B, Nc, device=rays.device, dtype=torch.float32)
+    if rng is not None:        # jitter generated in the kernel: stream offset + 0
+        r = rng.c(0)
+        _lib.check(_lib.load().cnerf_coarse_z_rng(_p(rays), rays.shape[1], B, Nc, _p(_t_vals(Nc, rays.device)), C.byref(r),
+                                                  int(lindisp), _p(z), _stream()), "cnerf_coarse_z_rng")
+        return z
     _lib.check(_lib.load().cnerf_coarse_z(_p(rays), rays.shape[1], B, Nc, _p(_t_vals(Nc, rays.device)), _p(t_rand),
                                           int(lindisp), _p(z), _stream()), "cnerf_coarse_z")
     return z
@@ -165,9 +223,19 @@ def sample_pdf(bins: Tensor, weights: Tensor, u: Tensor, want_inds: bool = False
     return (samples, inds) if want_inds else samples
 
 
-def resample(z: Tensor, weights: Tensor, u: Tensor, want_samples: bool = False):
+def resample(z: Tensor, weights: Tensor, u: Optional[Tensor], want_samples: bool = False, rng: Optional[RngStream] = None,
+             Nf: Optional[int] = None):
     z, weights, u = _chk(z, "z"), _chk(weights, "weights"), _chk(u, "u")
     B, Nc = z.shape
+    if rng is not None:        # u generated in the kernel: stream offset + 1
+        z_fine = torch.empty(B, Nc + Nf, device=z.device, dtype=torch.float32)
+        z_std = torch.empty(B, device=z.device, dtype=torch.float32)
+        samples = torch.empty(B, Nf, device=z.device, dtype=torch.float32) if want_samples else None
+        inds = torch.empty(B, Nf, device=z.device, dtype=torch.int64) if want_samples else None
+        r = rng.c(1)
+        _lib.check(_lib.load().cnerf_resample_rng(_p(z), _p(weights), C.byref(r), B, Nc, Nf, _p(z_fine), _p(z_std), _p(samples),
+                                                  _p(inds), _stream()), "cnerf_resample_rng")
+        return (z_fine, z_std, samples, inds) if want_samples else (z_fine, z_std)
     Nf = u.shape[-1]
     stride = 0 if u.dim() == 1 or u.shape[0] == 1 else Nf
     z_fine = torch.empty(B, Nc + Nf, device=z.device, dtype=torch.float32)
@@ -437,6 +505,63 @@ def composite_forward(raw: Tensor, z: Tensor, rays: Tensor, noise: Optional[Tens
                                                int(white_bkgd), _p(rgb), _p(disp), _p(acc), _p(depth), _p(weights),
                                                _stream()), "cnerf_composite_fwd")
     return rgb, disp, acc, weights, depth
+
+
+_MSE_COUNTERS = {}
+
+
+def _mse_counter(device) -> Tensor:
+    """The ticket counter of cnerf_composite_fwd_mse: one zeroed uint32 per (device, stream) — the kernel leaves it zero.  Under a
+    hipGraph recording: one per device that was allocated BEFORE the recording (prepare_capture; memory allocated inside a recording
+    belongs to that graph's pool and must not be cached); without it, a throw-away zeroed word owned by the graph."""
+    if torch.cuda.is_current_stream_capturing():
+        t = _MSE_COUNTERS.get((str(device), "graph"))
+        return t if t is not None else torch.zeros(1, device=device, dtype=torch.int32)
+    key = (str(device), torch.cuda.current_stream().cuda_stream)
+    if key not in _MSE_COUNTERS:
+        _MSE_COUNTERS[key] = torch.zeros(1, device=device, dtype=torch.int32)
+    return _MSE_COUNTERS[key]
+
+
+def prepare_capture(device):
+    """Allocate, outside the recording, what the kernels of a recorded step keep across replays."""
+    key = (str(torch.device(device)), "graph")
+    if key not in _MSE_COUNTERS:
+        _MSE_COUNTERS[key] = torch.zeros(1, device=device, dtype=torch.int32)
+
+
+def composite_forward_mse(raw: Tensor, z: Tensor, rays: Tensor, noise: Optional[Tensor], white_bkgd: bool, target: Tensor,
+                          loss_add: Optional[Tensor] = None):
+    """cnerf_composite_fwd_mse -> (rgb, disp, acc, weights, depth, loss[1]): raw2outputs + img2mse(rgb_map, target) (+ loss_add)."""
+    raw, z, rays, noise = _chk(raw, "raw"), _chk(z, "z"), _chk(rays, "rays"), _chk(noise, "noise")
+    target, loss_add = _chk(target, "target"), _chk(loss_add, "loss_add")
+    B, S = z.shape
+    if B == 0 or tuple(target.shape) != (B, 3):
+        raise CnerfError(f"composite_forward_mse: target must be [{B}, 3] with B > 0, got {tuple(target.shape)}")
+    dev = raw.device
+    rgb = torch.empty(B, 3, device=dev)
+    disp, acc, depth = torch.empty(B, device=dev), torch.empty(B, device=dev), torch.empty(B, device=dev)
+    weights = torch.empty(B, S, device=dev)
+    loss = torch.empty(1, device=dev)
+    lib = _lib.load()
+    ws = torch.empty(lib.cnerf_composite_mse_ws_floats(B) // 2, device=dev, dtype=torch.float64)
+    _lib.check(lib.cnerf_composite_fwd_mse(_p(raw), raw.shape[-1], _p(z), _p(rays), rays.shape[1], _p(noise), B, S,
+                                           int(white_bkgd), _p(target), _p(loss_add), _p(rgb), _p(disp), _p(acc), _p(depth),
+                                           _p(weights), _p(loss), _p(ws), _p(_mse_counter(dev)), _stream()),
+               "cnerf_composite_fwd_mse")
+    return rgb, disp, acc, weights, depth, loss
+
+
+def composite_backward_mse(raw, z, rays, noise, white_bkgd, rgb, target, g_loss) -> Tensor:
+    """cnerf_composite_bwd_mse: d_raw of mean((rgb_map - target)^2) * g_loss (a device scalar, or None = 1)."""
+    raw, z, rays, noise = _chk(raw, "raw"), _chk(z, "z"), _chk(rays, "rays"), _chk(noise, "noise")
+    rgb, target, g_loss = _chk(rgb, "rgb"), _chk(target, "target"), _chk(g_loss, "g_loss")
+    B, S = z.shape
+    d_raw = torch.empty_like(raw)
+    _lib.check(_lib.load().cnerf_composite_bwd_mse(_p(raw), raw.shape[-1], _p(z), _p(rays), rays.shape[1], _p(noise), B, S,
+                                                   int(white_bkgd), _p(rgb), _p(target), _p(g_loss), _p(d_raw), _stream()),
+               "cnerf_composite_bwd_mse")
+    return d_raw
 
 
 def composite_backward(raw, z, rays, noise, white_bkgd, g_rgb, g_disp, g_acc, g_depth) -> Tensor:

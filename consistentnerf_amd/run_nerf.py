@@ -356,6 +356,51 @@ class _CompositeFn(torch.autograd.Function):
         return d_raw, None, None, None, None
 
 
+class _RenderLossFn(torch.autograd.Function):
+    """raw2outputs of the LAST level (R:265-308) with the photometric loss of the training loop folded in (R:769-775):
+    loss = img2mse(rgb_map, target) [+ img2mse(rgb0, target)] as ONE autograd node from (raw, raw_coarse) to the scalar.  Forward:
+    the last level's compositing kernel also reduces the squared error and adds the coarse level's term (computed by ITS compositing
+    launch, render_rays); backward: the two compositing-backward kernels form their seed (2 / n) (rgb - target) * g in registers.
+    Gone from the step: two loss launches, their `+`, the two `d_x * g` of their backward.  The maps come back detached (values for
+    logging, R:776): a caller that differentiates anything else of a map uses render() + img2mse()."""
+
+    @staticmethod
+    def forward(ctx, raw, raw_c, z, z_c, rays, noise, noise_c, white, target, rgb_c, loss_c):
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3] or ctx.needs_input_grad[4] or ctx.needs_input_grad[8]:
+            raise ops.CnerfError("render_loss: gradients w.r.t. z_vals / rays / target are not implemented (only w.r.t. raw)")
+        rgb, disp, acc, weights, depth, loss = ops.composite_forward_mse(raw, z, rays, noise, white, target, loss_add=loss_c)
+        ctx.save_for_backward(raw, raw_c, z, z_c, rays, target, rgb, rgb_c)
+        ctx.noise, ctx.noise_c, ctx.white = noise, noise_c, white
+        ctx.mark_non_differentiable(rgb, disp, acc, weights, depth)
+        ctx.set_materialize_grads(False)
+        return loss.view(()), rgb, disp, acc, weights, depth
+
+    @staticmethod
+    def backward(ctx, g_loss, *_maps):
+        raw, raw_c, z, z_c, rays, target, rgb, rgb_c = ctx.saved_tensors
+        d_raw = d_raw_c = None
+        if g_loss is not None:
+            if ctx.needs_input_grad[0]:
+                d_raw = ops.composite_backward_mse(raw, z, rays, ctx.noise, ctx.white, rgb, target, g_loss)
+            if raw_c is not None and ctx.needs_input_grad[1]:
+                d_raw_c = ops.composite_backward_mse(raw_c, z_c, rays, ctx.noise_c, ctx.white, rgb_c, target, g_loss)
+        return (d_raw, d_raw_c) + (None,) * 9
+
+
+_ONES = {}
+
+
+def backward(loss):
+    """`loss.backward()` without the fill launch of its implicit ones_like seed: the seed is a cached device constant."""
+    key = (str(loss.device), loss.dtype)
+    one = _ONES.get(key)
+    if one is None:
+        one = torch.ones((), device=loss.device, dtype=loss.dtype)
+        if not torch.cuda.is_current_stream_capturing():     # (a tensor allocated inside a recording belongs to the graph's pool)
+            _ONES[key] = one
+    torch.autograd.backward(loss, grad_tensors=one)
+
+
 # ----------------------------------------------------------------------------- reference surface
 def batchify(fn, chunk):
     """R:27-34.  Kept for API parity; the fused kernel tiles internally so chunking is a no-op."""
@@ -428,6 +473,12 @@ def _jitter_and_u(rows, Nc, Nf, dev, global_rows):
     return t_rand, u
 
 
+def _in_kernel_rng():
+    """The jitter / resampling streams are generated inside coarse_z_k / resample_k (ops.rng_draw) — unless switched off, or a
+    hipGraph is being recorded by something other than graph.GraphedStep (torch.rand is the graph-safe generator then)."""
+    return ops.IN_KERNEL_RNG and (ops.RngCapture.active is not None or not torch.cuda.is_current_stream_capturing())
+
+
 def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0, white_bkgd=False, pytest=False):
     """R:265-308 -> (rgb_map, disp_map, acc_map, weights, depth_map)."""
     B = z_vals.shape[0]
@@ -480,6 +531,25 @@ def batchify_rays(rays_flat, chunk=1024 * 32, **kwargs):
         for k in ret:
             all_ret.setdefault(k, []).append(ret[k])
     return {k: (v[0] if len(v) == 1 else torch.cat(v, 0)) for k, v in all_ret.items()}
+
+
+def render_loss(H, W, K, target_s, chunk=1024 * 32, rays=None, **kwargs):
+    """R:764-775 as one call — `rgb, disp, acc, extras = render(H, W, K, chunk=, rays=batch_rays, retraw=True, **render_kwargs_train);
+    img_loss = img2mse(rgb, target_s); loss = img_loss (+ img2mse(extras['rgb0'], target_s))` — with the loss folded into the
+    compositing launches (_RenderLossFn).  -> (loss, rgb, disp, acc, extras); the same values and, after loss.backward() (or
+    run_nerf.backward(loss): no seed fill), the same parameter gradients bit for bit as the lines above, from 6 launches fewer.
+    The maps are detached.  Batches larger than `chunk`, or an empty one, take the lines above literally."""
+    n = rays[0].reshape(-1, 3).shape[0] if rays is not None else 0
+    tgt = target_s.reshape(-1, 3) if torch.is_tensor(target_s) else None
+    if (rays is None or n == 0 or n > chunk or tgt is None or not tgt.is_cuda or tgt.dtype != torch.float32 or tgt.shape[0] != n
+            or kwargs.get('c2w') is not None):
+        rgb, disp, acc, extras = render(H, W, K, chunk=chunk, rays=rays, **kwargs)
+        loss = img2mse(rgb, target_s)
+        if 'rgb0' in extras:
+            loss = loss + img2mse(extras['rgb0'], target_s)
+        return loss, rgb, disp, acc, extras
+    rgb, disp, acc, extras = render(H, W, K, chunk=chunk, rays=rays, _target=tgt.contiguous(), **kwargs)
+    return extras.pop('loss'), rgb, disp, acc, extras
 
 
 def _ray_batch(H, W, K, rays, c2w, ndc, near, far, use_viewdirs, c2w_staticcam, device):
@@ -583,6 +653,11 @@ def _render_camera(H, W, K, chunk, c2w, ndc, near, far, use_viewdirs, with_depth
         if perturb > 0.:
             if pytest:
                 t_rand = pytest_uniform((B, Nc), dev)
+            elif _in_kernel_rng():
+                # the streams render_rays' kernels generate for the same generator state, materialised (this C call takes tensors)
+                rng = ops.rng_draw(dev)
+                t_rand = ops.uniform_rng(rng, B, Nc, dev, 0)
+                u = ops.uniform_rng(rng, B, Nf, dev, 1) if Nf > 0 else None
             else:
                 t_rand, u = _jitter_and_u(B, Nc, Nf, dev, None)     # (the same draw as render_rays: bit-identical paths)
         noise0 = _density_noise((B, Nc), std, pytest, dev)
@@ -616,7 +691,8 @@ def _render(H, W, K, chunk, rays, c2w, ndc, near, far, use_viewdirs, c2w_staticc
     batch, sh = _ray_batch(H, W, K, rays, c2w, ndc, near, far, use_viewdirs, c2w_staticcam, device)
     all_ret = batchify_rays(batch, chunk, _with_depth=with_depth, **kwargs)
     for k in all_ret:
-        all_ret[k] = torch.reshape(all_ret[k], list(sh) + list(all_ret[k].shape[1:]))
+        if all_ret[k].dim() > 0:          # (the scalar of render_loss passes through)
+            all_ret[k] = torch.reshape(all_ret[k], list(sh) + list(all_ret[k].shape[1:]))
     k_extract = ['rgb_map', 'disp_map', 'acc_map'] + (['depth_map'] if with_depth else [])
     ret_list = [all_ret[k] for k in k_extract]
     ret_dict = {k: all_ret[k] for k in all_ret if k not in k_extract}
@@ -742,10 +818,12 @@ def _create_nerf(args, model_cls, view_variant):
 
 def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False, lindisp=False, perturb=0.,
                 N_importance=0, network_fine=None, white_bkgd=False, raw_noise_std=0., verbose=False, pytest=False,
-                _with_depth=False, _debug=False, _global_rows=None):
+                _with_depth=False, _debug=False, _global_rows=None, _target=None):
     """R:311-421 (V:441-551 when _with_depth).  Returns the same dict (+ the sample depths when _debug).
     `_global_rows = (offset, total)`: `ray_batch` is rows [offset, offset + N_rays) of a global batch of `total` rays sharded over
-    ranks — the jitter / resampling / noise streams are drawn for the whole batch and sliced (_rows_of_global)."""
+    ranks — the jitter / resampling / noise streams are drawn for the whole batch and sliced (_rows_of_global).
+    `_target` [N_rays, 3] (render_loss): the compositing launches also produce ret['loss'] = img2mse(rgb_map, _target)
+    (+ img2mse(rgb0, _target) with two levels) through _RenderLossFn; the maps are then detached values."""
     rays = ray_batch if ray_batch.is_contiguous() else ray_batch.contiguous()
     N_rays, dev = rays.shape[0], rays.device
     if N_rays == 0:   # nothing to launch (the reference's batchify_rays raises on an empty batch; here: empty maps)
@@ -763,36 +841,55 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
                 ret['depth0'] = e(0)
         return ret
     viewdirs = rays[:, -3:] if rays.shape[-1] > 8 else None
-    t_rand = u_drawn = None
+    t_rand = u_drawn = rng = None
     if perturb > 0.:
         if pytest:
             t_rand = _pytest_rows(N_rays, N_samples, dev, _global_rows)
+        elif _in_kernel_rng():
+            # no generator launch: both streams are generated where they are consumed, indexed by the GLOBAL row (a shard of a
+            # batch sees the rows the unsharded call sees without drawing the whole batch's stream)
+            rng = ops.rng_draw(dev, 0 if _global_rows is None else int(_global_rows[0]))
         else:
             t_rand, u_drawn = _jitter_and_u(N_rays, N_samples, N_importance, dev, _global_rows)
-    z_vals = ops.coarse_z(rays, N_samples, t_rand, lindisp)
+    z_vals = ops.coarse_z(rays, N_samples, t_rand, lindisp, rng=rng)
     if N_importance > 0:
         _prepack_pair(network_fn, network_fine)
     raw = network_query_fn(RayPoints(rays, z_vals), viewdirs, network_fn)
     noise = _density_noise((N_rays, N_samples), raw_noise_std, pytest, dev, _global_rows)
-    rgb_map, disp_map, acc_map, weights, depth_map = _CompositeFn.apply(raw, z_vals, rays, noise, bool(white_bkgd))
-    z_coarse = z_vals
+    loss = loss_c = None
+    if _target is None:
+        rgb_map, disp_map, acc_map, weights, depth_map = _CompositeFn.apply(raw, z_vals, rays, noise, bool(white_bkgd))
+    elif N_importance > 0:    # coarse level of two: its loss term rides in its compositing launch; the autograd node comes below
+        rgb_map, disp_map, acc_map, weights, depth_map, loss_c = ops.composite_forward_mse(raw, z_vals, rays, noise, bool(white_bkgd),
+                                                                                          _target)
+    else:
+        loss, rgb_map, disp_map, acc_map, weights, depth_map = _RenderLossFn.apply(raw, None, z_vals, None, rays, noise, None,
+                                                                                   bool(white_bkgd), _target, None, None)
+    z_coarse, noise_coarse = z_vals, noise
     if N_importance > 0:
         rgb_map_0, disp_map_0, acc_map_0, depth_map_0 = rgb_map, disp_map, acc_map, depth_map
-        if u_drawn is not None:
+        if rng is not None:
+            u = None                                     # generated inside resample_k
+        elif u_drawn is not None:
             u = u_drawn                                  # drawn together with the jitter above (one generator call)
         elif _global_rows is not None and perturb != 0.:
             u = _pytest_rows(N_rays, N_importance, dev, _global_rows)
         else:
             u = sample_u(N_rays, N_importance, perturb == 0., pytest, dev)
-        z_vals, z_std = ops.resample(z_vals, weights, u)          # R:395-399 + R:415, no gradient (R:397)
+        z_vals, z_std = ops.resample(z_vals, weights, u, rng=rng, Nf=N_importance)   # R:395-399 + R:415, no gradient (R:397)
         run_fn = network_fn if network_fine is None else network_fine
         raw_coarse = raw
         raw = network_query_fn(RayPoints(rays, z_vals), viewdirs, run_fn)
         _link_levels(raw_coarse, raw)
         noise = _density_noise((N_rays, N_samples + N_importance), raw_noise_std, pytest, dev, _global_rows)
-        rgb_map, disp_map, acc_map, weights, depth_map = _CompositeFn.apply(raw, z_vals, rays, noise,
-                                                                            bool(white_bkgd))
+        if _target is None:
+            rgb_map, disp_map, acc_map, weights, depth_map = _CompositeFn.apply(raw, z_vals, rays, noise, bool(white_bkgd))
+        else:
+            loss, rgb_map, disp_map, acc_map, weights, depth_map = _RenderLossFn.apply(
+                raw, raw_coarse, z_vals, z_coarse, rays, noise, noise_coarse, bool(white_bkgd), _target, rgb_map_0, loss_c)
     ret = {'rgb_map': rgb_map, 'disp_map': disp_map, 'acc_map': acc_map}
+    if loss is not None:
+        ret['loss'] = loss
     if _with_depth:
         ret['depth_map'] = depth_map
     if retraw:

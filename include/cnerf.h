@@ -21,7 +21,8 @@
 extern "C" {
 #endif
 
-#define CNERF_ABI_VERSION 2   /* 2: cnerf_adam_step takes its hyper-parameters as double; the *_pair, *_cam, *_bf entry points */
+#define CNERF_ABI_VERSION 3   /* 3: + in-kernel uniform streams (cnerf_rng, *_rng) and compositing with img2mse folded in (*_mse);
+                                * every v2 entry point unchanged.   2: cnerf_adam_step takes its hyper-parameters as double; the *_pair, *_cam, *_bf entry points */
 
 #define CNERF_OK 0
 #define CNERF_E_ARG (-1)        /* null pointer / negative size / inconsistent shapes            */
@@ -73,6 +74,23 @@ int cnerf_pack_weights_pair(const cnerf_net* net0, const cnerf_ptrs* params0, fl
  * jitter; lindisp selects inverse-depth spacing. */
 int cnerf_coarse_z(const float* rays, int ray_stride, int64_t B, int Nc, const float* t_vals,
                    const float* t_rand, int lindisp, float* z, void* stream);
+
+/* The two torch.rand draws of render_rays — t_rand (R:376) and u (H:227) — generated INSIDE the kernels that consume them: a
+ * counter-based stream (Philox4x32-10, one block per element; csrc/rng.hpp, restated in oracle/philox.py) indexed by the GLOBAL element
+ * (row0 + ray) * cols + col, so that a rank holding rows [row0, row0 + B) of a sharded batch sees the rows the unsharded call sees.
+ * Values lie on the 24-bit grid of [0, 1) (ATen's CPU torch.rand for float32).  state_dev != NULL: {seed, base offset} are read from
+ * device memory (uint64[2]) and `offset` is added to the base — the form a captured hipGraph replays with fresh numbers. */
+typedef struct cnerf_rng {
+  uint64_t seed;              /* ignored when state_dev != NULL */
+  uint64_t offset;            /* one value = one independent [rows, cols] stream */
+  const uint64_t* state_dev;  /* NULL or device uint64[2] = {seed, base offset} */
+  int64_t row0;               /* global row of this call's first ray */
+} cnerf_rng;
+/* out[rows, cols] = the stream itself (what the two entry points below consume; for tests and for callers that want the tensor). */
+int cnerf_uniform_rng(const cnerf_rng* rng, int64_t rows, int cols, float* out, void* stream);
+/* cnerf_coarse_z with t_rand[b, i] = stream element (row0 + b, i) of an [*, Nc] stream. */
+int cnerf_coarse_z_rng(const float* rays, int ray_stride, int64_t B, int Nc, const float* t_vals, const cnerf_rng* rng,
+                       int lindisp, float* z, void* stream);
 
 /* ---- a5: stand-alone positional encoding (Embedder.embed H:15-45): x[M,3] -> out[M, 3+6L]. The render
  *      path does not use it (encodings are generated inside cnerf_mlp_fwd and never reach HBM). */
@@ -174,6 +192,21 @@ int cnerf_composite_bwd(const float* raw, int raw_ch, const float* z, const floa
                         const float* g_disp, const float* g_acc, const float* g_depth, float* d_raw,
                         void* stream);
 
+/* a7 with `img2mse(rgb_map, target)` (H:9; R:769-775) folded in — the training step's two loss launches, their sum, and the two
+ * `d_x * g` of their backward disappear.  Forward: as cnerf_composite_fwd (rgb required) + loss[0] = mean((rgb - target)^2)
+ * (+ loss_add[0] when given: the other level's term, added in fp32 like `img_loss + img_loss0`).  Per-workgroup fp64 partial sums in
+ * `workspace` (cnerf_composite_mse_ws_floats(B) floats, 8-byte aligned) are summed in index order by the workgroup that finishes
+ * last; `counter` is one device uint32 that is zero on entry and left zero (one per stream in flight).  Backward: d_raw from the seed
+ * (2 / (3 B)) (rgb - target) * g_loss[0] (g_loss NULL = 1) formed in registers; bit-identical to cnerf_mse + cnerf_composite_bwd. */
+int64_t cnerf_composite_mse_ws_floats(int64_t B);
+int cnerf_composite_fwd_mse(const float* raw, int raw_ch, const float* z, const float* rays, int ray_stride,
+                            const float* noise, int64_t B, int S, int white_bkgd, const float* target, const float* loss_add,
+                            float* rgb, float* disp, float* acc, float* depth, float* weights, float* loss, float* workspace,
+                            unsigned* counter, void* stream);
+int cnerf_composite_bwd_mse(const float* raw, int raw_ch, const float* z, const float* rays, int ray_stride,
+                            const float* noise, int64_t B, int S, int white_bkgd, const float* rgb, const float* target,
+                            const float* g_loss, float* d_raw, void* stream);
+
 /* ---- a8: inverse-CDF sampling  (sample_pdf H:206-250) ------------------------------------------ */
 /* bins[B,Nb], weights[B,Nb-1], u[B,Nf] (u_row_stride 0 broadcasts one row) -> samples[B,Nf];
  * inds[B,Nf] int64 (searchsorted right=True result, the bit-exact parity target) optional.
@@ -191,6 +224,10 @@ int cnerf_sample_pdf(const float* bins, const float* weights, const float* u, in
 int cnerf_resample(const float* z, const float* weights, const float* u, int64_t u_row_stride, int64_t B,
                    int Nc, int Nf, float* z_fine, float* z_std, float* samples, int64_t* inds,
                    void* stream);
+
+/* cnerf_resample with u[b, k] = stream element (row0 + b, k) of an [*, Nf] stream. */
+int cnerf_resample_rng(const float* z, const float* weights, const cnerf_rng* rng, int64_t B, int Nc, int Nf, float* z_fine,
+                       float* z_std, float* samples, int64_t* inds, void* stream);
 
 /* ---- a3 as one call: render_rays (R:311-421 / V:441-551) and its autograd ---------------------------------------- */
 /* The launch sequence of one ray batch — coarse_z -> [encoding + MLP](coarse) -> composite -> (Nf > 0:) resample ->

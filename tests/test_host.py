@@ -30,7 +30,7 @@ def test_header_symbols_all_exported(lib):
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r" T (cnerf_[a-z0-9_]+)", out))
     assert declared <= exported, declared - exported
-    assert lib.cnerf_abi_version() == 2
+    assert lib.cnerf_abi_version() == 3
     assert lib.cnerf_strerror(-2).decode().startswith("configuration")
 
 
@@ -529,3 +529,19 @@ def test_bench_launches_per_step_reads_the_last_full_step():
     assert r["total"] == 8 and r["own"] == 6 and r["aten_and_runtime"] == 2
     assert r["kernels"]["mlp_fwd_k<8, true, true>"] == 2 and r["kernels"]["aten:FillFunctor"] == 2 and r["kernels"]["adam_k"] == 1
     assert bench.launches_per_step({1: own("adam_k"), 2: own("pack_k")}) is None
+
+
+def test_philox_known_answers():
+    """oracle/philox.py (the numpy restatement of csrc/rng.hpp's generator) against the known-answer vectors Random123 publishes
+    for philox4x32-10 (kat_vectors: counter, key -> output) — the pin of the stream oracle the GPU tests compare the kernels with."""
+    from oracle import philox as P
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, out in kat:
+        assert tuple(int(x) for x in P.philox4x32_10(ctr, key)) == out
+    u = P.uniform(7, 12, 512, 64, row0=100)
+    assert u.dtype == np.float32 and u.min() >= 0.0 and u.max() < 1.0 and abs(u.mean() - 0.5) < 0.01
+    # a shard's rows are the rows of the global stream; distinct offsets / seeds are distinct streams
+    assert np.array_equal(P.uniform(7, 12, 612, 64)[100:], u)
+    assert not np.array_equal(P.uniform(7, 13, 512, 64, row0=100), u) and not np.array_equal(P.uniform(8, 12, 512, 64, row0=100), u)
