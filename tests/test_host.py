@@ -545,3 +545,29 @@ def test_philox_known_answers():
     # a shard's rows are the rows of the global stream; distinct offsets / seeds are distinct streams
     assert np.array_equal(P.uniform(7, 12, 612, 64)[100:], u)
     assert not np.array_equal(P.uniform(7, 13, 512, 64, row0=100), u) and not np.array_equal(P.uniform(8, 12, 512, 64, row0=100), u)
+
+
+def test_philox_streams_are_uniform_and_uncorrelated():
+    """Distribution of the in-kernel streams, tested on the numpy restatement (the kernels equal it bit for bit, tests/test_gpu_fused_step.py):
+    chi-square uniformity on 256 bins, lag correlations along a row / down a column / across the two streams of one render_rays
+    call (offset + 0 jitter, offset + 1 resampling) / across consecutive calls (offset + 4) — all at 5 sigma of their nulls."""
+    from oracle import philox as P
+    rows, cols = 4096, 64
+    a = P.uniform(1234, 8, rows, cols).astype(np.float64)
+    n = a.size
+    hist = np.bincount((a.reshape(-1) * 256).astype(np.int64), minlength=256)
+    chi2 = float(((hist - n / 256) ** 2 / (n / 256)).sum())
+    assert abs(chi2 - 255) < 5 * np.sqrt(2 * 255), chi2
+    c = a - 0.5
+
+    def corr(x, y):
+        return float((x * y).mean() / (1 / 12))
+    b = P.uniform(1234, 9, rows, cols).astype(np.float64) - 0.5
+    nxt = P.uniform(1234, 12, rows, cols).astype(np.float64) - 0.5
+    other_seed = P.uniform(1235, 8, rows, cols).astype(np.float64) - 0.5
+    for name, r, m in (("along a row", corr(c[:, :-1], c[:, 1:]), rows * (cols - 1)), ("down a column", corr(c[:-1], c[1:]), (rows - 1) * cols),
+                       ("jitter vs resampling stream", corr(c, b), n), ("consecutive calls", corr(c, nxt), n),
+                       ("adjacent seeds", corr(c, other_seed), n)):
+        assert abs(r) < 5 / np.sqrt(m), (name, r)
+    # 24-bit grid, like ATen's CPU torch.rand for float32
+    assert np.all(a * 2 ** 24 == np.round(a * 2 ** 24))
