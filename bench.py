@@ -980,27 +980,44 @@ def main():
 
     force_leg = os.environ.get("CNERF_BENCH_FORCE_LEG") == "1" and dist.is_initialized()     # (exercise the leg on a 1-rank group)
     if not a.no_extra and (world > 1 or force_leg) and per_rank == B_PER_GPU and B_PER_GPU % world == 0:
-        # the same process group on the strong-scaling shard of C4.  A watchdog prints the line without this leg and ends
-        # the process if the leg has not finished (a collective that never completes cannot be interrupted from Python).
+        # the same process group on the strong-scaling shard of C4 — a SIDE experiment (eager / split-graph / RCCL recorded inside the
+        # graph) that has never seen real multi-GPU hardware.  At world > 1 the contract line therefore goes out FIRST: nothing this
+        # leg does (an exception, a collective that never completes, an abort inside the communicator) can void the measurement of
+        # the timed region.  Its result follows on stderr as its own JSON object (and in gpurun_out/ when that directory exists);
+        # a watchdog ends the process if the leg has not finished (a hung collective cannot be interrupted from Python).  The exit
+        # status stays the main leg's.
+        if world > 1:
+            emit()
         done = threading.Event()
 
         def watchdog():
             if not done.wait(float(os.environ.get("CNERF_BENCH_LEG_TIMEOUT", "120"))):
                 if rank == 0:
                     out.setdefault("extra", {})["c4_strong"] = {"error": "leg did not finish within the watchdog's limit"}
+                    sys.stderr.write(json.dumps({"after_the_line": out["extra"]}) + "\n")
                     emit()
                 sys.stderr.flush()
-                os._exit(6)        # the main line is out, but the launcher must see that a leg hung
+                os._exit(status[0] if world > 1 else 6)
         threading.Thread(target=watchdog, daemon=True).start()
         try:
             leg = shard_leg(wl, B_PER_GPU // (8 if force_leg and world == 1 else world), 100, 10, collective="split",
                             also_capture=dist.get_backend() == "nccl")
         except Exception as e:  # noqa: BLE001 — the main line must survive a failure of the side leg
             leg = {"error": f"{type(e).__name__}: {e}"}
-            status[0] = 5
+            if world == 1:
+                status[0] = 5
         done.set()
         if rank == 0:
             out["extra"] = {"note": "same process group, after the timed region; not part of `value`", "c4_strong": leg}
+            if world > 1:
+                blob = json.dumps({"after_the_line": out["extra"], "n_gpus": world})
+                sys.stderr.write(blob + "\n")
+                try:
+                    if os.path.isdir("gpurun_out"):
+                        with open(os.path.join("gpurun_out", f"bench_c4_strong_{world}gpus.json"), "w") as f:
+                            f.write(blob + "\n")
+                except OSError:
+                    pass
     if rank == 0:
         if world == 1 and not a.no_extra and not force_leg:
             extra = {"note": "same process, after the timed C2 region; not part of `value`"}
