@@ -126,9 +126,19 @@ def draw_patch_starts(H, W, n_patches=4, patch_size=16, precrop=None):
     return starts
 
 
+def _host_to_device(a, dtype, device):
+    """A small host array to the device WITHOUT stalling the host: staged through pinned memory and copied stream-ordered
+    (a pageable-memory copy makes the host wait for everything queued on the stream — one full GPU drain per training step when the
+    array is the step's patch corners)."""
+    t = torch.as_tensor(a, dtype=dtype)
+    if device is None or torch.device(device).type != "cuda" or t.is_cuda:
+        return t if device is None else t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
+
+
 def patch_coords(starts, patch_size=16, device=None):
     """[P, 2] corners -> [P * ps * ps, 2] (row, col); within a patch the ROW index runs fastest (V:1490-1494)."""
-    s = torch.as_tensor(np.asarray(starts), dtype=torch.long, device=device).reshape(-1, 1, 2)
+    s = _host_to_device(np.asarray(starts), torch.long, device).reshape(-1, 1, 2)
     k = torch.arange(patch_size * patch_size, device=device)
     off = torch.stack([k % patch_size, k // patch_size], -1)[None]
     return (s + off).reshape(-1, 2)

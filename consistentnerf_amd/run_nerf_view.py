@@ -205,11 +205,12 @@ def ss_consistency(rays_o, rays_d, depth_cas_s, pose_ref, K, image_ref, depth_re
     c2w_ref[:3, :4] = torch.as_tensor(np.asarray(pose_ref.cpu() if isinstance(pose_ref, torch.Tensor) else pose_ref),
                                       dtype=torch.float32)[:3, :4]
     w2c_ref = torch.inverse(c2w_ref)                       # 4x4 on the host, as VT:910
-    Kt = torch.as_tensor(np.asarray(K.cpu() if isinstance(K, torch.Tensor) else K), dtype=torch.float32).to(dev)
+    from .raybank import _host_to_device          # (small host matrices go up without stalling the host on the stream)
+    Kt = _host_to_device(np.asarray(K.cpu() if isinstance(K, torch.Tensor) else K), torch.float32, dev)
     img = torch.as_tensor(image_ref, dtype=torch.float32).to(dev)[None].permute(0, 3, 1, 2)
     dep = torch.as_tensor(depth_ref, dtype=torch.float32).to(dev)[None]
     rgb_target_ref, rays_depth_ref, pts_c_ref, rays_o_ref, rays_d_ref, mask_bound = get_ref_rays(
-        w2c_ref.to(dev)[None], c2w_ref.to(dev)[None], Kt[None], point_samples_w[None, :, None, :], img, dep, variant="VT")
+        _host_to_device(w2c_ref, torch.float32, dev)[None], _host_to_device(c2w_ref, torch.float32, dev)[None], Kt[None], point_samples_w[None, :, None, :], img, dep, variant="VT")
     if rays_o_ref.shape[0] == 0:
         raise ops.CnerfError("ss_consistency: no point of the batch projects into the reference view "
                              "(the reference loops forever here)")
