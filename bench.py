@@ -357,7 +357,7 @@ def hbm_kernels(dev, reps=20):
             add("composite_fwd_k", f"{tag}, S={S}", B * S * 24 + B * (44 + 28), ms, "24 B per ray-sample (raw 16 + z 4 in, weights 4 out) + 72 B per ray")
             tgt_, loss_ = torch.rand(B, 3, generator=g).to(dev), torch.empty(1, device=dev)
             ws_ = torch.empty(lib.cnerf_composite_mse_ws_floats(B) // 2, device=dev, dtype=torch.float64)
-            ctr_ = torch.zeros(1, device=dev, dtype=torch.int32)
+            ctr_ = torch.zeros(int(lib.cnerf_composite_mse_counter_words()), device=dev, dtype=torch.int32)
             ms = timeit(lambda: lib.cnerf_composite_fwd_mse(P(raw), 4, P(z), P(rays), 11, None, B, S, 0, P(tgt_), None, P(rgb), P(disp), P(acc),
                                                             P(depth), P(wts), P(loss_), P(ws_), P(ctr_), st()))
             add("composite_fwd_k + img2mse (render_loss)", f"{tag}, S={S}", B * S * 24 + B * (44 + 28 + 12), ms,

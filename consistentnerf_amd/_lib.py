@@ -73,6 +73,8 @@ SIGNATURES = {
     "cnerf_coarse_z_rng": (_i, [_vp, _i, _i64, _i, _vp, _RngP, _i, _vp, _vp]),
     "cnerf_resample_rng": (_i, [_vp, _vp, _RngP, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "cnerf_composite_mse_ws_floats": (_i64, [_i64]),
+    "cnerf_composite_mse_counter_words": (_i64, []),
+    "cnerf_composite_mse_max_rays": (_i64, []),
     "cnerf_composite_fwd_mse": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cnerf_composite_bwd_mse": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "cnerf_embed": (_i, [_vp, _i64, _i, _vp, _vp]),

@@ -15,10 +15,14 @@ constexpr int WAVES = 4;
 // level's term, `img_loss + img_loss0` in fp32 like R:775) and re-arms the counter.  Backward: the seed d loss / d rgb_map =
 // (2 / n) (rgb_map - target) * g[0] is formed per ray in registers — same operations, same order as img2mse's own backward, so the
 // fused and the separate paths agree bit for bit.
+constexpr int MSE_WAVES = 8;              // rays per workgroup of the loss form
+constexpr unsigned MSE_GROUP = 64;        // workgroups per first-level ticket counter
+constexpr unsigned MSE_CTR_STRIDE = 64;   // uint32 words between counters (256 B: one counter per cache line / channel)
+constexpr unsigned MSE_CTR_WORDS = 16384; // the caller's zeroed counter block: top counter + up to 255 group counters
 struct MseFwd {
   const float* tgt;      // [B,3]; nullptr = no loss
   double* part;          // [gridDim.x]
-  unsigned* counter;     // zero on entry, zero on exit
+  unsigned* counter;     // MSE_CTR_WORDS words, zero on entry, zero on exit
   float* loss;           // [1]
   const float* loss_add; // [1] or nullptr
   double n;              // elements of the mean (3 B)
@@ -155,8 +159,9 @@ __device__ __forceinline__ double composite_ray(const float* __restrict__ raw, i
   return err;
 }
 
-template <int C>
-__global__ __launch_bounds__(WAVES * 64) void composite_fwd_k(const float* __restrict__ raw, int ch,
+// WV = rays (waves) per workgroup: WAVES for the plain form; MSE_WAVES for the loss form (fewer, fatter partials and tickets)
+template <int C, int WV>
+__global__ __launch_bounds__(WV * 64) void composite_fwd_k(const float* __restrict__ raw, int ch,
                                                               const float* __restrict__ z,
                                                               const float* __restrict__ rays, int rs,
                                                               const float* __restrict__ noise, int64_t B, int S,
@@ -165,27 +170,51 @@ __global__ __launch_bounds__(WAVES * 64) void composite_fwd_k(const float* __res
                                                               float* __restrict__ depth, float* __restrict__ weights,
                                                               RayGenDev cam, MseFwd mse) {
   const int lane = threadIdx.x & 63;
-  const int64_t b = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
+  const int64_t b = (int64_t)blockIdx.x * WV + (threadIdx.x >> 6);
   if (mse.tgt != nullptr) {
-    // loss variant: every wave reaches the workgroup reduction below (a wave past the last ray contributes 0)
-    __shared__ double sq[WAVES];
-    __shared__ int is_last;
+    // loss variant: every wave reaches the workgroup reduction below (a wave past the last ray contributes 0); after it only wave 0
+    // stays for the tickets (the others retire: a workgroup that waits ~2 us for two memory round trips must not hold 16 wave slots)
+    __shared__ double sq[WV];
     double e = 0.0;
     if (b < B) e = composite_ray<C>(raw, ch, z, rays, rs, noise, b, S, white, rgb, disp, acc, depth, weights, cam, mse.tgt);
     if (lane == 0) sq[threadIdx.x >> 6] = e;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x >= 64) return;
+    int is_last = 0;
+    if (lane == 0) {
       double s = 0.0;
-      for (int w = 0; w < WAVES; ++w) s += sq[w];
+      for (int w = 0; w < WV; ++w) s += sq[w];
+      // Publish the partial, then take a ticket.  Everything that crosses workgroups here is an agent-scope ATOMIC access (the
+      // partial is stored write-through with sc1, the reducer loads it with sc1), so no L2 write-back / invalidate is needed: the
+      // store only has to be COMPLETE before the ticket is taken — a workgroup-scope release = s_waitcnt vmcnt(0).  (A full
+      // agent-scope __threadfence() here made every workgroup write back its XCD's L2.)
       __hip_atomic_store(reinterpret_cast<unsigned long long*>(mse.part) + blockIdx.x, (unsigned long long)__double_as_longlong(s),
                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef CN_MSE_HEAVY_FENCE
       __threadfence();
-      const unsigned ticket = __hip_atomic_fetch_add(mse.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-      is_last = ticket == gridDim.x - 1;
+#else
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+#endif
+      // Two-level ticket: same-address atomics at agent scope serialise at ~40 ns each (measured: 8192 workgroups on ONE counter
+      // cost 0.36 ms), so a workgroup first tickets inside its group of MSE_GROUP (one counter per group, 256 B apart); the last of
+      // a group tickets at the top.  <= MSE_GROUP + ngroups serialised atomics instead of gridDim.x.
+      const unsigned grp = blockIdx.x / MSE_GROUP, ngroups = (gridDim.x + MSE_GROUP - 1) / MSE_GROUP;
+      const unsigned in_grp = grp + 1 == ngroups ? gridDim.x - grp * MSE_GROUP : MSE_GROUP;
+      unsigned* gctr = mse.counter + MSE_CTR_STRIDE * (1 + grp);
+      bool last = false;
+      if (__hip_atomic_fetch_add(gctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_grp - 1) {
+        __hip_atomic_store(gctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // re-arm (nobody else touches it any more)
+        last = __hip_atomic_fetch_add(mse.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngroups - 1;
+      }
+      is_last = last;
     }
-    __syncthreads();
-    if (is_last && threadIdx.x < 64) {
+    is_last = __builtin_amdgcn_readfirstlane(is_last);
+    if (is_last) {
+#ifdef CN_MSE_HEAVY_FENCE
       __threadfence();
+#else
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#endif
       double s = 0.0;
       for (unsigned i = lane; i < gridDim.x; i += 64)
         s += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(mse.part) + i, __ATOMIC_RELAXED,
@@ -195,7 +224,7 @@ __global__ __launch_bounds__(WAVES * 64) void composite_fwd_k(const float* __res
         float l = (float)(s / mse.n);
         if (mse.loss_add) l = l + mse.loss_add[0];
         mse.loss[0] = l;
-        __hip_atomic_store(mse.counter, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mse.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     return;
@@ -307,7 +336,7 @@ extern "C" int cnerf_composite_fwd(const float* raw, int raw_ch, const float* z,
   if (B == 0) return CNERF_OK;
   return dispatch_c(S, [&](auto c) -> int {
     constexpr int C = decltype(c)::value;
-    hipLaunchKernelGGL((composite_fwd_k<C>), dim3((unsigned)cn_div_up(B, WAVES)), dim3(WAVES * 64), 0,
+    hipLaunchKernelGGL((composite_fwd_k<C, WAVES>), dim3((unsigned)cn_div_up(B, WAVES)), dim3(WAVES * 64), 0,
                        cn_stream(stream), raw, raw_ch, z, rays, ray_stride, noise, B, S, white_bkgd, rgb, disp, acc,
                        depth, weights, cn_no_raygen(), MseFwd{});
     CN_CHECK_LAUNCH();
@@ -323,7 +352,7 @@ int cn_composite_fwd_cam(const float* raw, int raw_ch, const float* z, const Ray
   if (B == 0) return CNERF_OK;
   return dispatch_c(S, [&](auto c) -> int {
     constexpr int C = decltype(c)::value;
-    hipLaunchKernelGGL((composite_fwd_k<C>), dim3((unsigned)cn_div_up(B, WAVES)), dim3(WAVES * 64), 0, st, raw, raw_ch, z,
+    hipLaunchKernelGGL((composite_fwd_k<C, WAVES>), dim3((unsigned)cn_div_up(B, WAVES)), dim3(WAVES * 64), 0, st, raw, raw_ch, z,
                        (const float*)nullptr, 0, noise, B, S, white_bkgd, rgb, disp, acc, depth, weights, cam, MseFwd{});
     CN_CHECK_LAUNCH();
     return CNERF_OK;
@@ -348,6 +377,8 @@ extern "C" int cnerf_composite_bwd(const float* raw, int raw_ch, const float* z,
 
 // ---- compositing with img2mse(rgb_map, target) folded in (R:769-775): see MseFwd / MseBwd above ---------------------------------
 extern "C" int64_t cnerf_composite_mse_ws_floats(int64_t B) { return B <= 0 ? 0 : 2 * cn_div_up(B, WAVES) + 2; }
+extern "C" int64_t cnerf_composite_mse_counter_words(void) { return MSE_CTR_WORDS; }
+extern "C" int64_t cnerf_composite_mse_max_rays(void) { return (int64_t)(MSE_CTR_WORDS / MSE_CTR_STRIDE - 1) * MSE_GROUP * MSE_WAVES; }
 
 extern "C" int cnerf_composite_fwd_mse(const float* raw, int raw_ch, const float* z, const float* rays, int ray_stride,
                                        const float* noise, int64_t B, int S, int white_bkgd, const float* target,
@@ -356,13 +387,15 @@ extern "C" int cnerf_composite_fwd_mse(const float* raw, int raw_ch, const float
   if (!raw || !z || !rays || !target || !rgb || !loss || !workspace || !counter || B <= 0 || S <= 0 || raw_ch < 4 ||
       ray_stride < 6 || ((uintptr_t)workspace & 7) != 0)
     return CNERF_E_ARG;
+  if (B > cnerf_composite_mse_max_rays()) return CNERF_E_UNSUPPORTED;
   MseFwd m;
   m.tgt = target; m.part = reinterpret_cast<double*>(workspace); m.counter = counter; m.loss = loss; m.loss_add = loss_add;
   m.n = 3.0 * (double)B;
   return dispatch_c(S, [&](auto c) -> int {
     constexpr int C = decltype(c)::value;
-    hipLaunchKernelGGL((composite_fwd_k<C>), dim3((unsigned)cn_div_up(B, WAVES)), dim3(WAVES * 64), 0, cn_stream(stream), raw, raw_ch,
-                       z, rays, ray_stride, noise, B, S, white_bkgd, rgb, disp, acc, depth, weights, cn_no_raygen(), m);
+    hipLaunchKernelGGL((composite_fwd_k<C, MSE_WAVES>), dim3((unsigned)cn_div_up(B, MSE_WAVES)), dim3(MSE_WAVES * 64), 0,
+                       cn_stream(stream), raw, raw_ch, z, rays, ray_stride, noise, B, S, white_bkgd, rgb, disp, acc, depth, weights,
+                       cn_no_raygen(), m);
     CN_CHECK_LAUNCH();
     return CNERF_OK;
   });

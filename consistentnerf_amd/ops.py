@@ -511,23 +511,31 @@ _MSE_COUNTERS = {}
 
 
 def _mse_counter(device) -> Tensor:
-    """The ticket counter of cnerf_composite_fwd_mse: one zeroed uint32 per (device, stream) — the kernel leaves it zero.  Under a
+    """The ticket counters of cnerf_composite_fwd_mse: one zeroed block per (device, stream) — the kernel leaves it zero.  Under a
     hipGraph recording: one per device that was allocated BEFORE the recording (prepare_capture; memory allocated inside a recording
     belongs to that graph's pool and must not be cached); without it, a throw-away zeroed word owned by the graph."""
     if torch.cuda.is_current_stream_capturing():
         t = _MSE_COUNTERS.get((str(device), "graph"))
-        return t if t is not None else torch.zeros(1, device=device, dtype=torch.int32)
+        return t if t is not None else torch.zeros(_mse_counter_words(), device=device, dtype=torch.int32)
     key = (str(device), torch.cuda.current_stream().cuda_stream)
     if key not in _MSE_COUNTERS:
-        _MSE_COUNTERS[key] = torch.zeros(1, device=device, dtype=torch.int32)
+        _MSE_COUNTERS[key] = torch.zeros(_mse_counter_words(), device=device, dtype=torch.int32)
     return _MSE_COUNTERS[key]
+
+
+def _mse_counter_words() -> int:
+    return int(_lib.load().cnerf_composite_mse_counter_words())
+
+
+def composite_mse_max_rays() -> int:
+    return int(_lib.load().cnerf_composite_mse_max_rays())
 
 
 def prepare_capture(device):
     """Allocate, outside the recording, what the kernels of a recorded step keep across replays."""
     key = (str(torch.device(device)), "graph")
     if key not in _MSE_COUNTERS:
-        _MSE_COUNTERS[key] = torch.zeros(1, device=device, dtype=torch.int32)
+        _MSE_COUNTERS[key] = torch.zeros(_mse_counter_words(), device=device, dtype=torch.int32)
 
 
 def composite_forward_mse(raw: Tensor, z: Tensor, rays: Tensor, noise: Optional[Tensor], white_bkgd: bool, target: Tensor,

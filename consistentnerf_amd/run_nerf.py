@@ -541,7 +541,7 @@ def render_loss(H, W, K, target_s, chunk=1024 * 32, rays=None, **kwargs):
     The maps are detached.  Batches larger than `chunk`, or an empty one, take the lines above literally."""
     n = rays[0].reshape(-1, 3).shape[0] if rays is not None else 0
     tgt = target_s.reshape(-1, 3) if torch.is_tensor(target_s) else None
-    if (rays is None or n == 0 or n > chunk or tgt is None or not tgt.is_cuda or tgt.dtype != torch.float32 or tgt.shape[0] != n
+    if (rays is None or n == 0 or n > min(chunk, ops.composite_mse_max_rays()) or tgt is None or not tgt.is_cuda or tgt.dtype != torch.float32 or tgt.shape[0] != n
             or kwargs.get('c2w') is not None):
         rgb, disp, acc, extras = render(H, W, K, chunk=chunk, rays=rays, **kwargs)
         loss = img2mse(rgb, target_s)

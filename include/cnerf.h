@@ -196,9 +196,12 @@ int cnerf_composite_bwd(const float* raw, int raw_ch, const float* z, const floa
  * `d_x * g` of their backward disappear.  Forward: as cnerf_composite_fwd (rgb required) + loss[0] = mean((rgb - target)^2)
  * (+ loss_add[0] when given: the other level's term, added in fp32 like `img_loss + img_loss0`).  Per-workgroup fp64 partial sums in
  * `workspace` (cnerf_composite_mse_ws_floats(B) floats, 8-byte aligned) are summed in index order by the workgroup that finishes
- * last; `counter` is one device uint32 that is zero on entry and left zero (one per stream in flight).  Backward: d_raw from the seed
+ * last (two-level tickets); `counter` = cnerf_composite_mse_counter_words() device uint32 words that are zero on entry and left zero
+ * (one block per stream in flight); B <= cnerf_composite_mse_max_rays() (130 560), else CNERF_E_UNSUPPORTED.  Backward: d_raw from the seed
  * (2 / (3 B)) (rgb - target) * g_loss[0] (g_loss NULL = 1) formed in registers; bit-identical to cnerf_mse + cnerf_composite_bwd. */
 int64_t cnerf_composite_mse_ws_floats(int64_t B);
+int64_t cnerf_composite_mse_counter_words(void);
+int64_t cnerf_composite_mse_max_rays(void);
 int cnerf_composite_fwd_mse(const float* raw, int raw_ch, const float* z, const float* rays, int ray_stride,
                             const float* noise, int64_t B, int S, int white_bkgd, const float* target, const float* loss_add,
                             float* rgb, float* disp, float* acc, float* depth, float* weights, float* loss, float* workspace,

@@ -125,7 +125,7 @@ def _coarse_weights(out, rays, kw, dev):
 
 
 # ------------------------------------------------------------------------------------------------ loss folded into compositing
-@pytest.mark.parametrize("B", [1, 3, 4, 5, 511, 4096, 10007])
+@pytest.mark.parametrize("B", [1, 3, 4, 5, 255, 256, 257, 511, 4096, 10007, 65280])
 @pytest.mark.parametrize("S,white", [(64, False), (192, True), (40, False)])
 def test_composite_with_the_loss_folded_in(dev, B, S, white):
     """cnerf_composite_fwd_mse / _bwd_mse vs cnerf_composite_fwd + cnerf_mse + `d_x * g` + cnerf_composite_bwd: the maps and d_raw
@@ -140,7 +140,7 @@ def test_composite_with_the_loss_folded_in(dev, B, S, white):
     add = torch.rand(1, device=dev, generator=g)
     rgb, disp, acc, wts, depth = ops.composite_forward(raw, z, rays, None, white)
     loss_ref, d_x = ops.mse(rgb, tgt)
-    outs = [ops.composite_forward_mse(raw, z, rays, None, white, tgt, loss_add=add) for _ in range(3)]
+    outs = [ops.composite_forward_mse(raw, z, rays, None, white, tgt, loss_add=add) for _ in range(3 if B > 20000 else 25)]
     for o in outs:
         for a, b in zip(o[:5], (rgb, disp, acc, wts, depth)):
             assert same(a, b)
@@ -153,6 +153,21 @@ def test_composite_with_the_loss_folded_in(dev, B, S, white):
         want_d = ops.composite_backward(raw, z, rays, None, white, seed, None, None, None)
         got_d = ops.composite_backward_mse(raw, z, rays, None, white, rgb, tgt, gl)
         assert torch.equal(got_d, want_d)
+
+
+def test_composite_loss_limits(dev):
+    """Beyond cnerf_composite_mse_max_rays() rays per call the entry point refuses (render_loss then takes the reference's lines)."""
+    from consistentnerf_amd import ops
+    from consistentnerf_amd._lib import CnerfError
+    n = ops.composite_mse_max_rays()
+    assert n == 130560
+    B = n + 4
+    raw, z = torch.zeros(B, 8, 4, device=dev), torch.rand(B, 8, device=dev).sort(-1)[0]
+    rays = torch.ones(B, 11, device=dev)
+    with pytest.raises(CnerfError):
+        ops.composite_forward_mse(raw, z, rays, None, False, torch.zeros(B, 3, device=dev))
+    # the counters are left zero by every call, also by the refused one
+    assert int(ops._mse_counter(dev).abs().sum()) == 0
 
 
 def _step_pair(dev, Nf, owned):
