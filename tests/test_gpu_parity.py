@@ -2332,6 +2332,30 @@ def test_bench_gpus_2_launched_plainly_is_its_own_launcher(dev):
         assert "Traceback" not in r.stderr
 
 
+def test_bench_gpus_2_default_legs_line_first_then_the_side_leg(dev):
+    """The shape of the driver's N > 1 command — no --no-extra: at world > 1 the contract line is printed BEFORE the C4 strong-shard
+    side leg runs (nothing that leg does can void the scaling measurement), stdout still carries exactly one line, the leg's result
+    follows on stderr as its own JSON object, and the exit status is the main leg's.  Two ranks over gloo on the one GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                            "CNERF_FORCE_DIST")}
+    env.update(CNERF_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", CNERF_BENCH_LEG_TIMEOUT="600")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, env=env, timeout=1200)
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, lines, r.stderr[-3000:])
+    o = json.loads(lines[0])
+    assert o["n_gpus"] == 2 and o["dist"]["ranks"] == 2 and o["value"] > 0 and o["config"]["rays_per_gpu"] == 4096
+    assert "extra" not in o or "c4_strong" not in o.get("extra", {})          # the line left before the leg started
+    after = [json.loads(ln) for ln in r.stderr.splitlines() if ln.startswith('{"after_the_line"')]
+    assert len(after) == 1, r.stderr[-3000:]
+    leg = after[0]["after_the_line"]["c4_strong"]
+    assert "error" not in leg and leg["rays_per_gpu"] == 2048 and leg["ms_per_step_eager"] > 0, leg
+
+
 def test_graphed_step_equals_eager_steps(dev):
     """graph.GraphedStep: the whole training step (render of both levels, fused losses, the merged backward, FusedAdam with its
     scalars in device memory, weight packing) recorded once as a hipGraph and replayed — bit-identical to the same steps run
