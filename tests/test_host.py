@@ -34,6 +34,34 @@ def test_header_symbols_all_exported(lib):
     assert lib.cnerf_strerror(-2).decode().startswith("configuration")
 
 
+def test_every_entry_point_rejects_null_and_empty_arguments(lib):
+    """include/cnerf.h: "<0 for an argument error".  Every int-returning entry point called with null pointers and zero sizes
+    returns a CNERF_E_* code before it touches the device (so this runs without a GPU) — no launch, no crash.  One child
+    process for all of them: a regression that dereferences a null would end the child, not the test session."""
+    code = r"""
+import sys, ctypes as C
+sys.path.insert(0, %r)
+from consistentnerf_amd import _lib as L
+lib = C.CDLL(L.LIB_PATH)
+for name, (res, args) in L.SIGNATURES.items():
+    if res is not C.c_int or not args:
+        continue
+    fn = getattr(lib, name); fn.restype = res; fn.argtypes = args
+    kind = lambda a: getattr(a, "_type_", None)          # one-letter code for the scalar ctypes, else a pointer / char_p
+    vals = [0.0 if kind(a) in ("f", "d") else (0 if isinstance(kind(a), str) and kind(a) in "iIlLqQhHbB" else None) for a in args]
+    print(name, fn(*vals), flush=True)
+""" % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout[-300:], r.stderr[-300:])
+    seen = dict(ln.split() for ln in r.stdout.strip().splitlines())
+    from consistentnerf_amd import _lib
+    import ctypes as C
+    want = {n for n, (res, args) in _lib.SIGNATURES.items() if res is C.c_int and args}
+    assert set(seen) == want and len(want) >= 40
+    bad = {n: c for n, c in seen.items() if int(c) not in (-1, -2, -3)}
+    assert not bad, bad
+
+
 def test_tensor_bookkeeping_matches_reference_state_dict(lib):
     """cnerf_tensor_shape order/shapes == reference state_dict (minus the 3 scalars) for the BASELINE nets."""
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
