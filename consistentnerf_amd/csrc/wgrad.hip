@@ -39,7 +39,11 @@ constexpr int TM = 32;                      // points per LDS slab
 constexpr int OCTF = 264;                   // LDS pitch (floats) of one 32-point x 8-column block: 256 + 8 (banks)
 constexpr int LDS_BYTES = 160 * 1024;       // all of a CU's LDS: one workgroup per CU
 constexpr int DUMMY_BYTES = 1024;           // landing zone of the no-op DMA pieces (out-of-range reads write zeros)
+#ifdef CN_WGRAD_DYN
+constexpr int LDS_FLOATS = (LDS_BYTES - DUMMY_BYTES - 16) / 4;   // + one ticket word
+#else
 constexpr int LDS_FLOATS = (LDS_BYTES - DUMMY_BYTES) / 4;
+#endif
 
 struct WgJob {
   int net;            // which operand set (WgArgs::net) the job reads / writes: 0, or 1 for the second network of a pair
@@ -71,6 +75,8 @@ struct WgArgs {
   WgJob job[MAX_WG_JOBS];
   WgNet net[2];
   int nj;
+  int total;          // virtual blocks of the launch (CN_WGRAD_DYN)
+  int* counter;       // device ticket counter, zero before the launch (CN_WGRAD_DYN)
 };
 
 // The kernel argument block is read IN PLACE through the constant address space (scalar loads from the kernarg
@@ -124,8 +130,8 @@ __device__ __forceinline__ i32x4 dma_rsrc(const float* base, unsigned bytes) {
 
 // Body for a compile-time per-wave tile block AN x AK (<= 4 x 4); BS: this wave also sums the X columns (bias).
 template <int AN, int AK, bool BS>
-__device__ __forceinline__ void wgrad_body(WgNetC& a, WgJobC& jb, float* lds) {
-  const int split = __builtin_amdgcn_readfirstlane((int)blockIdx.x - jb.first);
+__device__ __forceinline__ void wgrad_body(WgNetC& a, WgJobC& jb, float* lds, const int vb) {
+  const int split = __builtin_amdgcn_readfirstlane(vb - jb.first);
   const int tid = threadIdx.x, lane = tid & 63, i31 = lane & 31, hh = lane >> 5;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform on the scalar unit: addresses stay SALU
   const int wn = wv / jb.gk, wk = wv - wn * jb.gk;
@@ -346,10 +352,10 @@ __device__ __forceinline__ void wgrad_body(WgNetC& a, WgJobC& jb, float* lds) {
 // MFMAs of K-step kk; a slab (32 points = 2 K-steps) is published by ONE barrier in the MIDDLE of the previous slab's iteration,
 // right before its first reads; its DMA is issued a full iteration ahead (two buffers).
 template <int AN, int AK, bool BS>
-__device__ __forceinline__ void wgrad_body_bf3(WgNetC& a, WgJobC& jb, float* lds) {
+__device__ __forceinline__ void wgrad_body_bf3(WgNetC& a, WgJobC& jb, float* lds, const int vb) {
   constexpr int NF = AN + AK;                       // fragments per K-step: A (dZ columns) 0..AN-1, B (H columns) AN..NF-1
   static_assert(AN * AK >= NF, "side work is dealt out over the tile pairs");
-  const int split = __builtin_amdgcn_readfirstlane((int)blockIdx.x - jb.first);
+  const int split = __builtin_amdgcn_readfirstlane(vb - jb.first);
   const int tid = threadIdx.x, lane = tid & 63, i31 = lane & 31, hh = lane >> 5;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wv / jb.gk, wk = wv - wn * jb.gk;
@@ -575,50 +581,74 @@ __device__ __forceinline__ void wgrad_body_bf3(WgNetC& a, WgJobC& jb, float* lds
 }
 
 template <int AN, int AK>
-__device__ __forceinline__ void wgrad_disp_bf3(WgNetC& a, WgJobC& jb, float* lds) {
+__device__ __forceinline__ void wgrad_disp_bf3(WgNetC& a, WgJobC& jb, float* lds, const int vb) {
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (jb.bias_tensor >= 0 && wv % jb.gk == 0) wgrad_body_bf3<AN, AK, true>(a, jb, lds);
-  else wgrad_body_bf3<AN, AK, false>(a, jb, lds);
+  if (jb.bias_tensor >= 0 && wv % jb.gk == 0) wgrad_body_bf3<AN, AK, true>(a, jb, lds, vb);
+  else wgrad_body_bf3<AN, AK, false>(a, jb, lds, vb);
 }
 
 template <int AN, int AK>
-__device__ __forceinline__ void wgrad_disp(WgNetC& a, WgJobC& jb, float* lds) {
+__device__ __forceinline__ void wgrad_disp(WgNetC& a, WgJobC& jb, float* lds, const int vb) {
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (jb.bias_tensor >= 0 && wv % jb.gk == 0) wgrad_body<AN, AK, true>(a, jb, lds);
-  else wgrad_body<AN, AK, false>(a, jb, lds);
+  if (jb.bias_tensor >= 0 && wv % jb.gk == 0) wgrad_body<AN, AK, true>(a, jb, lds, vb);
+  else wgrad_body<AN, AK, false>(a, jb, lds, vb);
 }
 
 // `wgrad_k` = the exact-fp32 kernel of the default path (its code is untouched by the opt-in arithmetic); `wgrad_mixed_k` = the
 // same grid with the bf16x3 body for the jobs flagged bf3 and the fp32 body for the rest (launched only by cnerf_mlp_wgrad_bf*).
 template <bool MIXED>
-__device__ __forceinline__ void wgrad_kernel_body() {
-  extern __shared__ __attribute__((aligned(16))) float lds[];   // [2 buffers][X slab | Y slab]
-  WgArgsC& args = *(WgArgsC*)__builtin_amdgcn_kernarg_segment_ptr();
-  // 1-D grid, jobs back to back: the job of this block = the last one whose first block id is <= blockIdx.x (scalar loads
+__device__ __forceinline__ void wgrad_one(WgArgsC& args, float* lds, const int vb) {
+  // 1-D grid, jobs back to back: the job of this block = the last one whose first block id is <= vb (scalar loads
   // from the kernarg segment, <= 28 entries)
   int ji = 0;
-  for (int i = 1; i < args.nj; ++i) ji = (int)blockIdx.x >= args.job[i].first ? i : ji;
+  for (int i = 1; i < args.nj; ++i) ji = vb >= args.job[i].first ? i : ji;
   WgJobC& jb = args.job[ji];
   WgNetC& a = args.net[jb.net];
   if (MIXED && jb.bf3) {           // block-uniform: the opt-in bf16x3 body (wide GEMMs only, plan in add_net_jobs)
     switch (jb.an * 8 + jb.ak) {
-      case 4 * 8 + 4: wgrad_disp_bf3<4, 4>(a, jb, lds); return;
-      case 4 * 8 + 2: wgrad_disp_bf3<4, 2>(a, jb, lds); return;
-      case 2 * 8 + 4: wgrad_disp_bf3<2, 4>(a, jb, lds); return;
+      case 4 * 8 + 4: wgrad_disp_bf3<4, 4>(a, jb, lds, vb); return;
+      case 4 * 8 + 2: wgrad_disp_bf3<4, 2>(a, jb, lds, vb); return;
+      case 2 * 8 + 4: wgrad_disp_bf3<2, 4>(a, jb, lds, vb); return;
       default: break;
     }
   }
   switch (jb.an * 8 + jb.ak) {     // block-uniform
-    case 4 * 8 + 4: wgrad_disp<4, 4>(a, jb, lds); break;
-    case 4 * 8 + 2: wgrad_disp<4, 2>(a, jb, lds); break;
-    case 2 * 8 + 4: wgrad_disp<2, 4>(a, jb, lds); break;
-    case 4 * 8 + 1: wgrad_disp<4, 1>(a, jb, lds); break;
-    case 1 * 8 + 4: wgrad_disp<1, 4>(a, jb, lds); break;
-    case 2 * 8 + 2: wgrad_disp<2, 2>(a, jb, lds); break;
-    case 2 * 8 + 1: wgrad_disp<2, 1>(a, jb, lds); break;
-    case 1 * 8 + 2: wgrad_disp<1, 2>(a, jb, lds); break;
-    default: wgrad_disp<1, 1>(a, jb, lds); break;
+    case 4 * 8 + 4: wgrad_disp<4, 4>(a, jb, lds, vb); break;
+    case 4 * 8 + 2: wgrad_disp<4, 2>(a, jb, lds, vb); break;
+    case 2 * 8 + 4: wgrad_disp<2, 4>(a, jb, lds, vb); break;
+    case 4 * 8 + 1: wgrad_disp<4, 1>(a, jb, lds, vb); break;
+    case 1 * 8 + 4: wgrad_disp<1, 4>(a, jb, lds, vb); break;
+    case 2 * 8 + 2: wgrad_disp<2, 2>(a, jb, lds, vb); break;
+    case 2 * 8 + 1: wgrad_disp<2, 1>(a, jb, lds, vb); break;
+    case 1 * 8 + 2: wgrad_disp<1, 2>(a, jb, lds, vb); break;
+    default: wgrad_disp<1, 1>(a, jb, lds, vb); break;
   }
+}
+
+template <bool MIXED>
+__device__ __forceinline__ void wgrad_kernel_body() {
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // [2 buffers][X slab | Y slab]
+  WgArgsC& args = *(WgArgsC*)__builtin_amdgcn_kernarg_segment_ptr();
+#ifdef CN_WGRAD_DYN
+  // EXPERIMENT (-DCN_WGRAD_DYN): one resident workgroup per CU pulls virtual block ids from a device counter (first id = blockIdx.x,
+  // then gridDim.x + ticket): the hardware's first-free-CU balance without the workgroup hand-over (LDS release, dispatch, kernarg
+  // loads).  The next ticket is requested at the START of a job (the atomic's round trip hides behind the job) and published to
+  // the other waves through the LDS word in front of the DMA dummy block at its end.
+  volatile int* tick = (volatile int*)(lds + LDS_FLOATS);
+  int vb = (int)blockIdx.x;
+  for (;;) {
+    int nxt = 0;
+    if (threadIdx.x == 0) nxt = (int)gridDim.x + atomicAdd(args.counter, 1);
+    wgrad_one<MIXED>(args, lds, vb);
+    if (threadIdx.x == 0) *tick = nxt;
+    __syncthreads();
+    vb = __builtin_amdgcn_readfirstlane(*tick);
+    __syncthreads();
+    if (vb >= args.total) break;
+  }
+#else
+  wgrad_one<MIXED>(args, lds, (int)blockIdx.x);
+#endif
 }
 
 __global__ __launch_bounds__(64 * NWAVES) void wgrad_k(WgArgs a_by_value) {
@@ -900,8 +930,25 @@ int cn_wgrad_launch_n(int n, const NetGeom* const* g, const float* const* stash,
       return (int)hipGetLastError();
     attr_set[bf3 ? 1 : 0][dev] = true;
   }
-  if (bf3) hipLaunchKernelGGL(wgrad_mixed_k, dim3(first), dim3(64 * NWAVES), lds_bytes, st, b);
-  else hipLaunchKernelGGL(wgrad_k, dim3(first), dim3(64 * NWAVES), lds_bytes, st, b);
+#ifdef CN_WGRAD_DYN
+  static int* tickets[64] = {};
+  static int ncu[64] = {};
+  if (!tickets[dev]) {
+    if (hipMalloc(reinterpret_cast<void**>(&tickets[dev]), 256) != hipSuccess) return (int)hipGetLastError();
+    if (hipDeviceGetAttribute(&ncu[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return (int)hipGetLastError();
+    if (const char* e = getenv("CNERF_WGRAD_DYN_GRID")) ncu[dev] = atoi(e);
+  }
+  if (hipMemsetAsync(tickets[dev], 0, 4, st) != hipSuccess) return (int)hipGetLastError();
+  b.total = first;
+  b.counter = tickets[dev];
+  const int grid = first < ncu[dev] ? first : ncu[dev];
+#else
+  b.total = first;
+  b.counter = nullptr;
+  const int grid = first;
+#endif
+  if (bf3) hipLaunchKernelGGL(wgrad_mixed_k, dim3(grid), dim3(64 * NWAVES), lds_bytes, st, b);
+  else hipLaunchKernelGGL(wgrad_k, dim3(grid), dim3(64 * NWAVES), lds_bytes, st, b);
   CN_CHECK_LAUNCH();
   r.accumulate = accumulate;
   hipLaunchKernelGGL(wgrad_reduce_k, dim3(64, nr), dim3(256), 0, st, r);
