@@ -47,7 +47,9 @@ def main():
     fn = lambda: lib.cnerf_mlp_wgrad_pair(C.byref(f["net"]), B, f["S"], p(f["stash"]), p(f["ws"]), C.byref(f["ptrs"]),  # noqa: E731
                                           C.byref(c["net"]), B, c["S"], p(c["stash"]), p(c["ws"]), C.byref(c["ptrs"]), 0, st())
     for _ in range(3):
-        fn()
+        rc = fn()
+        if rc != 0:
+            raise SystemExit(f"cnerf_mlp_wgrad_pair -> {rc}")
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); fn(); e1.record()
@@ -55,10 +57,11 @@ def main():
     ms = e0.elapsed_time(e1)
     plan = raw.cnerf_debug_wgrad_plan
     plan.restype = C.c_int
-    out = (C.c_int * (6 * 48))()
-    mk, ideal = C.c_double(), C.c_double()
-    nj = plan(C.byref(f["net"]), C.c_int64(B * 192), C.byref(c["net"]), C.c_int64(B * 64), 256, out, 48, C.byref(mk), C.byref(ideal))
-    jobs = [tuple(out[6 * i:6 * i + 6]) for i in range(nj)]
+    plan.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]
+    out = (C.c_int * (7 * 48))()
+    nj = plan(C.byref(f["net"]), B * 192, C.byref(c["net"]), B * 64, out, 48)   # (net, N, K, tiles, ranges, chunk, tensor) per job
+    assert nj > 0, nj
+    jobs = [tuple(out[7 * i:7 * i + 6]) for i in range(nj)]
     nblocks = sum(j[4] for j in jobs)
     getter = raw.cnerf_debug_timing_wgrad
     getter.restype, getter.argtypes = C.c_int, [C.c_void_p, C.c_int64]
@@ -67,7 +70,7 @@ def main():
     assert getter(buf.ctypes.data, buf.size) == 0
     t = buf.reshape(nw, NS).astype(np.float64)
     t0 = t[:, 6][t[:, 6] > 0].min()
-    print(f"B={B}: wgrad pair (+reduce) {ms:.3f} ms; {nblocks} workgroups; model makespan {mk.value:.0f} us; "
+    print(f"B={B}: wgrad pair (+reduce) {ms:.3f} ms; {nblocks} workgroups; "
           f"measured span of the wgrad kernel {(t[:, 7].max() - t0) / 100:.0f} us")
     b0 = 0
     for (n_, N, K, tiles, ns, ch) in jobs:
@@ -80,7 +83,8 @@ def main():
         act = r[:, :, 5] > 0
         print(f"  net{n_} {N:3d}x{K:3d} tiles {tiles:2d} ranges {ns:3d} x {ch:6d} pts: life {life.mean():7.1f} us (min {life.min():7.1f} max {life.max():7.1f}) "
               f"= {life.mean() / slabs:6.3f} us/slab, {cyc.mean() / slabs:7.0f} cyc/slab; starts {start.min():7.1f}..{start.max():7.1f} us; "
-              f"mfma-loop {100 * r[:, :, 2][act].mean() / r[:, :, 5][act].mean():4.1f}% barrier {100 * r[:, :, 1][act].mean() / r[:, :, 5][act].mean():4.1f}%")
+              f"mfma-loop {100 * r[:, :, 2][act].mean() / r[:, :, 5][act].mean():4.1f}% barrier {100 * r[:, :, 1][act].mean() / r[:, :, 5][act].mean():4.1f}% "
+              f"prologue {r[:, :, 0][act].mean():6.0f} cyc epilogue {r[:, :, 3][act].mean():6.0f} cyc of {r[:, :, 5][act].mean():8.0f}")
         b0 += ns
     # dispatch pattern: XCC of block i, and how many distinct CUs were used
     w0 = t[0::4]      # wave 0 of every block is always active
