@@ -151,7 +151,7 @@ def cpu_baseline(seconds_budget=25.0):
         step(Bc)                               # warm-up (also the bound on what the timed steps will cost)
         tw = time.perf_counter() - t0
         if tw > budget:                        # one step already blew the budget: report it rather than spend more
-            return Bc * (NC + NC + NF) / tw, 1, tw
+            return Bc * (NC + NC + NF) / tw, 0, tw         # n = 0: only the cold step ran
         t0, n = time.perf_counter(), 0
         while n < 1 or (time.perf_counter() - t0 + tw < budget and n < max_steps):
             step(Bc)
@@ -163,14 +163,14 @@ def cpu_baseline(seconds_budget=25.0):
     v256, _, dt256 = timed(256, ncores, 6.0, max_steps=2)
     Bc = 1024 if 4 * dt256 * 3 < seconds_budget else 256
     val, n, dt = timed(Bc, ncores, seconds_budget - 8.0)
-    # all physical cores: a 32-ray probe first (on hundreds of threads a step can collapse to minutes)
+    # all physical cores (SURVEY 8d "N = all physical cores"): the same protocol as the headline figure — one warm-up step, then
+    # >= 3 timed steps of 256 rays inside a 12 s budget (round 4 reported one COLD 32-ray step here, which measured thread start-up)
     phys_val = phys_sample = None
     if phys > ncores:
-        pv, _, pdt = timed(32, phys, 0.0)
-        phys_val, phys_sample = pv, f"one 32-ray step, {pdt:.2f} s"
-        if pv > 0.5 * val:
-            pv2, pn, pdt2 = timed(256, phys, 8.0, max_steps=3)
-            phys_val, phys_sample = pv2, f"{pn} steps of 256 rays, {pdt2:.2f} s/step"
+        pv, pn, pdt = timed(256, phys, 12.0, max_steps=3)
+        phys_val = pv
+        phys_sample = (f"{pn} warm training steps of 256 rays, {pdt:.2f} s/step on {phys} threads" if pn > 0 else
+                       f"ONE cold 256-ray step ({pdt:.2f} s: over the 12 s budget, no warm step was affordable)")
     v1, _, dt1 = timed(64, 1, 0.0)
     torch.set_num_threads(ncores)
     # forward only (the C5 shapes: perturb 0, no gradient): 2048 rays, one warm + one timed call (SURVEY 8d asks for both views)
@@ -187,7 +187,7 @@ def cpu_baseline(seconds_budget=25.0):
             "value_all_physical_cores": phys_val, "value_32_threads": val,
             "sample_physical_cores": phys_sample, "single_thread_value": v1, "logical_cpus_usable": avail,
             "inference_value": inf_val, "inference_sample": f"forward only, 2 x 1024 rays, {ncores} threads (the C5 shapes)",
-            "sample": f"{n} training steps of {Bc} rays (same C2 shapes: 64+192 samples, D=8/W=256, fwd+bwd+Adam), "
+            "sample": f"{max(n, 1)} {'warm' if n else 'COLD'} training steps of {Bc} rays (same C2 shapes: 64+192 samples, D=8/W=256, fwd+bwd+Adam), "
                       f"{dt:.2f} s/step on {ncores} threads, torch {torch.__version__} CPU fp32; host has {phys} physical cores "
                       f"({avail} usable logical cpus of {os.cpu_count()}); `value` = the better of the {ncores}-thread and the "
                       f"{phys}-thread figure"}

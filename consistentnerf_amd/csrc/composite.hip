@@ -184,16 +184,19 @@ __global__ __launch_bounds__(WV * 64) void composite_fwd_k(const float* __restri
     if (lane == 0) {
       double s = 0.0;
       for (int w = 0; w < WV; ++w) s += sq[w];
-      // Publish the partial, then take a ticket.  Everything that crosses workgroups here is an agent-scope ATOMIC access (the
-      // partial is stored write-through with sc1, the reducer loads it with sc1), so no L2 write-back / invalidate is needed: the
-      // store only has to be COMPLETE before the ticket is taken — a workgroup-scope release = s_waitcnt vmcnt(0).  (A full
-      // agent-scope __threadfence() here made every workgroup write back its XCD's L2.)
+      // Publish the partial, then take a ticket.  Everything that crosses workgroups here is an agent-scope ATOMIC access: the
+      // partial is stored write-through (`global_store_dwordx2 ... sc1`), the reducer loads it with sc1, so neither side needs an
+      // L2 write-back / invalidate (the agent-scope release fence = `buffer_wbl2 sc1` made every workgroup write back its XCD's
+      // L2: 44 us per launch).  What the ticket DOES need is the store's completion: vmcnt(0) between the store and the atomic.
+      // A workgroup-scope release fence compiles to NOTHING on gfx950 (the ticket could overtake the partial), so the
+      // wait is written out; `scripts/isa_ticket_check.py` asserts the s_waitcnt vmcnt(0) sits between the two in the ISA.
       __hip_atomic_store(reinterpret_cast<unsigned long long*>(mse.part) + blockIdx.x, (unsigned long long)__double_as_longlong(s),
                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#ifdef CN_MSE_HEAVY_FENCE
+#if defined(CN_MSE_HEAVY_FENCE)
       __threadfence();
-#else
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+#elif !defined(CN_MSE_RELEASE_TICKET)
+      __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): the sc1 store has been acknowledged by the memory side
+      __builtin_amdgcn_sched_barrier(0);
 #endif
       // Two-level ticket: same-address atomics at agent scope serialise at ~40 ns each (measured: 8192 workgroups on ONE counter
       // cost 0.36 ms), so a workgroup first tickets inside its group of MSE_GROUP (one counter per group, 256 B apart); the last of
@@ -202,18 +205,25 @@ __global__ __launch_bounds__(WV * 64) void composite_fwd_k(const float* __restri
       const unsigned in_grp = grp + 1 == ngroups ? gridDim.x - grp * MSE_GROUP : MSE_GROUP;
       unsigned* gctr = mse.counter + MSE_CTR_STRIDE * (1 + grp);
       bool last = false;
-      if (__hip_atomic_fetch_add(gctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_grp - 1) {
+#ifdef CN_MSE_RELEASE_TICKET   // ablation: the textbook form (release-ordered agent-scope RMW; measured in profiles/r05_ticket_*.txt)
+      constexpr int TICKET_ORDER = __ATOMIC_ACQ_REL;
+#else
+      constexpr int TICKET_ORDER = __ATOMIC_RELAXED;
+#endif
+      if (__hip_atomic_fetch_add(gctr, 1u, TICKET_ORDER, __HIP_MEMORY_SCOPE_AGENT) == in_grp - 1) {
         __hip_atomic_store(gctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // re-arm (nobody else touches it any more)
-        last = __hip_atomic_fetch_add(mse.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngroups - 1;
+        last = __hip_atomic_fetch_add(mse.counter, 1u, TICKET_ORDER, __HIP_MEMORY_SCOPE_AGENT) == ngroups - 1;
       }
       is_last = last;
     }
     is_last = __builtin_amdgcn_readfirstlane(is_last);
     if (is_last) {
+      // The tickets form a chain of agent-scope RMWs on device memory: the last ticket was granted after every other workgroup's
+      // (its partial complete before it, above).  The partial loads below are agent-scope atomic loads (sc1: served by the memory
+      // side, never by this XCD's L2 or the vector L1) and depend on is_last, which came back from the ticket atomic, so they cannot
+      // be issued before it returned.
 #ifdef CN_MSE_HEAVY_FENCE
       __threadfence();
-#else
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #endif
       double s = 0.0;
       for (unsigned i = lane; i < gridDim.x; i += 64)

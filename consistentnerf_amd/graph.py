@@ -9,9 +9,12 @@ recorded once and replayed with a single launch).  What changes from step to ste
     whatever the host has written by the time the GPU gets there);
   * randomness: the in-kernel jitter / resampling streams (csrc/rng.hpp) read {seed, base offset} from device memory under a
     recording (ops.RngCapture); `__call__` uploads the device generator's current pair (16 bytes, same pinned-ring discipline as
-    Adam's scalars) and advances the generator by what one replay consumes — a replayed step sees exactly the numbers the eager
-    step in its place would have seen.  Any torch.rand left in the step is graph-safe by itself (torch advances its philox offsets
-    per replay).
+    Adam's scalars) and advances the generator by what one replay consumes.  For a step whose only random numbers are these
+    in-kernel streams and which calls render_rays ONCE (the C2 / C4 step: raw_noise_std = 0) a replayed step sees exactly the
+    numbers the eager step in its place would have seen (tested).  Any torch.rand / torch.randn left in the step (raw_noise_std > 0)
+    is graph-safe by itself — torch advances its philox offsets per replay — and its stream stays disjoint from the in-kernel
+    ones, but the offsets interleave differently from eager stepping (the recording reserves all in-kernel offsets first, torch's
+    whole-graph increment after): valid, independent numbers, NOT the eager step's numbers.
 
 Data-parallel steps (a `distributed.GradReducer` is passed): the gradient exchange sits between the backward and Adam.
   collective="split"   (default) two graphs around it: [render, loss, backward] -> eager all-reduce of the flat gradient on the
@@ -69,7 +72,7 @@ class GraphedStep:
             reducer.timing = False                # (timed events cannot be recorded into a graph)
             reducer.hold = collective == "split"  # split: nothing leaves from inside the (recorded) backward
         self.graph = torch.cuda.CUDAGraph()
-        ops.prepare_capture(self.static_in[0].device)
+        self._mse_counters = ops.prepare_capture(self.static_in[0].device)     # this recording's own ticket block
         self._rng = ops.RngCapture(self.static_in[0].device)
         self._rng_ring = [torch.zeros(2, dtype=torch.int64).pin_memory() for _ in range(4)]
         self._rng_ev, self._rng_i = [None] * 4, 0
@@ -90,6 +93,7 @@ class GraphedStep:
             ok = True
         finally:
             ops.RngCapture.active = None
+            ops.end_capture(self.static_in[0].device)
             if reducer is not None:
                 reducer.timing = timing
                 if not ok:

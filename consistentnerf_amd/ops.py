@@ -512,8 +512,9 @@ _MSE_COUNTERS = {}
 
 def _mse_counter(device) -> Tensor:
     """The ticket counters of cnerf_composite_fwd_mse: one zeroed block per (device, stream) — the kernel leaves it zero.  Under a
-    hipGraph recording: one per device that was allocated BEFORE the recording (prepare_capture; memory allocated inside a recording
-    belongs to that graph's pool and must not be cached); without it, a throw-away zeroed word owned by the graph."""
+    hipGraph recording: the block the recorder allocated BEFORE the recording and owns (prepare_capture: one per GraphedStep, so
+    two recorded steps replayed concurrently on different streams never share tickets; memory allocated inside a recording
+    belongs to that graph's pool and must not be cached); without a recorder, a throw-away zeroed block owned by the graph."""
     if torch.cuda.is_current_stream_capturing():
         t = _MSE_COUNTERS.get((str(device), "graph"))
         return t if t is not None else torch.zeros(_mse_counter_words(), device=device, dtype=torch.int32)
@@ -531,11 +532,17 @@ def composite_mse_max_rays() -> int:
     return int(_lib.load().cnerf_composite_mse_max_rays())
 
 
-def prepare_capture(device):
-    """Allocate, outside the recording, what the kernels of a recorded step keep across replays."""
-    key = (str(torch.device(device)), "graph")
-    if key not in _MSE_COUNTERS:
-        _MSE_COUNTERS[key] = torch.zeros(_mse_counter_words(), device=device, dtype=torch.int32)
+def prepare_capture(device) -> Tensor:
+    """Allocate, outside the recording, what the kernels of a recorded step keep across replays: a ticket-counter block of the
+    recording's OWN (returned: the recorder keeps it alive as long as its graph) — installed as the block launches recorded on this
+    device use until end_capture()."""
+    t = torch.zeros(_mse_counter_words(), device=device, dtype=torch.int32)
+    _MSE_COUNTERS[(str(torch.device(device)), "graph")] = t
+    return t
+
+
+def end_capture(device):
+    _MSE_COUNTERS.pop((str(torch.device(device)), "graph"), None)
 
 
 def composite_forward_mse(raw: Tensor, z: Tensor, rays: Tensor, noise: Optional[Tensor], white_bkgd: bool, target: Tensor,

@@ -17,6 +17,7 @@ from . import ops
 # What a FusedAdam-owned parameter's view of the flat gradient holds: zeros nothing has written since / a gradient / a gradient
 # that zero_grad() dropped (stale values the next writer must overwrite, or zero first).
 GRAD_ZERO, GRAD_LIVE, GRAD_DROPPED = 0, 1, 2
+GRAD_DETACHED = 3      # the caller set p.grad = None and autograd attached a tensor of its own: step() copies it into the view
 
 
 def _materialize_on_tensor_route(p):
@@ -24,6 +25,9 @@ def _materialize_on_tensor_route(p):
     the .grad view) — a view whose contents zero_grad() dropped has to be zero first."""
     def hook(g):
         if g is None:        # (the direct route hands autograd no gradient; the engine still runs the hook of the leaf)
+            return None
+        if p.grad is None:   # the caller detached the view (model.zero_grad(), p.grad = None): AccumulateGrad simply SETS it
+            p._cnerf_grad_state = GRAD_DETACHED
             return None
         if p._cnerf_grad_state == GRAD_DROPPED:
             with torch.no_grad():
@@ -80,10 +84,13 @@ class FusedAdam:
         (run_nerf._MlpFn.backward); whatever else needs defined values first — the tensor route (a hook on every parameter),
         step() without a backward, the GradReducer's all-reduce of a network that had none — goes through materialize_grad().
         Views nothing has written since they were last zero (parameters no loss reaches) stay zero at no cost.
-        set_to_none=False: zero now."""
+        set_to_none=False: zero now.  Code that reads `flat_grad` itself before step() (gradient-norm logging, a hand-written
+        all-reduce) must call materialize_grad() first: until then the views of parameters no backward reached hold stale values."""
         for p, o in zip(self.params, self._offsets):
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
                 p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
+                if p._cnerf_grad_state == GRAD_DETACHED:      # (its gradient lived in autograd's own tensor: the view is stale)
+                    p._cnerf_grad_state = GRAD_DROPPED
         if set_to_none:
             for p in self.params:
                 if p._cnerf_grad_state == GRAD_LIVE:
@@ -97,6 +104,18 @@ class FusedAdam:
         """Gradients dropped by zero_grad() and not overwritten by a backward since become zeros (one fill per contiguous run)."""
         runs = []
         for p, o in zip(self.params, self._offsets):
+            if p._cnerf_grad_state == GRAD_DETACHED:
+                view = self.flat_grad[o:o + p.numel()].view(p.shape)
+                if p.grad is not None and p.grad.data_ptr() != view.data_ptr():
+                    with torch.no_grad():
+                        view.copy_(p.grad)
+                    p.grad = view
+                    p._cnerf_grad_state = GRAD_LIVE
+                elif p.grad is None:
+                    p.grad = view
+                    p._cnerf_grad_state = GRAD_DROPPED
+                else:
+                    p._cnerf_grad_state = GRAD_LIVE
             if p._cnerf_grad_state == GRAD_DROPPED:
                 p._cnerf_grad_state = GRAD_ZERO
                 if runs and runs[-1][1] == o:

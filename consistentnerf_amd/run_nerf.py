@@ -90,17 +90,32 @@ def _prepack_pair(model_a, model_b):
     mb.__dict__["_cnerf_packed"] = (kb, bb[gb & 1], gb, bb)
 
 
-def _packed_bf(model, planes):
-    """bf16-plane panels of `model` for the opt-in reduced-precision inference forward, re-packed when a parameter changed."""
+def _packed_bf_gen(model, planes):
+    """bf16-plane panels of `model` (opt-in reduced-precision forward / the bf16x3 training kernels), re-packed when a parameter
+    changed.  Same two-buffer / generation protocol as _packed_gen: the copy a training forward used survives ONE optimizer step
+    before its backward (forward A, step, forward B, backward A is legal with the fp32 panels, so it is here); a second re-pack
+    overwrites it and the backward refuses (_packed_bf_still_valid).  Returns (buffer, generation)."""
     ts = model.kernel_tensors()
     key = (planes,) + tuple((t.data_ptr(), t._version, getattr(t, "_cnerf_epoch", 0)) for t in ts)
     cache = model.__dict__.get("_cnerf_packed_bf")
     if cache is None or cache[0] != key:
+        same_planes = cache is not None and cache[0][0] == planes
+        gen = cache[2] + 1 if cache is not None else 0          # (monotonic also across a change of plane count)
+        bufs = cache[3] if same_planes else [None, None]
         with torch.no_grad():
-            buf = ops.pack_weights_bf(model.spec(), ts, planes, None if cache is None or cache[0][0] != planes else cache[1])
-        cache = (key, buf)
+            bufs[gen & 1] = ops.pack_weights_bf(model.spec(), ts, planes, bufs[gen & 1])
+        cache = (key, bufs[gen & 1], gen, bufs)
         model.__dict__["_cnerf_packed_bf"] = cache
-    return cache[1]
+    return cache[1], cache[2]
+
+
+def _packed_bf(model, planes):
+    return _packed_bf_gen(model, planes)[0]
+
+
+def _packed_bf_still_valid(model, gen, buf):
+    cache = model.__dict__.get("_cnerf_packed_bf")
+    return cache is not None and cache[2] - gen <= 1 and any(b is buf for b in cache[3])
 
 
 # Training arithmetic: "fp32" (default: exact fp32 MFMA, the arithmetic every parity statement and the headline bench line are
@@ -278,7 +293,7 @@ class _MlpFn(torch.autograd.Function):
         elif train and training_precision(model) == "bf16x3":
             # OPT-IN second training arithmetic (never the default): the forward GEMMs on the bf16 matrix cores at three planes
             # per operand; same stash, so the backward below is unchanged.  `packed` (fp32 panels) still feeds the dgrad.
-            ctx.packed_bf = _packed_bf(model, 3)
+            ctx.packed_bf, ctx.packed_bf_gen = _packed_bf_gen(model, 3)
             raw, stash = ops.mlp_forward_bf_train(spec, ctx.packed_bf, B, S, pts=pts, rays=rays, z=z, dirs=dirs)
         else:
             raw, stash = ops.mlp_forward(spec, packed, B, S, pts=pts, rays=rays, z=z, dirs=dirs, want_stash=train)
@@ -295,6 +310,9 @@ class _MlpFn(torch.autograd.Function):
         if not _packed_still_valid(ctx.model, ctx.packed_gen):
             raise ops.CnerfError("the network's weights were updated twice between this forward pass and its backward "
                                  "(the kernel-layout copy it used has been re-packed)")
+        if getattr(ctx, "packed_bf", None) is not None and not _packed_bf_still_valid(ctx.model, ctx.packed_bf_gen, ctx.packed_bf):
+            raise ops.CnerfError("the network's weights were updated twice between this bf16x3 forward pass and its backward "
+                                 "(the bf16-plane copy it used has been re-packed)")
         # Parameters owned by FusedAdam carry their .grad as a view into the flat gradient buffer: under loss.backward()
         # the wgrad reduction accumulates straight into it (what AccumulateGrad would do with ~50 add/copy launches per
         # step) and autograd gets no per-tensor gradients back.  Anything else — plain nn.Parameters, and
@@ -872,8 +890,10 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
             u = None                                     # generated inside resample_k
         elif u_drawn is not None:
             u = u_drawn                                  # drawn together with the jitter above (one generator call)
-        elif _global_rows is not None and perturb != 0.:
+        elif _global_rows is not None and pytest and perturb != 0.:
             u = _pytest_rows(N_rays, N_importance, dev, _global_rows)
+        elif _global_rows is not None and perturb != 0.:    # (perturb < 0: random u, no jitter was drawn — H:221 det = perturb == 0)
+            u = _rows_of_global(lambda n, c: torch.rand(n, c, device=dev), N_rays, N_importance, _global_rows)
         else:
             u = sample_u(N_rays, N_importance, perturb == 0., pytest, dev)
         z_vals, z_std = ops.resample(z_vals, weights, u, rng=rng, Nf=N_importance)   # R:395-399 + R:415, no gradient (R:397)

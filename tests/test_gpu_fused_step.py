@@ -155,6 +155,59 @@ def test_composite_with_the_loss_folded_in(dev, B, S, white):
         assert torch.equal(got_d, want_d)
 
 
+def test_ticket_publish_under_concurrent_streams_and_hbm_pressure(dev):
+    """VERDICT r04 item 6 / ADVICE r04: the loss form publishes a per-workgroup partial (write-through store, completed by an
+    explicit vmcnt(0)) and then takes a two-level ticket; the last workgroup sums the partials.  Stress: two streams launch it 1000
+    times each, concurrently, on their own counter blocks and workspaces (per-stream, ops._mse_counter), alternating between inputs
+    of different size so that a workspace always holds the PREVIOUS launch's partials of OTHER data (a partial read before it was
+    published would be a wrong, not a stale-but-equal, number), while a third stream keeps HBM saturated with 1 GiB copies.  Every
+    one of the 2000 losses must equal, bit for bit, the value the same launch gives alone on an idle GPU, which in turn equals the
+    two-kernel path (cnerf_composite_fwd + cnerf_mse) to the fp64-association round-off."""
+    from consistentnerf_amd import ops
+    g = torch.Generator(device=dev).manual_seed(5)
+    cases = []
+    for B, S in ((4096, 192), (1000, 64), (8200, 64), (513, 192)):
+        raw = torch.randn(B, S, 4, device=dev, generator=g) * 2
+        rays = T(I.ray_batch(B, seed=B), dev)
+        z = ops.coarse_z(rays, S, torch.rand(B, S, device=dev, generator=g), False)
+        tgt = torch.rand(B, 3, device=dev, generator=g)
+        quiet = ops.composite_forward_mse(raw, z, rays, None, False, tgt)
+        two = ops.mse(ops.composite_forward(raw, z, rays, None, False)[0], tgt, want_grad=False)[0]
+        assert abs(quiet[5].item() - two.item()) <= 2e-7 * two.item()
+        cases.append((raw, z, rays, tgt, quiet[5].clone(), quiet[0].clone()))
+    torch.cuda.synchronize()
+    N = 1000
+    streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+    got = [torch.empty(N, device=dev) for _ in range(2)]
+    rgb_bad = [torch.zeros((), device=dev, dtype=torch.int32) for _ in range(2)]
+    big = torch.empty(2, 1 << 28, device=dev)            # 2 x 1 GiB
+    ctr_ptrs = []
+    for rnd in range(N // 50):
+        with torch.cuda.stream(streams[2]):
+            for _ in range(12):                           # ~2 GiB of traffic per copy: the box's HBM stays busy under the launches
+                big[1].copy_(big[0], non_blocking=True)
+        for k in range(2):
+            with torch.cuda.stream(streams[k]):
+                if rnd == 0:
+                    ctr_ptrs.append(ops._mse_counter(dev).data_ptr())
+                for i in range(rnd * 50, rnd * 50 + 50):
+                    raw, z, rays, tgt, _, rgb_q = cases[(i + k) % len(cases)]
+                    o = ops.composite_forward_mse(raw, z, rays, None, False, tgt)
+                    got[k][i] = o[5][0]
+                    if i % 100 == 0:
+                        rgb_bad[k] += (o[0] != rgb_q).any().to(torch.int32)
+    torch.cuda.synchronize()
+    assert ctr_ptrs[0] != ctr_ptrs[1]                     # distinct counter blocks
+    for k in range(2):
+        want = torch.stack([cases[(i + k) % len(cases)][4][0] for i in range(N)])
+        bad = (got[k] != want).nonzero().flatten()
+        assert bad.numel() == 0, (k, bad[:10].tolist(), got[k][bad[:10]].tolist(), want[bad[:10]].tolist())
+        assert int(rgb_bad[k]) == 0
+        with torch.cuda.stream(streams[k]):
+            assert int(ops._mse_counter(dev).abs().sum()) == 0     # re-armed
+    del big
+
+
 def test_composite_loss_limits(dev):
     """Beyond cnerf_composite_mse_max_rays() rays per call the entry point refuses (render_loss then takes the reference's lines)."""
     from consistentnerf_amd import ops

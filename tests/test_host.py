@@ -367,6 +367,28 @@ def test_no_inline_asm_valu_next_to_mfma(tmp_path):
     assert pick("mlp_fwd_kILi8ELb1ELb1E")["sgpr_spill_count"] == 0 and pick("mlp_fwd_kILi8ELb1ELb1E")["vgpr_spill_count"] <= 8
 
 
+def test_ticket_is_taken_after_the_partial_store_completed(tmp_path):
+    """composite.hip's loss form: the per-workgroup partial (write-through store) must be complete before the workgroup's ticket
+    atomic (a workgroup-scope release fence compiles to nothing on gfx950).  scripts/isa_ticket_check.py reads it off
+    the device ISA; a synthetic positive control proves it can find the bad order."""
+    root = os.path.join(os.path.dirname(__file__), "..")
+    sys.path.insert(0, os.path.join(root, "scripts"))
+    import isa_ticket_check
+    bad = tmp_path / "bad.s"
+    bad.write_text("k:\n\tglobal_store_dwordx2 v0, v[2:3], s[6:7] sc1\n\ts_lshr_b32 s3, s2, 6\n"
+                   "\tglobal_atomic_add v2, v2, v3, s[62:63] sc0\n\ts_waitcnt vmcnt(0)\n.Lfunc_end0:\n")
+    found = isa_ticket_check.check(str(bad), need_sites=0)
+    assert len(found) == 1 and "possibly in flight" in found[0], found
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    r = subprocess.run(["bash", os.path.join(root, "scripts", "isa_stats.sh"), str(tmp_path)],
+                       env=dict(os.environ, FILES="composite"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    # one publish site per compiled sample-count variant of the loss form (C = 1, 2, 3, 4, 8, 16)
+    assert isa_ticket_check.check(str(tmp_path / "composite.s"), need_sites=6) == []
+
+
 def test_engine_query_probe_selects_the_plain_route_without_the_private_symbol(monkeypatch):
     """run_nerf's direct-accumulate route and merged coarse+fine backward depend on torch._C._will_engine_execute_node (private).
     The import-time probe must accept this torch's symbol, reject a missing one and one that answers differently, and with the
