@@ -34,6 +34,33 @@ struct MseBwd {
   float w;               // fp32(2 / n)
 };
 
+// ConsistentNeRF's masked losses (V:1645-1648, V:1737, V:1786-1788, V:1865) folded into the compositing of a level the same way —
+// without tickets: every workgroup leaves FIVE fp64 partials (squared colour error over the rays with m == 1 and with m == 0, squared
+// depth error (depth / far - prior / far)^2 over m == 1, and the two counts) in part[k * gridDim.x + blockIdx.x]; the step's loss
+// tail (loss.hip closs_tail_k, the next launch on the stream: it also evaluates the monocular patch term, which needs whole
+// depth maps) sums them in index order, normalises by the (possibly global) counts and leaves the three seed weights the backward
+// uses.  Backward: seed_rgb = (w_m (rgb - target)) * g_rgb, seed_depth = (w_d (depth / far - prior / far)) * g_depth (+ the patch
+// term's d_depth * g_patch on the patch rays) — the operations of masked_loss_k / patch_depth_loss_k and autograd's `d * g`.
+struct ClossFwd {
+  const float* tgt;      // [B,3]
+  const float* mask;     // [B] or nullptr (every ray in the m == 1 set)
+  const float* prior;    // [B] or nullptr (no depth term)
+  float far;
+  double* part;          // [5][gridDim.x]
+};
+struct ClossBwd {
+  const float* rgb;      // forward rgb_map [B,3]
+  const float* depth;    // forward depth_map [B] (with prior)
+  const float* tgt;
+  const float* mask;
+  const float* prior;
+  const float* stats;    // device [3]: w1, w0, wd (closs_tail_k)
+  const float* g;        // upstream gradient of the total loss (device scalar) or nullptr = 1
+  const float* patch_d;  // [n_patch] d patch_loss / d depth of this level, or nullptr
+  int64_t n_patch;
+  float far, rgb_w, depth_w, patch_w;
+};
+
 struct Sample {
   float e;      // exp(-relu(sigma)*dist)
   float alpha;  // 1 - e
@@ -111,7 +138,7 @@ __device__ __forceinline__ double composite_ray(const float* __restrict__ raw, i
                                                const float* __restrict__ rays, int rs, const float* __restrict__ noise, int64_t b,
                                                int S, int white, float* __restrict__ rgb, float* __restrict__ disp,
                                                float* __restrict__ acc, float* __restrict__ depth, float* __restrict__ weights,
-                                               const RayGenDev& cam, const float* __restrict__ tgt) {
+                                               const RayGenDev& cam, const float* __restrict__ tgt, float (&out4)[4]) {
   const int lane = threadIdx.x & 63;
   double err = 0.0;
   Sample sm[C];
@@ -144,6 +171,7 @@ __device__ __forceinline__ double composite_ray(const float* __restrict__ raw, i
     const float fa = (float)sa, fd = (float)sd;
     float r = (float)sr, g = (float)sg, bl = (float)sb;
     if (white) { const float bg = 1.f - fa; r += bg; g += bg; bl += bg; }   // R:305-306
+    out4[0] = r; out4[1] = g; out4[2] = bl; out4[3] = fd;
     if (rgb) { rgb[b * 3 + 0] = r; rgb[b * 3 + 1] = g; rgb[b * 3 + 2] = bl; }
     if (acc) acc[b] = fa;
     if (depth) depth[b] = fd;
@@ -168,15 +196,51 @@ __global__ __launch_bounds__(WV * 64) void composite_fwd_k(const float* __restri
                                                               int white, float* __restrict__ rgb,
                                                               float* __restrict__ disp, float* __restrict__ acc,
                                                               float* __restrict__ depth, float* __restrict__ weights,
-                                                              RayGenDev cam, MseFwd mse) {
+                                                              RayGenDev cam, MseFwd mse, ClossFwd cl) {
   const int lane = threadIdx.x & 63;
   const int64_t b = (int64_t)blockIdx.x * WV + (threadIdx.x >> 6);
+  float o4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (cl.tgt != nullptr) {
+    // masked-loss variant: per-ray terms in lane 0 (the arithmetic of masked_loss_k: e = d0^2 + d1^2 + d2^2 in fp32, sums in
+    // fp64), five partials per workgroup summed over its waves in wave order; no tickets (see ClossFwd)
+    __shared__ double sq[WV][5];
+    double t[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    if (b < B) {
+      composite_ray<C>(raw, ch, z, rays, rs, noise, b, S, white, rgb, disp, acc, depth, weights, cam, nullptr, o4);
+      if (lane == 0) {
+        const float m = cl.mask ? cl.mask[b] : 1.f;
+        float e = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float d = o4[c] - cl.tgt[b * 3 + c];
+          e += d * d;
+        }
+        if (m == 1.f) { t[0] = (double)e; t[3] = 1.0; }
+        if (m == 0.f) { t[1] = (double)e; t[4] = 1.0; }
+        if (cl.prior && m == 1.f) {
+          const float d = o4[3] / cl.far - cl.prior[b] / cl.far;
+          t[2] = (double)(d * d);
+        }
+      }
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 5; ++k) sq[threadIdx.x >> 6][k] = t[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) {
+      double s = 0.0;
+      for (int w = 0; w < WV; ++w) s += sq[w][threadIdx.x];
+      cl.part[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = s;
+    }
+    return;
+  }
   if (mse.tgt != nullptr) {
     // loss variant: every wave reaches the workgroup reduction below (a wave past the last ray contributes 0); after it only wave 0
     // stays for the tickets (the others retire: a workgroup that waits ~2 us for two memory round trips must not hold 16 wave slots)
     __shared__ double sq[WV];
     double e = 0.0;
-    if (b < B) e = composite_ray<C>(raw, ch, z, rays, rs, noise, b, S, white, rgb, disp, acc, depth, weights, cam, mse.tgt);
+    if (b < B) e = composite_ray<C>(raw, ch, z, rays, rs, noise, b, S, white, rgb, disp, acc, depth, weights, cam, mse.tgt, o4);
     if (lane == 0) sq[threadIdx.x >> 6] = e;
     __syncthreads();
     if (threadIdx.x >= 64) return;
@@ -240,7 +304,7 @@ __global__ __launch_bounds__(WV * 64) void composite_fwd_k(const float* __restri
     return;
   }
   if (b >= B) return;
-  composite_ray<C>(raw, ch, z, rays, rs, noise, b, S, white, rgb, disp, acc, depth, weights, cam, nullptr);
+  composite_ray<C>(raw, ch, z, rays, rs, noise, b, S, white, rgb, disp, acc, depth, weights, cam, nullptr, o4);
 }
 
 template <int C>
@@ -252,7 +316,7 @@ __global__ __launch_bounds__(WAVES * 64) void composite_bwd_k(const float* __res
                                                               const float* __restrict__ g_disp,
                                                               const float* __restrict__ g_acc,
                                                               const float* __restrict__ g_depth,
-                                                              float* __restrict__ d_raw, MseBwd mse) {
+                                                              float* __restrict__ d_raw, MseBwd mse, ClossBwd cl) {
   const int lane = threadIdx.x & 63;
   const int64_t b = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
   if (b >= B) return;
@@ -270,6 +334,20 @@ __global__ __launch_bounds__(WAVES * 64) void composite_bwd_k(const float* __res
     gb += (mse.w * (mse.rgb[b * 3 + 2] - mse.tgt[b * 3 + 2])) * g0;
   }
   if (g_depth) gd = g_depth[b];
+  if (cl.rgb) {    // the masked rgb / depth seeds (+ the patch term's) of this level, formed here (see ClossBwd)
+    const float g0 = cl.g ? cl.g[0] : 1.f;
+    const float m = cl.mask ? cl.mask[b] : 1.f;
+    const float w = m == 1.f ? cl.stats[0] : (m == 0.f ? cl.stats[1] : 0.f);
+    const float g_rgb_l = cl.rgb_w * g0;
+    gr += (w * (cl.rgb[b * 3 + 0] - cl.tgt[b * 3 + 0])) * g_rgb_l;
+    gg += (w * (cl.rgb[b * 3 + 1] - cl.tgt[b * 3 + 1])) * g_rgb_l;
+    gb += (w * (cl.rgb[b * 3 + 2] - cl.tgt[b * 3 + 2])) * g_rgb_l;
+    if (cl.prior) {
+      const float dd = m == 1.f ? cl.stats[2] * (cl.depth[b] / cl.far - cl.prior[b] / cl.far) : 0.f;
+      gd += dd * (cl.depth_w * g0);
+    }
+    if (cl.patch_d && b < cl.n_patch) gd += cl.patch_d[b] * (cl.patch_w * g0);
+  }
   if (g_acc) ga = g_acc[b];
   if (white) ga -= (gr + gg + gb);
   if (g_disp) {
@@ -348,7 +426,7 @@ extern "C" int cnerf_composite_fwd(const float* raw, int raw_ch, const float* z,
     constexpr int C = decltype(c)::value;
     hipLaunchKernelGGL((composite_fwd_k<C, WAVES>), dim3((unsigned)cn_div_up(B, WAVES)), dim3(WAVES * 64), 0,
                        cn_stream(stream), raw, raw_ch, z, rays, ray_stride, noise, B, S, white_bkgd, rgb, disp, acc,
-                       depth, weights, cn_no_raygen(), MseFwd{});
+                       depth, weights, cn_no_raygen(), MseFwd{}, ClossFwd{});
     CN_CHECK_LAUNCH();
     return CNERF_OK;
   });
@@ -363,7 +441,7 @@ int cn_composite_fwd_cam(const float* raw, int raw_ch, const float* z, const Ray
   return dispatch_c(S, [&](auto c) -> int {
     constexpr int C = decltype(c)::value;
     hipLaunchKernelGGL((composite_fwd_k<C, WAVES>), dim3((unsigned)cn_div_up(B, WAVES)), dim3(WAVES * 64), 0, st, raw, raw_ch, z,
-                       (const float*)nullptr, 0, noise, B, S, white_bkgd, rgb, disp, acc, depth, weights, cam, MseFwd{});
+                       (const float*)nullptr, 0, noise, B, S, white_bkgd, rgb, disp, acc, depth, weights, cam, MseFwd{}, ClossFwd{});
     CN_CHECK_LAUNCH();
     return CNERF_OK;
   });
@@ -379,7 +457,7 @@ extern "C" int cnerf_composite_bwd(const float* raw, int raw_ch, const float* z,
     constexpr int C = decltype(c)::value;
     hipLaunchKernelGGL((composite_bwd_k<C>), dim3((unsigned)cn_div_up(B, WAVES)), dim3(WAVES * 64), 0,
                        cn_stream(stream), raw, raw_ch, z, rays, ray_stride, noise, B, S, white_bkgd, g_rgb, g_disp,
-                       g_acc, g_depth, d_raw, MseBwd{});
+                       g_acc, g_depth, d_raw, MseBwd{}, ClossBwd{});
     CN_CHECK_LAUNCH();
     return CNERF_OK;
   });
@@ -405,7 +483,7 @@ extern "C" int cnerf_composite_fwd_mse(const float* raw, int raw_ch, const float
     constexpr int C = decltype(c)::value;
     hipLaunchKernelGGL((composite_fwd_k<C, MSE_WAVES>), dim3((unsigned)cn_div_up(B, MSE_WAVES)), dim3(MSE_WAVES * 64), 0,
                        cn_stream(stream), raw, raw_ch, z, rays, ray_stride, noise, B, S, white_bkgd, rgb, disp, acc, depth, weights,
-                       cn_no_raygen(), m);
+                       cn_no_raygen(), m, ClossFwd{});
     CN_CHECK_LAUNCH();
     return CNERF_OK;
   });
@@ -421,7 +499,49 @@ extern "C" int cnerf_composite_bwd_mse(const float* raw, int raw_ch, const float
     constexpr int C = decltype(c)::value;
     hipLaunchKernelGGL((composite_bwd_k<C>), dim3((unsigned)cn_div_up(B, WAVES)), dim3(WAVES * 64), 0, cn_stream(stream), raw, raw_ch,
                        z, rays, ray_stride, noise, B, S, white_bkgd, (const float*)nullptr, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, d_raw, m);
+                       (const float*)nullptr, (const float*)nullptr, d_raw, m, ClossBwd{});
+    CN_CHECK_LAUNCH();
+    return CNERF_OK;
+  });
+}
+
+// ---- compositing with ConsistentNeRF's masked rgb / depth losses folded in (V:1645-1865): see ClossFwd / ClossBwd above ----------
+extern "C" int64_t cnerf_closs_ws_floats(int64_t B) { return B <= 0 ? 0 : 10 * cn_div_up(B, MSE_WAVES); }
+
+extern "C" int cnerf_composite_fwd_closs(const float* raw, int raw_ch, const float* z, const float* rays, int ray_stride,
+                                         const float* noise, int64_t B, int S, int white_bkgd, const cnerf_closs* L, float* rgb,
+                                         float* disp, float* acc, float* depth, float* weights, float* workspace, void* stream) {
+  if (!raw || !z || !rays || !L || !L->target || !rgb || !workspace || B <= 0 || S <= 0 || raw_ch < 4 || ray_stride < 6 ||
+      ((uintptr_t)workspace & 7) != 0 || (L->prior && (!depth || !(L->far > 0.f))))
+    return CNERF_E_ARG;
+  ClossFwd c;
+  c.tgt = L->target; c.mask = L->mask; c.prior = L->prior; c.far = L->far; c.part = reinterpret_cast<double*>(workspace);
+  return dispatch_c(S, [&](auto cc) -> int {
+    constexpr int C = decltype(cc)::value;
+    hipLaunchKernelGGL((composite_fwd_k<C, MSE_WAVES>), dim3((unsigned)cn_div_up(B, MSE_WAVES)), dim3(MSE_WAVES * 64), 0,
+                       cn_stream(stream), raw, raw_ch, z, rays, ray_stride, noise, B, S, white_bkgd, rgb, disp, acc, depth, weights,
+                       cn_no_raygen(), MseFwd{}, c);
+    CN_CHECK_LAUNCH();
+    return CNERF_OK;
+  });
+}
+
+extern "C" int cnerf_composite_bwd_closs(const float* raw, int raw_ch, const float* z, const float* rays, int ray_stride,
+                                         const float* noise, int64_t B, int S, int white_bkgd, const cnerf_closs* L, const float* rgb,
+                                         const float* depth, const float* stats, const float* g_loss, float rgb_w, float depth_w,
+                                         float patch_w, const float* patch_d, int64_t n_patch_rays, float* d_raw, void* stream) {
+  if (!raw || !z || !rays || !L || !L->target || !rgb || !stats || !d_raw || B <= 0 || S <= 0 || raw_ch < 4 || ray_stride < 6 ||
+      (L->prior && (!depth || !(L->far > 0.f))) || n_patch_rays < 0 || n_patch_rays > B)
+    return CNERF_E_ARG;
+  ClossBwd c;
+  c.rgb = rgb; c.depth = depth; c.tgt = L->target; c.mask = L->mask; c.prior = L->prior; c.stats = stats; c.g = g_loss;
+  c.patch_d = n_patch_rays > 0 ? patch_d : nullptr; c.n_patch = n_patch_rays; c.far = L->far; c.rgb_w = rgb_w; c.depth_w = depth_w;
+  c.patch_w = patch_w;
+  return dispatch_c(S, [&](auto cc) -> int {
+    constexpr int C = decltype(cc)::value;
+    hipLaunchKernelGGL((composite_bwd_k<C>), dim3((unsigned)cn_div_up(B, WAVES)), dim3(WAVES * 64), 0, cn_stream(stream), raw, raw_ch,
+                       z, rays, ray_stride, noise, B, S, white_bkgd, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, d_raw, MseBwd{}, c);
     CN_CHECK_LAUNCH();
     return CNERF_OK;
   });

@@ -94,12 +94,10 @@ __device__ __forceinline__ float nan_to_num(float v) {
   return v;
 }
 
-__global__ void patch_depth_loss_k(const float* __restrict__ depth, const float* __restrict__ mono, int P, int n,
-                                   float g_scale, float* __restrict__ loss, float* __restrict__ d_depth) {
-  __shared__ float part[16];
-  const int p = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const float* d = depth + (int64_t)p * n;
-  const float* g = mono + (int64_t)p * n;
+// one patch by one wave64: returns (all lanes) the patch's share of the loss, (float)(mean residual^2) / P / 2; writes d_depth[n]
+// (the gradient of that share times g_scale) when asked
+__device__ __forceinline__ float patch_wave(const float* __restrict__ d, const float* __restrict__ g, int P, int n, float g_scale,
+                                            float* __restrict__ d_depth, int lane) {
   auto inv = [&](int i) { const float x = d[i] <= 0.f ? 1e-4f : d[i]; return 1.f / x; };
   // pass 1: ranges
   float gmin = 1e5f, gmax = -INFINITY, pmin = 1e5f, pmax = -INFINITY;
@@ -126,14 +124,8 @@ __global__ void patch_depth_loss_k(const float* __restrict__ depth, const float*
     se2 += (double)(e * e); se += (double)e;
   }
   se2 = wave_sum(se2); se = wave_sum(se);
-  if (lane == 0) part[p] = (float)(se2 / n) / P / 2;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float l = 0.f;
-    for (int k = 0; k < P; ++k) l += part[k];
-    loss[0] = l;
-  }
-  if (!d_depth) return;
+  const float share = (float)(se2 / n) / P / 2;
+  if (!d_depth) return share;
   // pass 4: gradient sums.  dL/dprn_i = (mean(e) - e_i) / (n P)
   const float ebar = (float)(se / n), w = g_scale / ((float)n * (float)P);
   double s_mg = 0.0, s_gq = 0.0;
@@ -160,8 +152,90 @@ __global__ void patch_depth_loss_k(const float* __restrict__ depth, const float*
     if (m * pr == pmax) dpr += m * d_pmax / (float)cmax;
     const float dc = (c == c && fabsf(c) != INFINITY) ? dpr : 0.f;     // nan_to_num backward
     const float dx = -dc * c * c;                                      // reciprocal backward
-    d_depth[(int64_t)p * n + i] = d[i] <= 0.f ? 0.f : dx;
+    d_depth[i] = d[i] <= 0.f ? 0.f : dx;
   }
+  return share;
+}
+
+__global__ void patch_depth_loss_k(const float* __restrict__ depth, const float* __restrict__ mono, int P, int n,
+                                   float g_scale, float* __restrict__ loss, float* __restrict__ d_depth) {
+  __shared__ float part[16];
+  const int p = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const float share = patch_wave(depth + (int64_t)p * n, mono + (int64_t)p * n, P, n, g_scale,
+                                 d_depth ? d_depth + (int64_t)p * n : nullptr, lane);
+  if (lane == 0) part[p] = share;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float l = 0.f;
+    for (int k = 0; k < P; ++k) l += part[k];
+    loss[0] = l;
+  }
+}
+
+// ---- the loss tail of a ConsistentNeRF step whose masked losses rode in the compositing launches (composite.hip ClossFwd) -------
+// ONE workgroup: sums each level's five per-workgroup fp64 partials in index order (thread t takes entries t, t + T, ...; then the
+// fixed-order block sum — the value does not depend on the grid's scheduling), normalises with the local or the caller's (global,
+// sharded batch) counts exactly as masked_loss_k does, evaluates the monocular patch term of both levels (one wave per patch: waves
+// [0, P) the last level, [P, 2P) the coarse one), assembles the step's loss in the reference's order of accumulation (V:1672-1865:
+// loss += w_rgb img_loss; loss += w_patch mono_mse; loss += w_depth depth_loss; then the same three of the coarse level) and leaves
+// the per-level seed weights (w1, w0, wd) for cnerf_composite_bwd_closs.
+struct ClossTail {
+  const double* part[2];     // [5][nparts] per level; level 0 = the last (fine) level, level 1 = coarse or nullptr
+  int nparts;
+  const float* counts;       // (n1, n0) or nullptr
+  float coef, far, rgb_w, depth_w, patch_w;
+  int has_depth;
+  const float* depth[2];     // depth maps of the levels (patch term), or nullptr
+  const float* mono;
+  int P, n;
+  float* patch_d[2];         // [P * n] per level or nullptr
+  float* terms;              // [8]: loss, img_loss, depth_loss, patch_loss, img_loss0, depth_loss0, patch_loss0, -
+  float* stats;              // [2][4]: w1, w0, wd, - per level
+};
+
+__global__ __launch_bounds__(T) void closs_tail_k(ClossTail a) {
+  __shared__ double sh[T / 64];
+  __shared__ float pshare[2][8];
+  __shared__ double tot[2][5];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int levels = a.part[1] ? 2 : 1;
+  for (int lv = 0; lv < levels; ++lv)
+    for (int k = 0; k < 5; ++k) {
+      double s = 0.0;
+      for (int i = threadIdx.x; i < a.nparts; i += T) s += a.part[lv][(int64_t)k * a.nparts + i];
+      s = block_sum(s, sh);
+      if (threadIdx.x == 0) tot[lv][k] = s;
+    }
+  if (a.P > 0 && wv < levels * a.P) {
+    const int lv = wv / a.P, p = wv - lv * a.P;
+    const float share = patch_wave(a.depth[lv] + (int64_t)p * a.n, a.mono + (int64_t)p * a.n, a.P, a.n, 1.f,
+                                   a.patch_d[lv] ? a.patch_d[lv] + (int64_t)p * a.n : nullptr, lane);
+    if (lane == 0) pshare[lv][p] = share;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  float loss = 0.f;
+  for (int lv = 0; lv < levels; ++lv) {
+    const double s1 = tot[lv][0], s0 = tot[lv][1], sd = tot[lv][2];
+    const double N1 = a.counts ? (double)a.counts[0] : tot[lv][3];
+    const double N0 = a.counts ? (double)a.counts[1] : tot[lv][4];
+    float il = (float)(s1 / (3.0 * N1));
+    if (N0 > 0) il += a.coef * (float)(s0 / (3.0 * N0));
+    const float dl = a.has_depth ? (float)(sd / N1) : 0.f;
+    float pl = 0.f;
+    for (int k = 0; k < a.P; ++k) pl += pshare[lv][k];
+    loss += a.rgb_w * il;
+    if (a.P > 0) loss += a.patch_w * pl;
+    if (a.has_depth) loss = loss + a.depth_w * dl;
+    a.terms[1 + 3 * lv] = il; a.terms[2 + 3 * lv] = dl; a.terms[3 + 3 * lv] = pl;
+    a.stats[4 * lv + 0] = (float)(2.0 / (3.0 * N1));
+    a.stats[4 * lv + 1] = N0 > 0 ? a.coef * (float)(2.0 / (3.0 * N0)) : 0.f;
+    a.stats[4 * lv + 2] = (float)(2.0 / N1) / a.far;
+    a.stats[4 * lv + 3] = 0.f;
+  }
+  if (levels == 1) { a.terms[4] = a.terms[5] = a.terms[6] = 0.f; }
+  a.terms[0] = loss;
+  a.terms[7] = 0.f;
 }
 
 }  // namespace
@@ -234,14 +308,92 @@ extern "C" int cnerf_mse_ws(const float* x, const float* y, int64_t n, float* lo
   return CNERF_OK;
 }
 
-extern "C" int64_t cnerf_loss_ws_floats(void) { return 0; }
+// Large batches (whole images through the masked losses: evaluation, or a caller that does not shard): stage 1 — one workgroup per
+// ML_CHUNK rays leaves its five fp64 partials; stage 2 — the same grid: every workgroup sums ALL partials in index order (a few
+// hundred doubles: cheaper than a third launch), workgroup 0 writes the loss, each writes the gradient seeds of its own chunk.
+// Fixed order at both stages: the value does not depend on scheduling.
+namespace {
+constexpr int64_t ML_CHUNK = 16384;
+constexpr int64_t ML_MAX_PARTS = 1024;
+__global__ __launch_bounds__(T) void masked_part_k(const float* __restrict__ rgb, const float* __restrict__ tgt,
+                                                   const float* __restrict__ depth, const float* __restrict__ prior,
+                                                   const float* __restrict__ mask, int64_t B, float far, double* __restrict__ part) {
+  __shared__ double sh[T / 64];
+  const int64_t lo = (int64_t)blockIdx.x * ML_CHUNK, hi = lo + ML_CHUNK < B ? lo + ML_CHUNK : B;
+  double n1 = 0, n0 = 0, s1 = 0, s0 = 0, sd = 0;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += T) {
+    const float m = mask ? mask[i] : 1.f;
+    const bool in1 = m == 1.f, in0 = m == 0.f;
+    float e = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float d = rgb[3 * i + c] - tgt[3 * i + c];
+      e += d * d;
+    }
+    if (in1) { n1 += 1.0; s1 += (double)e; }
+    if (in0) { n0 += 1.0; s0 += (double)e; }
+    if (depth && in1) {
+      const float d = depth[i] / far - prior[i] / far;
+      sd += (double)(d * d);
+    }
+  }
+  n1 = block_sum(n1, sh); n0 = block_sum(n0, sh);
+  s1 = block_sum(s1, sh); s0 = block_sum(s0, sh); sd = block_sum(sd, sh);
+  if (threadIdx.x == 0) {
+    double* o = part + 5 * (int64_t)blockIdx.x;
+    o[0] = s1; o[1] = s0; o[2] = sd; o[3] = n1; o[4] = n0;
+  }
+}
+__global__ __launch_bounds__(T) void masked_fin_k(const float* __restrict__ rgb, const float* __restrict__ tgt,
+                                                  const float* __restrict__ depth, const float* __restrict__ prior,
+                                                  const float* __restrict__ mask, int64_t B, float far, float coef,
+                                                  const float* __restrict__ counts, float g_scale, const double* __restrict__ part,
+                                                  float* __restrict__ loss, float* __restrict__ d_rgb, float* __restrict__ d_depth) {
+  double t[5] = {0, 0, 0, 0, 0};
+  for (unsigned p = 0; p < gridDim.x; ++p)
+    for (int k = 0; k < 5; ++k) t[k] += part[5 * (int64_t)p + k];
+  const double N1 = counts ? (double)counts[0] : t[3];
+  const double N0 = counts ? (double)counts[1] : t[4];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    float l = (float)(t[0] / (3.0 * N1));
+    if (N0 > 0) l += coef * (float)(t[1] / (3.0 * N0));
+    loss[0] = l;
+    loss[1] = depth ? (float)(t[2] / N1) : 0.f;
+  }
+  const float w1 = g_scale * (float)(2.0 / (3.0 * N1));
+  const float w0 = N0 > 0 ? g_scale * coef * (float)(2.0 / (3.0 * N0)) : 0.f;
+  const float wd = g_scale * (float)(2.0 / N1) / far;
+  const int64_t lo = (int64_t)blockIdx.x * ML_CHUNK, hi = lo + ML_CHUNK < B ? lo + ML_CHUNK : B;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += T) {
+    const float m = mask ? mask[i] : 1.f;
+    const float w = m == 1.f ? w1 : (m == 0.f ? w0 : 0.f);
+    if (d_rgb) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) d_rgb[3 * i + c] = w * (rgb[3 * i + c] - tgt[3 * i + c]);
+    }
+    if (d_depth) d_depth[i] = (depth && m == 1.f) ? wd * (depth[i] / far - prior[i] / far) : 0.f;
+  }
+}
+}  // namespace
+
+extern "C" int64_t cnerf_loss_ws_floats(void) { return 2 * 5 * ML_MAX_PARTS; }
 
 extern "C" int cnerf_masked_loss(const float* rgb, const float* target, const float* depth, const float* prior,
                                  const float* mask, int64_t B, float far, float coef, const float* counts,
                                  float g_scale, float* loss, float* d_rgb, float* d_depth, float* workspace,
                                  void* stream) {
-  (void)workspace;
-  if (!rgb || !target || !loss || B <= 0 || (depth && !prior) || !(far > 0.f)) return CNERF_E_ARG;
+  if (!rgb || !target || !loss || B <= 0 || (depth && !prior) || !(far > 0.f) || ((uintptr_t)workspace & 7) != 0) return CNERF_E_ARG;
+  const int64_t nparts = (B + ML_CHUNK - 1) / ML_CHUNK;
+  if (workspace && nparts > 1 && nparts <= ML_MAX_PARTS) {
+    double* part = reinterpret_cast<double*>(workspace);
+    hipLaunchKernelGGL(masked_part_k, dim3((unsigned)nparts), dim3(T), 0, cn_stream(stream), rgb, target, depth, prior, mask, B, far,
+                       part);
+    CN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(masked_fin_k, dim3((unsigned)nparts), dim3(T), 0, cn_stream(stream), rgb, target, depth, prior, mask, B, far,
+                       coef, counts, g_scale, part, loss, d_rgb, d_depth);
+    CN_CHECK_LAUNCH();
+    return CNERF_OK;
+  }
   hipLaunchKernelGGL(masked_loss_k, dim3(1), dim3(T), 0, cn_stream(stream), rgb, target, depth, prior, mask, B, far,
                      coef, counts, g_scale, loss, d_rgb, d_depth);
   CN_CHECK_LAUNCH();
@@ -253,6 +405,26 @@ extern "C" int cnerf_patch_depth_loss(const float* depth_pred, const float* mono
   if (!depth_pred || !mono || !loss || P <= 0 || P > 16 || n <= 0) return CNERF_E_ARG;
   hipLaunchKernelGGL(patch_depth_loss_k, dim3(1), dim3(64 * P), 0, cn_stream(stream), depth_pred, mono, P, n, g_scale,
                      loss, d_depth);
+  CN_CHECK_LAUNCH();
+  return CNERF_OK;
+}
+
+extern "C" int cnerf_closs_tail(const cnerf_closs_tail* t, float* terms, float* stats, float* patch_d, void* stream) {
+  if (!t || !terms || !stats || !t->ws_last || t->B <= 0 || t->P < 0 || t->P > 8 || (t->P > 0 && (t->n <= 0 || !t->mono || !t->depth_last)) ||
+      (t->P > 0 && t->ws_coarse && !t->depth_coarse) || (t->has_depth && !(t->far > 0.f)) || (int64_t)t->P * t->n > t->B ||
+      ((uintptr_t)t->ws_last & 7) != 0 || ((uintptr_t)t->ws_coarse & 7) != 0)
+    return CNERF_E_ARG;
+  ClossTail a;
+  a.part[0] = reinterpret_cast<const double*>(t->ws_last);
+  a.part[1] = reinterpret_cast<const double*>(t->ws_coarse);
+  a.nparts = (int)((t->B + 7) / 8);       // composite.hip MSE_WAVES rays per workgroup
+  a.counts = t->counts; a.coef = t->coef; a.far = t->has_depth ? t->far : 1.f; a.rgb_w = t->rgb_w; a.depth_w = t->depth_w;
+  a.patch_w = t->patch_w; a.has_depth = t->has_depth;
+  a.depth[0] = t->depth_last; a.depth[1] = t->depth_coarse; a.mono = t->mono; a.P = t->P; a.n = t->n;
+  a.patch_d[0] = (patch_d && t->P > 0) ? patch_d : nullptr;
+  a.patch_d[1] = (patch_d && t->P > 0 && t->ws_coarse) ? patch_d + (int64_t)t->P * t->n : nullptr;
+  a.terms = terms; a.stats = stats;
+  hipLaunchKernelGGL(closs_tail_k, dim3(1), dim3(T), 0, cn_stream(stream), a);
   CN_CHECK_LAUNCH();
   return CNERF_OK;
 }

@@ -38,16 +38,23 @@ __device__ __forceinline__ void cn_finish_ray(float ox, float oy, float oz, floa
   o[0] = ox; o[1] = oy; o[2] = oz; d[0] = dx; d[1] = dy; d[2] = dz;
 }
 
+// pre-NDC direction of pixel (row j, column i) of the camera (H:167-170).  Works on any address space of `g`.
+template <class G>
+__device__ __forceinline__ void cn_raw_dir(const G& g, int j, int i, float& dx, float& dy, float& dz) {
+  const float d0 = ((float)i - g.cx) / g.fx, d1 = -((float)j - g.cy) / g.fy, d2 = -1.f;   // H:167
+  // rays_d = sum(dirs[..., None, :] * c2w[:3,:3], -1)  (H:170): three products, then a 3-term sum
+  dx = d0 * g.r[0] + d1 * g.r[1] + d2 * g.r[2];
+  dy = d0 * g.r[3] + d1 * g.r[4] + d2 * g.r[5];
+  dz = d0 * g.r[6] + d1 * g.r[7] + d2 * g.r[8];
+}
+
 // ray `idx` (row-major pixel) of the camera.  Works on any address space of `g` (kernarg segment included).
 template <class G>
 __device__ __forceinline__ void cn_gen_ray(const G& g, int64_t idx, float (&o)[3], float (&d)[3], float (&v)[3]) {
   const int W = g.W;
   const int j = (int)(idx / W), i = (int)(idx - (int64_t)j * W);
-  const float d0 = ((float)i - g.cx) / g.fx, d1 = -((float)j - g.cy) / g.fy, d2 = -1.f;   // H:167
-  // rays_d = sum(dirs[..., None, :] * c2w[:3,:3], -1)  (H:170): three products, then a 3-term sum
-  const float dx = d0 * g.r[0] + d1 * g.r[1] + d2 * g.r[2];
-  const float dy = d0 * g.r[3] + d1 * g.r[4] + d2 * g.r[5];
-  const float dz = d0 * g.r[6] + d1 * g.r[7] + d2 * g.r[8];
+  float dx, dy, dz;
+  cn_raw_dir(g, j, i, dx, dy, dz);
   cn_finish_ray(g.t[0], g.t[1], g.t[2], dx, dy, dz, g.vd, g.ndc, g.ax, g.ay, o, d, v);
 }
 

@@ -21,7 +21,9 @@
 extern "C" {
 #endif
 
-#define CNERF_ABI_VERSION 3   /* 3: + in-kernel uniform streams (cnerf_rng, *_rng) and compositing with img2mse folded in (*_mse);
+#define CNERF_ABI_VERSION 4   /* 4: + cnerf_sample_pixels (one-launch training batch of an image), the ConsistentNeRF losses folded into
+                                * compositing (cnerf_closs, *_closs, cnerf_closs_tail); cnerf_masked_loss uses its workspace for
+                                * batches > 16384 rays; every v3 entry point unchanged.   3: + in-kernel uniform streams (cnerf_rng, *_rng) and compositing with img2mse folded in (*_mse);
                                 * every v2 entry point unchanged.   2: cnerf_adam_step takes its hyper-parameters as double; the *_pair, *_cam, *_bf entry points */
 
 #define CNERF_OK 0
@@ -210,6 +212,53 @@ int cnerf_composite_bwd_mse(const float* raw, int raw_ch, const float* z, const 
                             const float* noise, int64_t B, int S, int white_bkgd, const float* rgb, const float* target,
                             const float* g_loss, float* d_raw, void* stream);
 
+/* a7 with ConsistentNeRF's masked losses folded in (run_nerf_view.py:1645-1648 img_loss, :1737 depth_loss, :1786-1788 / :1865 the
+ * coarse level's, :1678-1726 the monocular patch term): what `run_nerf_view.render_loss` launches per step instead of 2 x
+ * cnerf_masked_loss + 2 x cnerf_patch_depth_loss + the ATen glue between them.
+ *   forward, per level:  cnerf_composite_fwd_closs = cnerf_composite_fwd + five fp64 partial sums per workgroup of 8 rays in
+ *       `workspace` (cnerf_closs_ws_floats(B) floats, 8-byte aligned): squared colour error over mask == 1 and over mask == 0,
+ *       squared (depth - prior) / far over mask == 1, the two counts.  mask NULL = every ray in the first set; prior NULL = no depth
+ *       term.  No tickets, no atomics.
+ *   cnerf_closs_tail (ONE workgroup, after the last level's forward): sums the partials of both levels in index order, forms
+ *       img_loss = s1 / (3 n1) + coef s0 / (3 n0) [second term iff n0 > 0] and depth_loss = sd / n1 with the local counts or the
+ *       caller's GLOBAL `counts[2]` (a batch sharded over ranks), evaluates the patch term of both levels (cnerf_patch_depth_loss's
+ *       arithmetic; P <= 8 patches of n rays = the first P n rays of the batch) and accumulates in the reference's order:
+ *       loss = rgb_w img_loss + patch_w patch + depth_w depth_loss (+ the same three of the coarse level).
+ *       terms[8] = loss, img_loss, depth_loss, patch_loss, img_loss0, depth_loss0, patch_loss0, 0;  stats[8] = per level
+ *       (2 / (3 n1), coef 2 / (3 n0), (2 / n1) / far, 0): the seed weights;  patch_d[levels][P n] = d patch_loss / d depth (NULL: not
+ *       wanted).
+ *   backward, per level:  cnerf_composite_bwd_closs = cnerf_composite_bwd with the seeds formed in registers:
+ *       g_rgb = (w_m (rgb - target)) (rgb_w g), g_depth = (w_d (depth / far - prior / far)) (depth_w g) [mask == 1] + patch_d (patch_w g)
+ *       [first n_patch_rays rays], g = g_loss[0] (NULL = 1) — the operations of cnerf_masked_loss / cnerf_patch_depth_loss followed by
+ *       autograd's `d * g`: bit-identical d_raw.  `stats` = the level's 4 floats of cnerf_closs_tail. */
+typedef struct cnerf_closs {
+  const float* target;   /* [B,3] */
+  const float* mask;     /* [B] floats 0 / 1, or NULL */
+  const float* prior;    /* [B] depth prior, or NULL (no depth term) */
+  float far;             /* depth terms compare depth / far (V:1737) */
+} cnerf_closs;
+typedef struct cnerf_closs_tail {
+  const float* ws_last;      /* workspace of the last (fine) level's forward */
+  const float* ws_coarse;    /* the coarse level's, or NULL (one level) */
+  int64_t B;
+  const float* counts;       /* device (n1, n0) or NULL */
+  float coef, far, rgb_w, depth_w, patch_w;
+  int32_t has_depth;
+  const float* depth_last;   /* depth maps (patch term; NULL with P == 0) */
+  const float* depth_coarse;
+  const float* mono;         /* [P n] monocular prior at the patch rays */
+  int32_t P, n;
+} cnerf_closs_tail;
+int64_t cnerf_closs_ws_floats(int64_t B);
+int cnerf_composite_fwd_closs(const float* raw, int raw_ch, const float* z, const float* rays, int ray_stride, const float* noise,
+                              int64_t B, int S, int white_bkgd, const cnerf_closs* L, float* rgb, float* disp, float* acc,
+                              float* depth, float* weights, float* workspace, void* stream);
+int cnerf_closs_tail(const cnerf_closs_tail* t, float* terms, float* stats, float* patch_d, void* stream);
+int cnerf_composite_bwd_closs(const float* raw, int raw_ch, const float* z, const float* rays, int ray_stride, const float* noise,
+                              int64_t B, int S, int white_bkgd, const cnerf_closs* L, const float* rgb, const float* depth,
+                              const float* stats, const float* g_loss, float rgb_w, float depth_w, float patch_w,
+                              const float* patch_d, int64_t n_patch_rays, float* d_raw, void* stream);
+
 /* ---- a8: inverse-CDF sampling  (sample_pdf H:206-250) ------------------------------------------ */
 /* bins[B,Nb], weights[B,Nb-1], u[B,Nf] (u_row_stride 0 broadcasts one row) -> samples[B,Nf];
  * inds[B,Nf] int64 (searchsorted right=True result, the bit-exact parity target) optional.
@@ -305,6 +354,33 @@ int cnerf_gen_rays(int H, int W, float fx, float fy, float cx, float cy, const f
 int cnerf_pack_rays(const float* rays_o, const float* rays_d, int64_t B, float near, float far,
                     int use_viewdirs, int ndc, float ndc_ax, float ndc_ay, float* rays, void* stream);
 
+/* ---- f-2: the training batch of ONE image in one launch  (run_nerf_view.py:1452-1517, run_nerf.py:730-757) --------------- */
+/* Rows [0, n_patches ps^2): the pixels of the patches (corner patch_start[q] = (row, col); inside a patch the ROW index runs
+ * fastest, V:1490-1494); rows after them: n_rand DISTINCT pixels of the grid [crop_r0, crop_r0 + crop_h) x [crop_c0, crop_c0 +
+ * crop_w) (the whole image, or the centre crop of R:741-753) — `select_inds[n_rand]` (device int64 indices into the row-major
+ * grid: the caller's own `np.random.choice(..., replace=False)`, V:1503; values must be < crop_h crop_w) or, when NULL, pi(0..n_rand-1)
+ * for a pseudo-random permutation pi of the grid keyed by `rng` (8-round alternating Feistel network over Philox4x32-10, cycle-walked;
+ * oracle/philox.py::permutation).  Per row b, any output may be NULL: rays[B, 8|11] exactly as cnerf_gen_rays writes that pixel's ray,
+ * rays_od[2, B, 3] = the raw (rays_o, rays_d) of get_rays (H:164-173; the reference's `batch_rays`), target[B, 3] = the first three
+ * channels of image[H, W, image_ch], extras_out[n_extras, B] = extras[e][H, W] at the pixel (extras: HOST array of n_extras <= 4
+ * device pointers), coords[B, 2] = (row, col). */
+typedef struct cnerf_pixel_batch {
+  int32_t H, W;
+  float fx, fy, cx, cy;
+  float c2w[12];
+  float near, far;
+  int32_t use_viewdirs, ndc;
+  float ndc_ax, ndc_ay;
+  int32_t crop_r0, crop_c0, crop_h, crop_w;
+  int32_t n_patches, patch_size;
+  int32_t patch_start[16][2];
+  int64_t n_rand;
+  int32_t image_ch, n_extras;
+} cnerf_pixel_batch;
+int cnerf_sample_pixels(const cnerf_pixel_batch* cfg, const int64_t* select_inds, const cnerf_rng* rng, const float* image,
+                        const float* const* extras, float* rays, float* rays_od, float* target, float* extras_out,
+                        int64_t* coords, void* stream);
+
 /* ---- a12/a13: cross-view depth warp and hard masks  (get_ref_rays V:576-627, get_test_label
  *      V:630-669, mask precompute V:994-1046) ---------------------------------------------------- */
 /* World points P[N,3] into the reference camera w2c[3,4] (HOST, 12 floats) with K (fx,fy,cx,cy):
@@ -335,7 +411,8 @@ int cnerf_mse_ws(const float* x, const float* y, int64_t n, float* loss, float* 
  * loss[1] = mean_{m==1}((depth-prior)/far)^2 (0 if depth==NULL).  Gradients d_rgb[B,3], d_depth[B]
  * (scaled by g_scale) are written if non-NULL.  mask==NULL = plain MSE over all rays (R:769).
  * counts[2] (n1, n0) may be supplied (e.g. all-reduced across ranks) or NULL to count locally.
- * Uses `workspace` of cnerf_loss_ws_floats() floats. */
+ * `workspace` of cnerf_loss_ws_floats() floats (8-byte aligned) or NULL: with it, batches of more than 16384 rays (up to 16.7 M)
+ * run as one workgroup per 16384 rays + a fixed-order second stage; otherwise one workgroup. */
 int64_t cnerf_loss_ws_floats(void);
 int cnerf_masked_loss(const float* rgb, const float* target, const float* depth, const float* prior,
                       const float* mask, int64_t B, float far, float coef, const float* counts,
