@@ -510,14 +510,11 @@ def launches_per_step(dispatches):
             "source": "ordered dispatch list of the rocprofv3 pass of THIS command; one step = the dispatches between two adam_k"}
 
 
-def c3_leg(dev, steps=20):
-    """BASELINE configs[2]: LLFF-like 3-view training step WITH the consistency terms — hard masks from the cross-view depth
-    warp (V:994-1046), masked rgb + depth losses on both levels (V:1645-1865), the monocular-depth patch term on 4 16x16
-    patches (V:1678-1720), clip 0.1 + Adam (V:1983).  378x504 views, no_ndc, near 1.2 / far 12, 4096 random + 1024 patch
-    rays per step."""
+def c3_scene(dev):
+    """The C3 leg's LLFF-like rig: 3 analytic 378x504 views, noisy depth priors, hard masks (V:994-1046), monocular priors."""
     import tempfile
     import _inputs as I
-    from consistentnerf_amd import raybank as RB, run_nerf_view as V
+    from consistentnerf_amd import run_nerf_view as V
     H, W, focal, near, far = 378, 504, 407.0, 1.2, 12.0
     a = make_args(tempfile.mkdtemp())
     a.dataset_type, a.stable_init = "llff", False
@@ -538,46 +535,185 @@ def c3_leg(dev, steps=20):
     torch.cuda.synchronize()
     t_masks = time.perf_counter() - t0
     mono = 1.0 / np.maximum(depths, 1e-3)
-    img_t = [torch.from_numpy(images[i]).to(dev) for i in range(3)]
-    dep_t = [torch.from_numpy(depths[i]).to(dev) for i in range(3)]
-    msk_t = [torch.from_numpy(masks[i].astype(np.float32)).to(dev) for i in range(3)]
-    mono_t = [torch.from_numpy(mono[i].astype(np.float32)).to(dev) for i in range(3)]
-    N_rand, B = 4096, 4096 + 1024
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(dev)  # noqa: E731
+    return dict(H=H, W=W, K=K, near=near, far=far, poses=poses, kw=kw_train, opt=optimizer, images=images, depths=depths, masks=masks,
+                img_t=[t(images[i]) for i in range(3)], dep_t=[t(depths[i]) for i in range(3)],
+                msk_t=[t(masks[i]) for i in range(3)], mono_t=[t(mono[i]) for i in range(3)], t_masks=t_masks)
+
+
+def c3_step_fn(sc, route="render_loss"):
+    """One C3 training step (V:1452-1517 batch, V:1636-1865 loss, V:1982-1994 tail) on the rig of c3_scene().
+    route "render_loss": the round-5 surface — raybank.sample_patch_rays (ONE sampling launch that also writes the packed ray rows),
+    run_nerf_view.render_loss (every loss term in the compositing launches + one tail launch), run_nerf.backward;
+    route "reference_lines": the same step as the reference's statements (round 4's form: separate loss launches + ATen glue)."""
+    from consistentnerf_amd import raybank as RB, run_nerf as R, run_nerf_view as V
+    H, W, K, far, kw, opt = sc["H"], sc["W"], sc["K"], sc["far"], sc["kw"], sc["opt"]
 
     def step(i):
         v = i % 3
         starts = RB.draw_patch_starts(H, W, 4, 16)
         rays, target, sel, (d_prior, m, mono_s) = RB.sample_patch_rays(
-            img_t[v], poses[v], H, W, K, N_rand, starts, extras=(dep_t[v], msk_t[v], mono_t[v]))
-        rgb, disp, acc, depth, extras = V.render(H, W, K, chunk=32768, rays=rays, retraw=True, **kw_train)
-        optimizer.zero_grad()
-        il, dl = V.hardmask_losses(rgb, target, m, 0.2, depth, d_prior, far)
-        il0, dl0 = V.hardmask_losses(extras['rgb0'], target, m, 0.2, extras['depth0'], d_prior, far)
-        loss = il + il0 + 0.1 * (dl + dl0)
-        loss = loss + 0.001 * (V.midas_patch_loss(depth, mono_s, 4, 16) + V.midas_patch_loss(extras['depth0'], mono_s, 4, 16))
-        loss.backward()
-        optimizer.step()
-        for pg in optimizer.param_groups:
+            sc["img_t"][v], sc["poses"][v], H, W, K, 4096, starts, extras=(sc["dep_t"][v], sc["msk_t"][v], sc["mono_t"][v]),
+            render_kwargs=kw)
+        if route == "render_loss":
+            loss = V.render_loss(H, W, K, target, mask=m, depth_prior=d_prior, chunk=32768, rays=rays, hardmask_coef=0.2,
+                                 depth_w=0.1, mono=mono_s, patch_num=4, patch_size=16, patch_w=0.001, retraw=True, **kw)[0]
+            opt.zero_grad()
+            R.backward(loss)
+        else:
+            rgb, disp, acc, depth, extras = V.render(H, W, K, chunk=32768, rays=rays, retraw=True, **kw)
+            opt.zero_grad()
+            il, dl = V.hardmask_losses(rgb, target, m, 0.2, depth, d_prior, far)
+            il0, dl0 = V.hardmask_losses(extras['rgb0'], target, m, 0.2, extras['depth0'], d_prior, far)
+            loss = il + il0 + 0.1 * (dl + dl0)
+            loss = loss + 0.001 * (V.midas_patch_loss(depth, mono_s, 4, 16) + V.midas_patch_loss(extras['depth0'], mono_s, 4, 16))
+            loss.backward()
+        opt.step()
+        for pg in opt.param_groups:
             pg['lr'] = 5e-4 * (0.1 ** (i / 250000))
         return loss
+    return step
 
-    for i in range(3):
+
+def c3_ss_step_fn(sc):
+    """The in-loop consistency variant of the step (run_nerf_view_test.py VT:895-972, `--ss_loss --with_depth_loss`): primary render of
+    4096 random rays of view v; their depth-prior points warped into a random other training view (a12, VT variant), occlusion test,
+    a SECOND full render on the warped rays + its four loss terms (run_nerf_view.ss_consistency); the primary render's terms
+    restricted by the masks per coin (ss_primary_losses); backward through both renders; Adam.  ~2x the MLP work of a plain step."""
+    from consistentnerf_amd import raybank as RB, run_nerf_view as V
+    H, W, K, kw, opt = sc["H"], sc["W"], sc["K"], sc["kw"], sc["opt"]
+    rs = np.random.RandomState(3)
+
+    def step(i):
+        v, r = i % 3, (i + 1 + int(rs.randint(0, 2))) % 3
+        rays, target, sel, (d_prior,) = RB.sample_patch_rays(sc["img_t"][v], sc["poses"][v], H, W, K, 4096, None,
+                                                             extras=(sc["dep_t"][v],), render_kwargs=kw)
+        rgb, disp, acc, depth, extras = V.render(H, W, K, chunk=32768, rays=rays, retraw=True, **kw)
+        ss = V.ss_consistency(rays[0], rays[1], d_prior, sc["poses"][r], K, sc["img_t"][r], sc["dep_t"][r], H, W, kw, chunk=32768,
+                              occlusion_threshold=0.1, with_depth_loss=True)
+        opt.zero_grad()
+        lp, _, _ = V.ss_primary_losses(rgb, depth, extras, target, d_prior, ss["mask_bound"], ss["mask"], with_depth_loss=True,
+                                       coins=[int(c) for c in rs.randint(0, 2, 4)])
+        loss = ss["loss"] + lp
+        loss.backward()
+        opt.step()
+        step.rays_second = int(ss["batch_rays_ref"].shape[1])
+        return loss
+    step.rays_second = 0
+    return step
+
+
+def _time_steps(step, steps, warm=3):
+    from consistentnerf_amd import ops
+    for i in range(warm):
         step(i)
     torch.cuda.synchronize()
+    ops.PROFILE = []
     t0 = time.perf_counter()
     for i in range(steps):
-        loss = step(3 + i)
+        loss = step(warm + i)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    prof, ops.PROFILE = ops.PROFILE, None
+    return dt, loss, prof
+
+
+def c3_dispatch_pass(leg):
+    """Launches of ONE step of a C3 leg: a `rocprofv3 --kernel-trace` pass over `bench.py --only-leg <leg>` (6 steps), the ordered
+    dispatch list cut at the adam_k launches (launches_per_step)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return {"total": None, "source": "rocprofv3 not on PATH"}
+    d = tempfile.mkdtemp(prefix="cnerf_c3_")
+    try:
+        cmd = ["rocprofv3", "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
+               os.path.abspath(__file__), "--only-leg", leg]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp")
+        except subprocess.TimeoutExpired:
+            return {"total": None, "source": "rocprofv3 --kernel-trace pass timed out"}
+        files = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            return {"total": None, "source": f"rocprofv3 pass rc={r.returncode}: {r.stderr[-300:]}"}
+        disp = {}
+        for f in files:
+            with open(f) as fh:
+                for row in csv.DictReader(fh):
+                    disp[(int(row["Start_Timestamp"]), int(row["Dispatch_Id"]))] = row["Kernel_Name"]
+        keys = sorted(disp)
+        out = launches_per_step({k: disp[key] for k, key in enumerate(keys)})
+        if out is not None:
+            out["source"] = f"rocprofv3 --kernel-trace pass of `bench.py --only-leg {leg}`; one step = the dispatches between two adam_k"
+        return out or {"total": None, "source": "fewer than two adam_k launches in the trace"}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def only_leg(dev, leg):
+    """`--only-leg c3 | c3_ss`: a few steps of that leg and nothing else (what c3_dispatch_pass profiles)."""
+    sc = c3_scene(dev)
+    step = c3_step_fn(sc) if leg == "c3" else c3_ss_step_fn(sc)
+    for i in range(6):
+        step(i)
+    torch.cuda.synchronize()
+
+
+def c3_leg(dev, steps=20):
+    """BASELINE configs[2]: LLFF-like 3-view training step WITH the consistency terms — hard masks from the cross-view depth
+    warp (V:994-1046), masked rgb + depth losses on both levels (V:1645-1865), the monocular-depth patch term on 4 16x16
+    patches (V:1678-1720), clip 0.1 + Adam (V:1983).  378x504 views, no_ndc, near 1.2 / far 12, 4096 random + 1024 patch
+    rays per step.  Timed through the round-5 one-call surface (c3_step_fn "render_loss"); the reference-lines form beside it."""
+    sc = c3_scene(dev)
+    B = 4096 + 1024
     n = B * (NC + NC + NF)
+    dt, loss, prof = _time_steps(c3_step_fn(sc), steps)
+    table = per_kernel_table(prof, dt * steps * 1e3)
     tf = n * 2 * (MAC_FWD + MAC_DGRAD + MAC_WGRAD) / dt / 1e12
-    return {"ms_per_step": dt * 1e3, "steps": steps, "rays_per_step": B, "ray_samples_per_s": n / dt,
-            "hard_masks_3views_ms": t_masks * 1e3, "hard_mask_fraction": float(masks.mean()), "final_loss": float(loss.item()),
-            "finite": bool(np.isfinite(loss.item())),
-            "step": "3 LLFF-like 378x504 views, no_ndc; hard masks + masked rgb/depth losses on both levels + monocular patch "
-                    "term (4 x 16x16) + clip 0.1 + Adam; 4096 random + 1024 patch rays, 64+128 samples, D=8 W=256",
-            "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4), "basis": "whole step, 3489024 FLOP per ray-sample"}}
+    dt_lines, loss_lines, _ = _time_steps(c3_step_fn(sc, "reference_lines"), steps)
+    masks = sc["masks"]
+    out = {"ms_per_step": dt * 1e3, "steps": steps, "rays_per_step": B, "ray_samples_per_s": n / dt,
+           "ms_per_step_reference_lines": dt_lines * 1e3,
+           "hard_masks_3views_ms": sc["t_masks"] * 1e3, "hard_mask_fraction": float(masks.mean()), "final_loss": float(loss.item()),
+           "finite": bool(np.isfinite(loss.item())),
+           "step": "3 LLFF-like 378x504 views, no_ndc; ONE sampling launch (patch + random pixels drawn in-kernel, rays / colours / "
+                   "priors gathered, ray rows packed); hard masks + masked rgb/depth losses on both levels + monocular patch term "
+                   "(4 x 16x16) folded into the compositing launches (run_nerf_view.render_loss); clip 0.1 + Adam; 4096 random + 1024 "
+                   "patch rays, 64+128 samples, D=8 W=256",
+           "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4), "basis": "whole step, 3489024 FLOP per ray-sample",
+                        "kernels": table},
+           "launches_per_step": c3_dispatch_pass("c3")}
+    del sc
+    torch.cuda.empty_cache()
+    return out
+
+
+def c3_ss_leg(dev, steps=10):
+    """a15 timed (VERDICT r04 missing 4): the in-loop consistency step, c3_ss_step_fn."""
+    sc = c3_scene(dev)
+    step = c3_ss_step_fn(sc)
+    dt, loss, prof = _time_steps(step, steps)
+    table = per_kernel_table(prof, dt * steps * 1e3)
+    # MFMA work actually launched per step: both renders' ray-samples (the second render's ray count varies: in-bounds warped rays)
+    pts = sum(r["points"] * r["launches"] for r in table if r["kernel"] == "mlp_wgrad") / steps
+    tf = pts * 2 * (MAC_FWD + MAC_DGRAD + MAC_WGRAD) / dt / 1e12
+    out = {"ms_per_step": dt * 1e3, "steps": steps, "rays_primary": 4096, "rays_second_render_last_step": step.rays_second,
+           "ray_samples_per_step_avg": pts, "ray_samples_per_s": pts / dt, "final_loss": float(loss.item()),
+           "finite": bool(np.isfinite(loss.item())),
+           "step": "VT:895-972 with --ss_loss --with_depth_loss: primary render (4096 rays) + warp into a reference view + occlusion "
+                   "mask + second render on the warped rays + 4 consistency terms + the primary terms under the masks per coin; "
+                   "backward through both renders; Adam",
+           "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                        "basis": "whole step / the ray-samples its wgrad launches covered, 3489024 FLOP per ray-sample", "kernels": table},
+           "launches_per_step": c3_dispatch_pass("c3_ss")}
+    del sc
+    torch.cuda.empty_cache()
+    return out
 
 
 def pmc_traffic(kernel, points):
@@ -871,7 +1007,14 @@ def main():
     ap.add_argument("--pmc", nargs="?", const="on", default="auto", choices=("auto", "on", "off"),
                     help="fill roofline.traffic from two rocprofv3 --pmc passes of THIS command (auto: at N=1 when the extra legs run and "
                          "rocprofv3 is on PATH; the committed lookup is the fallback)")
+    ap.add_argument("--only-leg", choices=("c3", "c3_ss"), default=None, help=argparse.SUPPRESS)
     a = ap.parse_args()
+    if a.only_leg:
+        sys.stdout.flush()
+        os.dup2(2, 1)
+        torch.cuda.set_device(0)
+        only_leg(torch.device("cuda", 0), a.only_leg)
+        return
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` launched plainly (no torchrun around it): become the launcher
         raise SystemExit(self_launch(a.gpus))
@@ -1060,6 +1203,10 @@ def main():
                 torch.cuda.empty_cache()
             extra["c5"] = c5_leg(dev)
             extra["c3"] = c3_leg(dev)
+            try:
+                extra["c3_ss"] = c3_ss_leg(dev)
+            except Exception as e:  # noqa: BLE001 — the headline line must survive a failure of a side leg
+                extra["c3_ss"] = {"error": f"{type(e).__name__}: {e}"}
             extra["hbm_kernels"] = hbm_kernels(dev)
             extra["launches_per_step"] = launches_live if launches_live is not None else {
                 "total": None, "source": "needs the rocprofv3 pass (--pmc auto|on with rocprofv3 on PATH)"}

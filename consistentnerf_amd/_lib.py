@@ -54,7 +54,30 @@ class Rng(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("offset", C.c_uint64), ("state_dev", C.c_void_p), ("row0", C.c_int64)]
 
 
+class Closs(C.Structure):
+    """struct cnerf_closs"""
+    _fields_ = [("target", C.c_void_p), ("mask", C.c_void_p), ("prior", C.c_void_p), ("far", C.c_float)]
+
+
+class ClossTail(C.Structure):
+    """struct cnerf_closs_sum"""
+    _fields_ = [("ws_last", C.c_void_p), ("ws_coarse", C.c_void_p), ("B", C.c_int64), ("counts", C.c_void_p),
+                ("coef", C.c_float), ("far", C.c_float), ("rgb_w", C.c_float), ("depth_w", C.c_float), ("patch_w", C.c_float),
+                ("has_depth", C.c_int32), ("depth_last", C.c_void_p), ("depth_coarse", C.c_void_p), ("mono", C.c_void_p),
+                ("P", C.c_int32), ("n", C.c_int32)]
+
+
+class PixelBatch(C.Structure):
+    """struct cnerf_pixel_batch"""
+    _fields_ = [("H", C.c_int32), ("W", C.c_int32), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("c2w", C.c_float * 12), ("near", C.c_float), ("far", C.c_float), ("use_viewdirs", C.c_int32), ("ndc", C.c_int32),
+                ("ndc_ax", C.c_float), ("ndc_ay", C.c_float), ("crop_r0", C.c_int32), ("crop_c0", C.c_int32),
+                ("crop_h", C.c_int32), ("crop_w", C.c_int32), ("n_patches", C.c_int32), ("patch_size", C.c_int32),
+                ("patch_start", (C.c_int32 * 2) * 16), ("n_rand", C.c_int64), ("image_ch", C.c_int32), ("n_extras", C.c_int32)]
+
+
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+_ClossP = C.POINTER(Closs)
 _RngP = C.POINTER(Rng)
 _NetP, _PtrsP = C.POINTER(Net), C.POINTER(Ptrs)
 
@@ -77,6 +100,12 @@ SIGNATURES = {
     "cnerf_composite_mse_max_rays": (_i64, []),
     "cnerf_composite_fwd_mse": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cnerf_composite_bwd_mse": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "cnerf_closs_ws_floats": (_i64, [_i64]),
+    "cnerf_composite_fwd_closs": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i64, _i, _i, _ClossP, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cnerf_closs_finish": (_i, [C.POINTER(ClossTail), _vp, _vp, _vp, _vp]),
+    "cnerf_composite_bwd_closs": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i64, _i, _i, _ClossP, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _i64,
+                                       _vp, _vp]),
+    "cnerf_sample_pixels": (_i, [C.POINTER(PixelBatch), _vp, _RngP, _vp, C.POINTER(_vp), _vp, _vp, _vp, _vp, _vp, _vp]),
     "cnerf_embed": (_i, [_vp, _i64, _i, _vp, _vp]),
     "cnerf_mlp_stash_floats": (_i64, [_NetP, _i64]),
     "cnerf_mlp_fwd": (_i, [_NetP, _vp, _vp, _vp, _i, _vp, _vp, _i64, _i, _vp, _vp, _vp]),
@@ -145,7 +174,7 @@ def load():
         except AttributeError as e:
             raise CnerfError(f"libcnerf_hip.so does not export {name}") from e
         fn.restype, fn.argtypes = res, args
-    if lib.cnerf_abi_version() != 3:
+    if lib.cnerf_abi_version() != 4:
         raise CnerfError("libcnerf_hip.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

@@ -409,7 +409,7 @@ extern "C" int cnerf_patch_depth_loss(const float* depth_pred, const float* mono
   return CNERF_OK;
 }
 
-extern "C" int cnerf_closs_tail(const cnerf_closs_tail* t, float* terms, float* stats, float* patch_d, void* stream) {
+extern "C" int cnerf_closs_finish(const cnerf_closs_sum* t, float* terms, float* stats, float* patch_d, void* stream) {
   if (!t || !terms || !stats || !t->ws_last || t->B <= 0 || t->P < 0 || t->P > 8 || (t->P > 0 && (t->n <= 0 || !t->mono || !t->depth_last)) ||
       (t->P > 0 && t->ws_coarse && !t->depth_coarse) || (t->has_depth && !(t->far > 0.f)) || (int64_t)t->P * t->n > t->B ||
       ((uintptr_t)t->ws_last & 7) != 0 || ((uintptr_t)t->ws_coarse & 7) != 0)

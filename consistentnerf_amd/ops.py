@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import CnerfError, Net, Ptrs, RayGen, RenderCfg, RenderGrads, RenderOut, Rng
+from ._lib import Closs, ClossTail, CnerfError, Net, PixelBatch, Ptrs, RayGen, RenderCfg, RenderGrads, RenderOut, Rng
 
 Tensor = torch.Tensor
 
@@ -579,6 +579,91 @@ def composite_backward_mse(raw, z, rays, noise, white_bkgd, rgb, target, g_loss)
     return d_raw
 
 
+# ---- the ConsistentNeRF losses folded into compositing (cnerf_composite_fwd_closs / cnerf_closs_finish / cnerf_composite_bwd_closs)
+@dataclass
+class ClossSpec:
+    """The loss of one ConsistentNeRF training batch (V:1645-1865): masked rgb + depth terms on every level (mask [B] 0/1 floats or
+    None; prior [B] or None = no depth term; depths compared after / far), the monocular patch term on the first P * n rays (mono
+    [P * n] or None), weights of the three kinds of term in the step's loss, optional GLOBAL (n1, n0) for a sharded batch."""
+    target: Tensor
+    mask: Optional[Tensor] = None
+    prior: Optional[Tensor] = None
+    far: float = 1.0
+    coef: float = 0.2
+    rgb_w: float = 1.0
+    depth_w: float = 1.0
+    patch_w: float = 0.001
+    mono: Optional[Tensor] = None
+    P: int = 0
+    n: int = 256
+    counts: Optional[Tensor] = None
+
+    def c(self) -> Closs:
+        return Closs(self.target.data_ptr(), None if self.mask is None else self.mask.data_ptr(),
+                     None if self.prior is None else self.prior.data_ptr(), float(self.far))
+
+    def checked(self, B: int) -> "ClossSpec":
+        t = _chk(self.target.reshape(-1, 3), "target")
+        if t.shape[0] != B or B == 0:
+            raise CnerfError(f"closs: target must be [{B}, 3] with B > 0, got {tuple(self.target.shape)}")
+        m = None if self.mask is None else _chk(self.mask.reshape(-1).to(torch.float32), "mask")
+        pr = None if self.prior is None else _chk(self.prior.reshape(-1), "prior")
+        mono = None if (self.mono is None or self.P <= 0) else _chk(self.mono.reshape(-1), "mono")
+        for x, nme in ((m, "mask"), (pr, "prior")):
+            if x is not None and x.numel() != B:
+                raise CnerfError(f"closs: {nme} must have {B} elements, got {x.numel()}")
+        P = int(self.P) if mono is not None else 0
+        if P > 0 and (mono.numel() < P * self.n or P * self.n > B or P > 8):
+            raise CnerfError(f"closs: the patch term needs P <= 8 patches of n rays inside the batch (P={P}, n={self.n}, B={B})")
+        return ClossSpec(t, m, pr, float(self.far), float(self.coef), float(self.rgb_w), float(self.depth_w), float(self.patch_w),
+                         mono, P, int(self.n), _chk(self.counts, "counts"))
+
+
+def composite_forward_closs(raw: Tensor, z: Tensor, rays: Tensor, noise: Optional[Tensor], white_bkgd: bool, L: ClossSpec):
+    """-> (rgb, disp, acc, weights, depth, ws): raw2outputs + the level's five masked-loss partial sums per workgroup in `ws`."""
+    raw, z, rays, noise = _chk(raw, "raw"), _chk(z, "z"), _chk(rays, "rays"), _chk(noise, "noise")
+    B, S = z.shape
+    dev = raw.device
+    rgb = torch.empty(B, 3, device=dev)
+    disp, acc, depth = torch.empty(B, device=dev), torch.empty(B, device=dev), torch.empty(B, device=dev)
+    weights = torch.empty(B, S, device=dev)
+    lib = _lib.load()
+    ws = torch.empty(lib.cnerf_closs_ws_floats(B) // 2, device=dev, dtype=torch.float64)
+    c = L.c()
+    _lib.check(lib.cnerf_composite_fwd_closs(_p(raw), raw.shape[-1], _p(z), _p(rays), rays.shape[1], _p(noise), B, S,
+                                             int(white_bkgd), C.byref(c), _p(rgb), _p(disp), _p(acc), _p(depth), _p(weights),
+                                             _p(ws), _stream()), "cnerf_composite_fwd_closs")
+    return rgb, disp, acc, weights, depth, ws
+
+
+def closs_finish(L: ClossSpec, B: int, ws_last: Tensor, ws_coarse: Optional[Tensor], depth_last: Optional[Tensor],
+                 depth_coarse: Optional[Tensor], want_grad: bool = True):
+    """cnerf_closs_finish -> (terms[8], stats[8], patch_d[levels, P * n] | None)."""
+    dev = ws_last.device
+    terms, stats = torch.empty(8, device=dev), torch.empty(8, device=dev)
+    levels = 2 if ws_coarse is not None else 1
+    patch_d = torch.empty(levels, L.P * L.n, device=dev) if (L.P > 0 and want_grad) else None
+    a = lambda x: None if x is None else x.data_ptr()  # noqa: E731
+    t = ClossTail(a(ws_last), a(ws_coarse), int(B), a(L.counts), L.coef, L.far, L.rgb_w, L.depth_w, L.patch_w,
+                  int(L.prior is not None), a(depth_last) if L.P > 0 else None,
+                  a(depth_coarse) if (L.P > 0 and levels == 2) else None, a(L.mono) if L.P > 0 else None, L.P, L.n)
+    _lib.check(_lib.load().cnerf_closs_finish(C.byref(t), _p(terms), _p(stats), _p(patch_d), _stream()), "cnerf_closs_finish")
+    return terms, stats, patch_d
+
+
+def composite_backward_closs(raw, z, rays, noise, white_bkgd, L: ClossSpec, rgb, depth, stats4, g_loss, patch_d) -> Tensor:
+    raw, z, rays, noise = _chk(raw, "raw"), _chk(z, "z"), _chk(rays, "rays"), _chk(noise, "noise")
+    B, S = z.shape
+    d_raw = torch.empty_like(raw)
+    c = L.c()
+    _lib.check(_lib.load().cnerf_composite_bwd_closs(_p(raw), raw.shape[-1], _p(z), _p(rays), rays.shape[1], _p(noise), B, S,
+                                                     int(white_bkgd), C.byref(c), _p(rgb), _p(depth), _p(stats4), _p(g_loss),
+                                                     L.rgb_w, L.depth_w, L.patch_w, _p(patch_d),
+                                                     L.P * L.n if patch_d is not None else 0, _p(d_raw), _stream()),
+               "cnerf_composite_bwd_closs")
+    return d_raw
+
+
 def composite_backward(raw, z, rays, noise, white_bkgd, g_rgb, g_disp, g_acc, g_depth) -> Tensor:
     raw, z, rays, noise = _chk(raw, "raw"), _chk(z, "z"), _chk(rays, "rays"), _chk(noise, "noise")
     g_rgb, g_disp, g_acc, g_depth = (_chk(g, "grad") for g in (g_rgb, g_disp, g_acc, g_depth))
@@ -619,6 +704,52 @@ def pack_rays(rays_o: Tensor, rays_d: Tensor, near: float, far: float, use_viewd
     return rays
 
 
+def sample_pixels(H: int, W: int, K, c2w, near: float, far: float, use_viewdirs: bool, ndc: bool, ndc_coef, crop, patch_starts,
+                  patch_size: int, n_rand: int, select_inds: Optional[Tensor], rng: Optional[RngStream], image: Tensor,
+                  extras: Sequence[Tensor] = (), want_rows: bool = True, want_od: bool = True, want_coords: bool = True):
+    """cnerf_sample_pixels: the training batch of one image in one launch -> (rays [B, 8|11] | None, rays_od [2, B, 3] | None,
+    target [B, 3], extras_out [n_extras, B], coords [B, 2] | None).  crop = (r0, c0, h, w) of the grid the random pixels come
+    from; patch_starts [P, 2] host integers (or None); select_inds: device int64 [n_rand] or None (device draw keyed by rng)."""
+    image = _chk(image, "image")
+    if image.dim() != 3 or image.shape[0] != H or image.shape[1] != W or image.shape[2] < 3:
+        raise CnerfError(f"sample_pixels: image must be [{H}, {W}, >=3], got {tuple(image.shape)}")
+    dev = image.device
+    ex = [_chk(e, "extra") for e in extras]
+    for e in ex:
+        if tuple(e.shape) != (H, W):
+            raise CnerfError(f"sample_pixels: per-pixel maps must be [{H}, {W}], got {tuple(e.shape)}")
+    starts = np.zeros((0, 2), np.int64) if patch_starts is None else np.asarray(patch_starts, np.int64).reshape(-1, 2)
+    P = starts.shape[0]
+    cfg = PixelBatch()
+    cfg.H, cfg.W, cfg.fx, cfg.fy, cfg.cx, cfg.cy = H, W, float(K[0][0]), float(K[1][1]), float(K[0][2]), float(K[1][2])
+    if isinstance(c2w, torch.Tensor):
+        c2w = c2w.detach().cpu().numpy()
+    cfg.c2w = _f4(c2w)
+    cfg.near, cfg.far, cfg.use_viewdirs, cfg.ndc = float(near), float(far), int(use_viewdirs), int(ndc)
+    cfg.ndc_ax, cfg.ndc_ay = float(ndc_coef[0]), float(ndc_coef[1])
+    cfg.crop_r0, cfg.crop_c0, cfg.crop_h, cfg.crop_w = (int(v) for v in crop)
+    cfg.n_patches, cfg.patch_size = P, int(patch_size)
+    for q in range(P):
+        cfg.patch_start[q][0], cfg.patch_start[q][1] = int(starts[q, 0]), int(starts[q, 1])
+    cfg.n_rand, cfg.image_ch, cfg.n_extras = int(n_rand), int(image.shape[2]), len(ex)
+    B = P * patch_size * patch_size + int(n_rand)
+    if select_inds is not None:
+        select_inds = _chk(select_inds, "select_inds", dtype=torch.int64)
+        if select_inds.numel() != n_rand:
+            raise CnerfError(f"sample_pixels: select_inds must have {n_rand} elements")
+    rows = torch.empty(B, 11 if use_viewdirs else 8, device=dev) if want_rows else None
+    od = torch.empty(2, B, 3, device=dev) if want_od else None
+    target = torch.empty(B, 3, device=dev)
+    ex_out = torch.empty(len(ex), B, device=dev) if ex else None
+    coords = torch.empty(B, 2, device=dev, dtype=torch.int64) if want_coords else None
+    ptrs = (C.c_void_p * max(1, len(ex)))(*[e.data_ptr() for e in ex])
+    r = rng.c(0) if (rng is not None and select_inds is None) else None
+    _lib.check(_lib.load().cnerf_sample_pixels(C.byref(cfg), _p(select_inds), C.byref(r) if r is not None else None, _p(image), ptrs,
+                                               _p(rows), _p(od), _p(target), _p(ex_out), _p(coords), _stream()),
+               "cnerf_sample_pixels")
+    return rows, od, target, ex_out, coords
+
+
 # ------------------------------------------------------------------------------------------ warp / masks
 def warp_points(P: Tensor, w2c, K, H: int, W: int, flip: bool):
     P = _chk(P.reshape(-1, 3), "P")
@@ -647,6 +778,9 @@ def hard_mask_pair(H, W, K, c2w_tgt, w2c_ref, depth_tgt: Tensor, depth_ref: Tens
 
 
 # ------------------------------------------------------------------------------------------ loss / optimiser
+MASKED_LOSS_SINGLE_WORKGROUP = 16384     # rays up to which cnerf_masked_loss runs as one workgroup
+
+
 def masked_loss(rgb, target, depth, prior, mask, far: float, coef: float, counts=None, g_scale: float = 1.0,
                 want_grads: bool = True):
     rgb, target = _chk(rgb, "rgb"), _chk(target, "target")
@@ -656,9 +790,11 @@ def masked_loss(rgb, target, depth, prior, mask, far: float, coef: float, counts
     loss = torch.empty(2, device=dev)
     d_rgb = torch.empty_like(rgb) if want_grads else None
     d_depth = torch.empty(B, device=dev) if (want_grads and depth is not None) else None
-    _lib.check(_lib.load().cnerf_masked_loss(_p(rgb), _p(target), _p(depth), _p(prior), _p(mask), B, float(far),
-                                             float(coef), _p(counts), float(g_scale), _p(loss), _p(d_rgb), _p(d_depth),
-                                             None, _stream()), "cnerf_masked_loss")
+    lib = _lib.load()
+    # beyond one workgroup's comfortable size: one workgroup per 16384 rays + a fixed-order second stage (needs the workspace)
+    ws = torch.empty(lib.cnerf_loss_ws_floats() // 2, device=dev, dtype=torch.float64) if B > MASKED_LOSS_SINGLE_WORKGROUP else None
+    _lib.check(lib.cnerf_masked_loss(_p(rgb), _p(target), _p(depth), _p(prior), _p(mask), B, float(far), float(coef), _p(counts),
+                                     float(g_scale), _p(loss), _p(d_rgb), _p(d_depth), _p(ws), _stream()), "cnerf_masked_loss")
     return loss, d_rgb, d_depth
 
 

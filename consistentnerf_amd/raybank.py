@@ -14,6 +14,59 @@ import numpy as np
 import torch
 
 from . import ops
+from .run_nerf_helpers import ndc_coefficients
+
+
+class PackedRays:
+    """The [B, 8|11] rows render() would assemble from a (rays_o, rays_d) batch (R:100-125), written by the sampler's own launch
+    for the camera / bounds named here; attached to the `batch_rays` tensor as `_cnerf_packed`, taken by run_nerf._ray_batch when
+    the render() call asks for exactly these bounds (otherwise the rays are packed again, as for any caller's batch)."""
+    __slots__ = ("rows", "H", "W", "focal", "near", "far", "use_viewdirs", "ndc")
+
+    def __init__(self, rows, H, W, focal, near, far, use_viewdirs, ndc):
+        self.rows, self.H, self.W, self.focal = rows, int(H), int(W), float(focal)
+        self.near, self.far, self.use_viewdirs, self.ndc = float(near), float(far), bool(use_viewdirs), bool(ndc)
+
+    def matches(self, H, W, K, near, far, use_viewdirs, ndc, device):
+        if torch.is_tensor(near) or torch.is_tensor(far):
+            return False
+        return (self.rows.device == torch.device(device) and float(near) == self.near and float(far) == self.far
+                and bool(use_viewdirs) == self.use_viewdirs and bool(ndc) == self.ndc
+                and (not self.ndc or (int(H) == self.H and int(W) == self.W and float(K[0][0]) == self.focal)))
+
+
+def _pack_args(render_kwargs):
+    """(near, far, use_viewdirs, ndc) of the render() call the batch is for (render's own defaults, R:70-71)."""
+    if render_kwargs is None:
+        return None
+    return (float(render_kwargs.get("near", 0.)), float(render_kwargs.get("far", 1.)),
+            bool(render_kwargs.get("use_viewdirs", False)), bool(render_kwargs.get("ndc", True)))
+
+
+def _sample(target, pose, H, W, K, N_rand, patch_starts, patch_size, select_inds, precrop_frac, extras, render_kwargs):
+    """One launch (cnerf_sample_pixels) for everything the two samplers below return."""
+    dev = target.device if isinstance(target, torch.Tensor) and target.is_cuda else torch.device(
+        "cuda", torch.cuda.current_device())
+    image = torch.as_tensor(target, dtype=torch.float32).to(dev)
+    H, W = int(H), int(W)
+    if precrop_frac is not None:
+        dH, dW = int(H // 2 * precrop_frac), int(W // 2 * precrop_frac)
+        crop = (H // 2 - dH, W // 2 - dW, 2 * dH, 2 * dW)
+    else:
+        crop = (0, 0, H, W)
+    pk = _pack_args(render_kwargs)
+    near, far, vd, ndc = pk if pk is not None else (0., 1., False, False)
+    coef = ndc_coefficients(H, W, K[0][0]) if ndc else (0., 0.)
+    sel = None if select_inds is None else torch.as_tensor(select_inds, device=dev, dtype=torch.long)
+    n_rand = int(N_rand) if sel is None else int(sel.numel())
+    rng = ops.rng_draw(dev) if sel is None and n_rand > 0 else None
+    ex = [torch.as_tensor(e, dtype=torch.float32).to(dev) for e in extras]
+    rows, od, tgt, ex_out, coords = ops.sample_pixels(H, W, K, np.asarray(pose.cpu() if isinstance(pose, torch.Tensor) else pose)[:3, :4],
+                                                      near, far, vd, ndc, coef, crop, patch_starts, patch_size, n_rand, sel, rng,
+                                                      image, ex, want_rows=pk is not None)
+    if rows is not None:
+        od._cnerf_packed = PackedRays(rows, H, W, K[0][0], near, far, vd, ndc)
+    return od, tgt, coords, ([ex_out[i] for i in range(len(ex))] if ex else [])
 
 
 def _perm_like_numpy_shuffle(n, seed):
@@ -90,22 +143,13 @@ def _coords_on(dev, H, W, precrop_frac):
     return _COORDS[key]
 
 
-def sample_image_rays(target, pose, H, W, K, N_rand, precrop_frac=None, select_inds=None):
+def sample_image_rays(target, pose, H, W, K, N_rand, precrop_frac=None, select_inds=None, render_kwargs=None):
     """R:730-757: N_rand distinct pixels of one image -> (batch_rays [2, B, 3], target_s [B, 3]).
-    `select_inds` = indices into the (cropped) pixel grid; default: a device-side draw without replacement."""
-    dev = target.device if isinstance(target, torch.Tensor) and target.is_cuda else torch.device(
-        "cuda", torch.cuda.current_device())
-    target = torch.as_tensor(target, dtype=torch.float32).to(dev)
-    c2w = torch.as_tensor(np.asarray(pose)[:3, :4] if not isinstance(pose, torch.Tensor) else pose[:3, :4],
-                          dtype=torch.float32)
-    r = ops.gen_rays(int(H), int(W), K, c2w, 0., 1., False, False, dev)
-    coords = _coords_on(dev, H, W, precrop_frac)
-    if select_inds is None:
-        select_inds = torch.randperm(coords.shape[0], device=dev)[:N_rand]
-    sel = coords[torch.as_tensor(select_inds, device=dev, dtype=torch.long)]
-    flat = sel[:, 0] * int(W) + sel[:, 1]
-    batch_rays = torch.stack([r[flat, 0:3], r[flat, 3:6]], 0)
-    return batch_rays, target[sel[:, 0], sel[:, 1], :3]
+    `select_inds` = indices into the (cropped) pixel grid (the reference's own `np.random.choice`); default: a device-side draw
+    without replacement inside the sampling launch (a keyed permutation of the grid, csrc/sampler.hip) — one launch either way.
+    `render_kwargs` (the dict the batch will be rendered with): the launch also writes the [B, 8|11] rows render() would pack."""
+    od, tgt, _, _ = _sample(target, pose, H, W, K, N_rand, None, 1, select_inds, precrop_frac, (), render_kwargs)
+    return od, tgt
 
 
 # ---- patch sampler of run_nerf_view.train() (V:1471-1517) ------------------------------------------------------------
@@ -145,22 +189,11 @@ def patch_coords(starts, patch_size=16, device=None):
 
 
 def sample_patch_rays(target, pose, H, W, K, N_rand, patch_starts, select_inds=None, precrop_frac=None, patch_size=16,
-                      extras=()):
+                      extras=(), render_kwargs=None):
     """V:1452-1517: the P patches' pixels first, then N_rand distinct random pixels of the (cropped) grid ->
     (batch_rays [2, P*ps*ps + N_rand, 3], target_s, select_coords [.., 2], [e[select_coords] for e in extras])
-    — `extras` are per-pixel maps sampled at the same pixels (depth priors, hard mask, monocular depth)."""
-    dev = target.device if isinstance(target, torch.Tensor) and target.is_cuda else torch.device(
-        "cuda", torch.cuda.current_device())
-    target = torch.as_tensor(target, dtype=torch.float32).to(dev)
-    c2w = torch.as_tensor(np.asarray(pose)[:3, :4] if not isinstance(pose, torch.Tensor) else pose[:3, :4],
-                          dtype=torch.float32)
-    r = ops.gen_rays(int(H), int(W), K, c2w, 0., 1., False, False, dev)
-    coords = _coords_on(dev, H, W, precrop_frac)
-    if select_inds is None:
-        select_inds = torch.randperm(coords.shape[0], device=dev)[:N_rand]
-    sel = torch.cat([patch_coords(patch_starts, patch_size, dev),
-                     coords[torch.as_tensor(select_inds, device=dev, dtype=torch.long)]], 0)
-    flat = sel[:, 0] * int(W) + sel[:, 1]
-    batch_rays = torch.stack([r[flat, 0:3], r[flat, 3:6]], 0)
-    ex = [torch.as_tensor(e).to(dev)[sel[:, 0], sel[:, 1]] for e in extras]
-    return batch_rays, target[sel[:, 0], sel[:, 1], :3], sel, ex
+    — `extras` are per-pixel maps sampled at the same pixels (depth priors, hard mask, monocular depth).  ONE launch
+    (cnerf_sample_pixels): the patch corners travel as kernel arguments, the random pixels are `select_inds` or drawn in the kernel,
+    rays / colours / maps are produced for the chosen pixels only (round 4: a full-image ray generation, a randperm over the grid
+    and ~15 ATen index / cat / stack kernels per step).  `render_kwargs`: see sample_image_rays."""
+    return _sample(target, pose, H, W, K, N_rand, patch_starts, patch_size, select_inds, precrop_frac, extras, render_kwargs)

@@ -405,6 +405,41 @@ class _RenderLossFn(torch.autograd.Function):
         return (d_raw, d_raw_c) + (None,) * 9
 
 
+class _RenderClossFn(torch.autograd.Function):
+    """raw2outputs of the LAST level with ConsistentNeRF's whole step loss folded in (V:1645-1865; ops.ClossSpec): ONE autograd node
+    from (raw, raw_coarse) to the scalar.  Forward: the last level's compositing launch leaves its masked-loss partial sums (the
+    coarse level's launch left its own, render_rays), cnerf_closs_finish sums both, evaluates the patch term of both levels and
+    assembles the loss; backward: the two compositing-backward launches form their rgb / depth / patch seeds in registers.  Gone from
+    the step: 2 masked-loss + 2 patch-term launches and the ~25 ATen kernels between them (adds, muls, index copies, fills)."""
+
+    @staticmethod
+    def forward(ctx, raw, raw_c, z, z_c, rays, noise, noise_c, white, L, rgb_c, depth_c, ws_c):
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3] or ctx.needs_input_grad[4]:
+            raise ops.CnerfError("render_loss: gradients w.r.t. z_vals / rays are not implemented (only w.r.t. raw)")
+        rgb, disp, acc, weights, depth, ws = ops.composite_forward_closs(raw, z, rays, noise, white, L)
+        want = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        terms, stats, patch_d = ops.closs_finish(L, z.shape[0], ws, ws_c, depth, depth_c, want_grad=want)
+        ctx.save_for_backward(raw, raw_c, z, z_c, rays, rgb, rgb_c, depth, depth_c, stats, patch_d)
+        ctx.noise, ctx.noise_c, ctx.white, ctx.L = noise, noise_c, white, L
+        ctx.mark_non_differentiable(terms, rgb, disp, acc, weights, depth)
+        ctx.set_materialize_grads(False)
+        return terms[0], terms, rgb, disp, acc, weights, depth
+
+    @staticmethod
+    def backward(ctx, g_loss, *_rest):
+        raw, raw_c, z, z_c, rays, rgb, rgb_c, depth, depth_c, stats, patch_d = ctx.saved_tensors
+        d_raw = d_raw_c = None
+        if g_loss is not None:
+            L = ctx.L
+            if ctx.needs_input_grad[0]:
+                d_raw = ops.composite_backward_closs(raw, z, rays, ctx.noise, ctx.white, L, rgb, depth, stats[0:4], g_loss,
+                                                     None if patch_d is None else patch_d[0])
+            if raw_c is not None and ctx.needs_input_grad[1]:
+                d_raw_c = ops.composite_backward_closs(raw_c, z_c, rays, ctx.noise_c, ctx.white, L, rgb_c, depth_c, stats[4:8],
+                                                       g_loss, None if patch_d is None else patch_d[1])
+        return (d_raw, d_raw_c) + (None,) * 10
+
+
 _ONES = {}
 
 
@@ -586,6 +621,10 @@ def _ray_batch(H, W, K, rays, c2w, ndc, near, far, use_viewdirs, c2w_staticcam, 
         else:
             batch = ops.gen_rays(H, W, K, c2w, near_s, far_s, use_viewdirs, ndc, device, coef)
     else:
+        pk = getattr(rays, "_cnerf_packed", None)
+        if pk is not None and pk.matches(H, W, K, near, far, use_viewdirs, ndc, device):
+            # raybank's one-launch sampler already wrote the [B, 8|11] rows this call would assemble (same arithmetic: raygen.hpp)
+            return pk.rows, (pk.rows.shape[0],)
         rays_o, rays_d = rays
         sh = tuple(rays_d.shape[:-1])
         batch = ops.pack_rays(rays_o.to(device), rays_d.to(device), near_s, far_s, use_viewdirs, ndc, coef)
@@ -709,7 +748,7 @@ def _render(H, W, K, chunk, rays, c2w, ndc, near, far, use_viewdirs, c2w_staticc
     batch, sh = _ray_batch(H, W, K, rays, c2w, ndc, near, far, use_viewdirs, c2w_staticcam, device)
     all_ret = batchify_rays(batch, chunk, _with_depth=with_depth, **kwargs)
     for k in all_ret:
-        if all_ret[k].dim() > 0:          # (the scalar of render_loss passes through)
+        if k not in ('loss', 'loss_terms'):          # (the scalars of render_loss pass through)
             all_ret[k] = torch.reshape(all_ret[k], list(sh) + list(all_ret[k].shape[1:]))
     k_extract = ['rgb_map', 'disp_map', 'acc_map'] + (['depth_map'] if with_depth else [])
     ret_list = [all_ret[k] for k in k_extract]
@@ -874,9 +913,17 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
         _prepack_pair(network_fn, network_fine)
     raw = network_query_fn(RayPoints(rays, z_vals), viewdirs, network_fn)
     noise = _density_noise((N_rays, N_samples), raw_noise_std, pytest, dev, _global_rows)
-    loss = loss_c = None
+    loss = loss_c = terms = None
     if _target is None:
         rgb_map, disp_map, acc_map, weights, depth_map = _CompositeFn.apply(raw, z_vals, rays, noise, bool(white_bkgd))
+    elif isinstance(_target, ops.ClossSpec):
+        _target = _target.checked(N_rays)
+        if N_importance > 0:  # coarse level of two: its partial sums ride in its compositing launch; the autograd node comes below
+            rgb_map, disp_map, acc_map, weights, depth_map, ws_c = ops.composite_forward_closs(raw, z_vals, rays, noise,
+                                                                                               bool(white_bkgd), _target)
+        else:
+            loss, terms, rgb_map, disp_map, acc_map, weights, depth_map = _RenderClossFn.apply(
+                raw, None, z_vals, None, rays, noise, None, bool(white_bkgd), _target, None, None, None)
     elif N_importance > 0:    # coarse level of two: its loss term rides in its compositing launch; the autograd node comes below
         rgb_map, disp_map, acc_map, weights, depth_map, loss_c = ops.composite_forward_mse(raw, z_vals, rays, noise, bool(white_bkgd),
                                                                                           _target)
@@ -904,12 +951,17 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
         noise = _density_noise((N_rays, N_samples + N_importance), raw_noise_std, pytest, dev, _global_rows)
         if _target is None:
             rgb_map, disp_map, acc_map, weights, depth_map = _CompositeFn.apply(raw, z_vals, rays, noise, bool(white_bkgd))
+        elif isinstance(_target, ops.ClossSpec):
+            loss, terms, rgb_map, disp_map, acc_map, weights, depth_map = _RenderClossFn.apply(
+                raw, raw_coarse, z_vals, z_coarse, rays, noise, noise_coarse, bool(white_bkgd), _target, rgb_map_0, depth_map_0, ws_c)
         else:
             loss, rgb_map, disp_map, acc_map, weights, depth_map = _RenderLossFn.apply(
                 raw, raw_coarse, z_vals, z_coarse, rays, noise, noise_coarse, bool(white_bkgd), _target, rgb_map_0, loss_c)
     ret = {'rgb_map': rgb_map, 'disp_map': disp_map, 'acc_map': acc_map}
     if loss is not None:
         ret['loss'] = loss
+    if terms is not None:
+        ret['loss_terms'] = terms
     if _with_depth:
         ret['depth_map'] = depth_map
     if retraw:

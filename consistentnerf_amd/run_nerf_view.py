@@ -185,6 +185,72 @@ def midas_patch_loss(depth_pred, mono_dpt_s, patch_num=4, patch_size=16):
     return _PatchDepthLossFn.apply(depth_pred, mono_dpt_s, int(patch_num), int(patch_size) * int(patch_size))
 
 
+# ----------------------------------------------------------------------------- the step's loss as one call
+_TERM_NAMES = ("loss", "img_loss", "depth_loss", "patch_loss", "img_loss0", "depth_loss0", "patch_loss0")
+
+
+def _render_loss_lines(H, W, K, target_s, mask, depth_prior, chunk, rays, coef, far, rgb_w, depth_w, mono, P, ps, patch_w, counts,
+                       kwargs):
+    """The reference's own sequence (V:1645-1865) on render()'s maps: what render_loss computes, launch by launch."""
+    rgb, disp, acc, depth, extras = render(H, W, K, chunk=chunk, rays=rays, **kwargs)
+    tgt = target_s.reshape(-1, 3)
+    with_depth = depth_prior is not None
+    terms = {}
+
+    def level(c, d, suffix):
+        il, dl = hardmask_losses(c, tgt, mask, coef, d if with_depth else None, depth_prior, far, counts)
+        part = rgb_w * il
+        terms["img_loss" + suffix] = il.detach()
+        if mono is not None and P > 0:
+            pl = midas_patch_loss(d, mono, P, ps)
+            part = part + patch_w * pl
+            terms["patch_loss" + suffix] = pl.detach()
+        if with_depth:
+            part = part + depth_w * dl
+            terms["depth_loss" + suffix] = dl.detach()
+        return part
+
+    loss = level(rgb, depth, "")
+    if 'rgb0' in extras:
+        loss = loss + level(extras['rgb0'], extras['depth0'], "0")
+    terms["loss"] = loss.detach()
+    return loss, terms, rgb, disp, acc, depth, extras
+
+
+def render_loss(H, W, K, target_s, mask=None, depth_prior=None, chunk=1024 * 32, rays=None, hardmask_coef=0.2, depth_far=None,
+                rgb_w=1.0, depth_w=1.0, mono=None, patch_num=4, patch_size=16, patch_w=0.001, counts=None, **kwargs):
+    """The loss of one run_nerf_view.train() step as ONE call (V:1636-1865 with the terms this package builds):
+
+        rgb, disp, acc, depth_pred, extras = render(H, W, K, chunk=, rays=batch_rays, retraw=True, **render_kwargs_train)
+        img_loss   = img2mse(rgb[m == 1], target_s[m == 1]) + hardmask_coef * img2mse(rgb[m == 0], target_s[m == 0])   # V:1645-1648
+        loss       = rgb_w * img_loss + patch_w * mono_depth_mses(depth_pred[:P * ps * ps], mono)                   # V:1672-1726
+        loss      += depth_w * img2mse(depth_pred[m == 1] / far, depth_prior[m == 1] / far)                         # V:1737
+        ... and the same three terms of the coarse level (V:1786-1788, V:1855-1857, V:1865)
+
+    with every term folded into the compositing launches (run_nerf._RenderClossFn): one autograd node from both levels' `raw` to
+    the scalar.  mask [B] (0 / 1; None = plain img2mse), depth_prior [B] (None = no depth terms), mono [P * ps * ps] (None = no patch
+    term), depth_far = the `far` the depths are divided by (default: the render's far bound), counts = global (n1, n0) for a batch
+    sharded over ranks.  -> (loss, terms, rgb, disp, acc, depth, extras); terms: dict of detached 0-d tensors (img_loss, depth_loss,
+    patch_loss, img_loss0, ...).  Values equal the lines above (fp64-association round-off on the sums), parameter gradients after
+    loss.backward() bit for bit.  Batches beyond one chunk, more than 8 patches, CPU tensors: the lines above, literally."""
+    far = float(kwargs.get('far', 1.)) if depth_far is None else float(depth_far)
+    n = rays[0].reshape(-1, 3).shape[0] if rays is not None else 0
+    P = int(patch_num) if mono is not None else 0
+    ps2 = int(patch_size) * int(patch_size)
+    tgt = target_s.reshape(-1, 3) if torch.is_tensor(target_s) else None
+    ok = (rays is not None and 0 < n <= chunk and tgt is not None and tgt.is_cuda and tgt.dtype == torch.float32 and tgt.shape[0] == n
+          and kwargs.get('c2w') is None and P <= 8 and P * ps2 <= n and not torch.is_tensor(kwargs.get('near'))
+          and not torch.is_tensor(kwargs.get('far')))
+    if not ok:
+        return _render_loss_lines(H, W, K, target_s, mask, depth_prior, chunk, rays, hardmask_coef, far, rgb_w, depth_w, mono, P,
+                                  patch_size, patch_w, counts, kwargs)
+    spec = ops.ClossSpec(tgt, mask, depth_prior, far, hardmask_coef, rgb_w, depth_w, patch_w, mono, P, ps2, counts)
+    rgb, disp, acc, depth, extras = render(H, W, K, chunk=chunk, rays=rays, _target=spec, **kwargs)
+    loss, t = extras.pop('loss'), extras.pop('loss_terms')
+    terms = {k: t[i] for i, k in enumerate(_TERM_NAMES)}
+    return loss, terms, rgb, disp, acc, depth, extras
+
+
 # ----------------------------------------------------------------------------- in-loop consistency (a15)
 def ss_consistency(rays_o, rays_d, depth_cas_s, pose_ref, K, image_ref, depth_ref, H, W, render_kwargs, chunk=1024 * 32,
                    occlusion_threshold=0.1, with_depth_loss=False):

@@ -22,7 +22,7 @@ extern "C" {
 #endif
 
 #define CNERF_ABI_VERSION 4   /* 4: + cnerf_sample_pixels (one-launch training batch of an image), the ConsistentNeRF losses folded into
-                                * compositing (cnerf_closs, *_closs, cnerf_closs_tail); cnerf_masked_loss uses its workspace for
+                                * compositing (cnerf_closs, *_closs, cnerf_closs_finish); cnerf_masked_loss uses its workspace for
                                 * batches > 16384 rays; every v3 entry point unchanged.   3: + in-kernel uniform streams (cnerf_rng, *_rng) and compositing with img2mse folded in (*_mse);
                                 * every v2 entry point unchanged.   2: cnerf_adam_step takes its hyper-parameters as double; the *_pair, *_cam, *_bf entry points */
 
@@ -219,7 +219,7 @@ int cnerf_composite_bwd_mse(const float* raw, int raw_ch, const float* z, const 
  *       `workspace` (cnerf_closs_ws_floats(B) floats, 8-byte aligned): squared colour error over mask == 1 and over mask == 0,
  *       squared (depth - prior) / far over mask == 1, the two counts.  mask NULL = every ray in the first set; prior NULL = no depth
  *       term.  No tickets, no atomics.
- *   cnerf_closs_tail (ONE workgroup, after the last level's forward): sums the partials of both levels in index order, forms
+ *   cnerf_closs_finish (ONE workgroup, after the last level's forward): sums the partials of both levels in index order, forms
  *       img_loss = s1 / (3 n1) + coef s0 / (3 n0) [second term iff n0 > 0] and depth_loss = sd / n1 with the local counts or the
  *       caller's GLOBAL `counts[2]` (a batch sharded over ranks), evaluates the patch term of both levels (cnerf_patch_depth_loss's
  *       arithmetic; P <= 8 patches of n rays = the first P n rays of the batch) and accumulates in the reference's order:
@@ -230,14 +230,14 @@ int cnerf_composite_bwd_mse(const float* raw, int raw_ch, const float* z, const 
  *   backward, per level:  cnerf_composite_bwd_closs = cnerf_composite_bwd with the seeds formed in registers:
  *       g_rgb = (w_m (rgb - target)) (rgb_w g), g_depth = (w_d (depth / far - prior / far)) (depth_w g) [mask == 1] + patch_d (patch_w g)
  *       [first n_patch_rays rays], g = g_loss[0] (NULL = 1) — the operations of cnerf_masked_loss / cnerf_patch_depth_loss followed by
- *       autograd's `d * g`: bit-identical d_raw.  `stats` = the level's 4 floats of cnerf_closs_tail. */
+ *       autograd's `d * g`: bit-identical d_raw.  `stats` = the level's 4 floats of cnerf_closs_finish. */
 typedef struct cnerf_closs {
   const float* target;   /* [B,3] */
   const float* mask;     /* [B] floats 0 / 1, or NULL */
   const float* prior;    /* [B] depth prior, or NULL (no depth term) */
   float far;             /* depth terms compare depth / far (V:1737) */
 } cnerf_closs;
-typedef struct cnerf_closs_tail {
+typedef struct cnerf_closs_sum {
   const float* ws_last;      /* workspace of the last (fine) level's forward */
   const float* ws_coarse;    /* the coarse level's, or NULL (one level) */
   int64_t B;
@@ -248,12 +248,12 @@ typedef struct cnerf_closs_tail {
   const float* depth_coarse;
   const float* mono;         /* [P n] monocular prior at the patch rays */
   int32_t P, n;
-} cnerf_closs_tail;
+} cnerf_closs_sum;
 int64_t cnerf_closs_ws_floats(int64_t B);
 int cnerf_composite_fwd_closs(const float* raw, int raw_ch, const float* z, const float* rays, int ray_stride, const float* noise,
                               int64_t B, int S, int white_bkgd, const cnerf_closs* L, float* rgb, float* disp, float* acc,
                               float* depth, float* weights, float* workspace, void* stream);
-int cnerf_closs_tail(const cnerf_closs_tail* t, float* terms, float* stats, float* patch_d, void* stream);
+int cnerf_closs_finish(const cnerf_closs_sum* t, float* terms, float* stats, float* patch_d, void* stream);
 int cnerf_composite_bwd_closs(const float* raw, int raw_ch, const float* z, const float* rays, int ray_stride, const float* noise,
                               int64_t B, int S, int white_bkgd, const cnerf_closs* L, const float* rgb, const float* depth,
                               const float* stats, const float* g_loss, float rgb_w, float depth_w, float patch_w,

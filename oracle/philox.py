@@ -33,3 +33,43 @@ def uniform(seed, offset, rows, cols, row0=0):
     off = int(offset) & 0xFFFFFFFFFFFFFFFF
     x0 = philox4x32_10([e & MASK, e >> np.uint64(32), off & 0xFFFFFFFF, off >> 32], [key & 0xFFFFFFFF, key >> 32])[0]
     return ((x0 >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)).astype(np.float32)
+
+
+PIXEL_KEY_XOR = 0x636e6572665f7078     # "cnerf_px": the pixel-draw permutation's key (csrc/sampler.hip)
+
+
+def permutation(seed, offset, n, count):
+    """The first `count` values pi(0), ..., pi(count - 1) of the keyed pseudo-random permutation pi of [0, n) that
+    csrc/sampler.hip::perm_index draws training pixels with (V:1503 `np.random.choice(n, N_rand, replace=False)`: any prefix of a
+    permutation is a draw without replacement).  pi: an alternating Feistel network on bits = max(2, ceil(log2 n)) bits — halves of
+    a = bits // 2 (high) and b = bits - a (low) bits; rounds r = 0, 2, 4, 6: L ^= F(r, R) & mask_a then R ^= F(r + 1, L) & mask_b,
+    F(r, v) = word 0 of Philox4x32-10 on counter (v, r, offset) under key seed ^ PIXEL_KEY_XOR — cycle-walked until the value is < n."""
+    n, count = int(n), int(count)
+    assert 0 <= count <= n < (1 << 31)
+    if n <= 1:
+        return np.zeros(count, dtype=np.int64)
+    bits = 2
+    while (1 << bits) < n:
+        bits += 1
+    a = bits // 2
+    b = bits - a
+    ma, mb = np.uint64((1 << a) - 1), np.uint64((1 << b) - 1)
+    key = (int(seed) ^ PIXEL_KEY_XOR) & 0xFFFFFFFFFFFFFFFF
+    off = int(offset) & 0xFFFFFFFFFFFFFFFF
+    kk = [key & 0xFFFFFFFF, key >> 32]
+
+    def F(r, v):
+        return philox4x32_10([v & MASK, np.full_like(v, r), off & 0xFFFFFFFF, off >> 32], kk)[0].astype(np.uint64)
+
+    x = np.arange(count, dtype=np.uint64)
+    todo = np.ones(count, dtype=bool)
+    while todo.any():
+        v = x[todo]
+        L, R = v >> np.uint64(b), v & mb
+        for r in range(0, 8, 2):
+            L = L ^ (F(r, R) & ma)
+            R = R ^ (F(r + 1, L) & mb)
+        v = (L << np.uint64(b)) | R
+        x[todo] = v
+        todo[todo] = v >= np.uint64(n)
+    return x.astype(np.int64)

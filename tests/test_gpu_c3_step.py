@@ -1,0 +1,288 @@
+"""GPU tests of the round-5 ConsistentNeRF (C3) step work: the training batch of an image as ONE launch
+(cnerf_sample_pixels: raybank.sample_patch_rays / sample_image_rays), the masked rgb + depth losses and the monocular patch term
+folded into the compositing launches (run_nerf_view.render_loss), the multi-workgroup form of cnerf_masked_loss, and the
+teacher-forced C3 step against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+import _inputs as I
+from oracle import nerf_oracle as O
+from oracle import philox as P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def T(a, dev=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return t.to(dev) if dev is not None else t
+
+
+def make_model(D, W, seed, dev):
+    from consistentnerf_amd.run_nerf_helpers import NeRF
+    sd = I.nerf_state_dict(D, W, 10, 4, 5, True, seed)
+    m = NeRF(D=D, W=W, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
+    m.load_state_dict({k: T(v) for k, v in sd.items()}, strict=True)
+    return m.to(dev), sd
+
+
+def _kwargs(coarse, fine, Nc, Nf, perturb, near, far):
+    from consistentnerf_amd.run_nerf import run_network
+    from consistentnerf_amd.run_nerf_helpers import get_embedder
+    e, _ = get_embedder(10, 0)
+    ed, _ = get_embedder(4, 0)
+    q = lambda inputs, viewdirs, fn: run_network(inputs, viewdirs, fn, embed_fn=e, embeddirs_fn=ed)  # noqa: E731
+    return dict(network_query_fn=q, perturb=perturb, N_importance=Nf, network_fine=fine, N_samples=Nc, network_fn=coarse,
+                white_bkgd=False, raw_noise_std=0.0, lindisp=False, use_viewdirs=True, ndc=False, near=near, far=far)
+
+
+# ------------------------------------------------------------------------------------------------ the one-launch sampler
+@pytest.mark.parametrize("H,W,P,ps,n_rand,crop,vd,ndc", [(60, 84, 4, 16, 37, None, True, False), (60, 84, 0, 1, 500, 0.5, False, False),
+                                                       (378, 504, 4, 16, 4096, None, True, False), (33, 47, 2, 8, 100, 0.9, True, True)])
+def test_sample_pixels_equals_the_gather_composition(dev, H, W, P, ps, n_rand, crop, vd, ndc):
+    """cnerf_sample_pixels with the caller's indices vs what round 4 launched for the same batch — cnerf_gen_rays over the whole
+    image, index / cat / stack kernels, cnerf_pack_rays: every output bit for bit (one definition of the ray arithmetic, raygen.hpp)."""
+    from consistentnerf_amd import ops, raybank as RB
+    from consistentnerf_amd.run_nerf_helpers import ndc_coefficients
+    rs = np.random.RandomState(H + n_rand)
+    K = I.intrinsics(H, W, 0.8 * W)
+    pose = I.camera_pose(25.0, -20.0, 3.5)
+    image = T(rs.uniform(size=(H, W, 3)).astype(np.float32), dev)
+    maps = [T(rs.uniform(0.5, 9.0, size=(H, W)).astype(np.float32), dev) for _ in range(3)]
+    grid = RB.crop_coords(H, W, crop)
+    sel = rs.choice(grid.shape[0], size=n_rand, replace=False)
+    starts = np.stack([rs.randint(0, H - ps + 1, P), rs.randint(0, W - ps + 1, P)], -1) if P else None
+    near, far = 1.0 if ndc else 1.2, 12.0
+    kw = dict(near=near, far=far, use_viewdirs=vd, ndc=ndc)
+    od, tgt, coords, ex = RB.sample_patch_rays(image, pose, H, W, K, n_rand, starts, select_inds=sel, precrop_frac=crop, patch_size=ps,
+                                               extras=maps, render_kwargs=kw)
+    want = grid[torch.as_tensor(sel)]
+    if P:
+        want = torch.cat([RB.patch_coords(starts, ps), want], 0)
+    assert torch.equal(coords.cpu(), want)
+    flat = (want[:, 0] * W + want[:, 1]).to(dev)
+    full = ops.gen_rays(H, W, K, pose[:3, :4], 0., 1., False, False, dev)
+    assert torch.equal(od[0], full[flat, 0:3]) and torch.equal(od[1], full[flat, 3:6])
+    assert torch.equal(tgt, image.reshape(-1, 3)[flat])
+    for e, m in zip(ex, maps):
+        assert torch.equal(e, m.reshape(-1)[flat])
+    coef = ndc_coefficients(H, W, K[0][0]) if ndc else (0., 0.)
+    rows = od._cnerf_packed.rows
+    assert torch.equal(rows, ops.pack_rays(od[0], od[1], near, far, vd, ndc, coef))
+    assert torch.equal(rows, ops.gen_rays(H, W, K, pose[:3, :4], near, far, vd, ndc, dev, coef)[flat])
+    # render() takes the rows as they are when it is asked for the bounds they were written for, and packs again otherwise
+    from consistentnerf_amd import run_nerf as R
+    b, sh = R._ray_batch(H, W, K, od, None, ndc, near, far, vd, None, dev)
+    assert b.data_ptr() == rows.data_ptr() and sh == (rows.shape[0],)
+    b2, _ = R._ray_batch(H, W, K, od, None, ndc, near, far + 1.0, vd, None, dev)
+    assert b2.data_ptr() != rows.data_ptr() and torch.equal(b2[:, :6], rows[:, :6]) and float(b2[0, 7]) == far + 1.0
+
+
+def test_device_pixel_draw_is_the_numpy_permutation(dev):
+    """Without `select_inds` the sampling launch draws the pixels itself: element k of the batch is pi(k) for the keyed permutation
+    of the (cropped) grid that oracle/philox.py::permutation restates — bit for bit, named by the torch generator's (seed, offset)
+    like the jitter streams; distinct pixels, uniform over the grid, a fresh draw per call."""
+    from consistentnerf_amd import ops, raybank as RB
+    H, W, N = 378, 504, 4096
+    K = I.intrinsics(H, W, 400.0)
+    pose = I.camera_pose(0.0, -10.0, 4.0)
+    image = torch.rand(H, W, 3, device=dev)
+    gen = torch.cuda.default_generators[0]
+    for crop in (None, 0.5):
+        grid = RB.crop_coords(H, W, crop).numpy()
+        torch.manual_seed(1234)
+        off = gen.get_offset()
+        od, tgt, coords, _ = RB.sample_patch_rays(image, pose, H, W, K, N, None, precrop_frac=crop)
+        assert gen.get_offset() == off + ops.RNG_STRIDE
+        want = grid[P.permutation(1234, off, grid.shape[0], N)]
+        got = coords.cpu().numpy()
+        assert np.array_equal(got, want)
+        assert len({(r, c) for r, c in got.tolist()}) == N
+        od2, _, coords2, _ = RB.sample_patch_rays(image, pose, H, W, K, N, None, precrop_frac=crop)
+        assert not torch.equal(coords2, coords)
+        assert np.array_equal(coords2.cpu().numpy(), grid[P.permutation(1234, off + ops.RNG_STRIDE, grid.shape[0], N)])
+    # uniformity: 100 draws of 4096 of 190 512 pixels, chi-square over 64 equal row bands (63 dof: mean 1, sd 0.18)
+    cnt = np.zeros(64)
+    for _ in range(100):
+        _, _, c, _ = RB.sample_patch_rays(image, pose, H, W, K, N, None)
+        flat = (c[:, 0] * W + c[:, 1]).cpu().numpy()
+        cnt += np.bincount(flat * 64 // (H * W), minlength=64)
+    chi2 = float(((cnt - cnt.mean()) ** 2 / cnt.mean()).sum() / 63)
+    assert 0.4 < chi2 < 1.9, chi2
+    # a whole tiny grid: the draw IS a permutation
+    _, _, c, _ = RB.sample_patch_rays(image[:5, :7].contiguous(), pose, 5, 7, I.intrinsics(5, 7, 6.0), 35, None)
+    assert sorted((c[:, 0] * 7 + c[:, 1]).tolist()) == list(range(35))
+
+
+# ------------------------------------------------------------------------------------------------ the loss folded into compositing
+def _batch(dev, B, seed, far):
+    rs = np.random.RandomState(seed)
+    rays = T(I.ray_batch(B, seed=seed, near=1.2, far=far), dev)
+    target = T(rs.uniform(size=(B, 3)).astype(np.float32), dev)
+    prior = T(rs.uniform(1.2, far, size=(B,)).astype(np.float32), dev)
+    mask = T((rs.uniform(size=(B,)) < 0.55).astype(np.float32), dev)
+    mono = T(rs.uniform(0.05, 1.0, size=(1024,)).astype(np.float32), dev)
+    return rays, target, prior, mask, mono
+
+
+@pytest.mark.parametrize("Nf,with_depth,with_patch,with_mask,owned", [(48, True, True, True, True), (48, True, True, True, False),
+                                                                      (0, True, True, True, True), (48, False, False, True, True),
+                                                                      (48, True, False, False, True), (24, False, True, True, False)])
+def test_render_loss_equals_the_reference_lines(dev, Nf, with_depth, with_patch, with_mask, owned):
+    """run_nerf_view.render_loss (everything in the compositing launches + ONE tail launch) vs the reference's statements on
+    render()'s maps (`_render_loss_lines`: cnerf_masked_loss x 2, cnerf_patch_depth_loss x 2, ATen arithmetic): every term to
+    fp64-association round-off (2e-7), the maps bit for bit, and after backward() every parameter gradient BIT FOR BIT (the seeds
+    are formed by the same fp32 operations in the same order) — FusedAdam-owned (merged backward into the flat gradient) or plain."""
+    from consistentnerf_amd import run_nerf_view as V
+    from consistentnerf_amd.optim import FusedAdam
+    B, far = 1500, 12.0
+    rays, target, prior, mask, mono = _batch(dev, B, 31, far)
+    H = W = 64
+    K = I.intrinsics(H, W, 50.0)
+    res = []
+    for fused in (True, False):
+        coarse, _ = make_model(4, 128, 93, dev)
+        fine = make_model(4, 128, 94, dev)[0] if Nf else None
+        params = list(coarse.parameters()) + (list(fine.parameters()) if fine is not None else [])
+        opt = FusedAdam(params, lr=5e-4) if owned else None
+        kw = _kwargs(coarse, fine, 32, Nf, 1.0, 1.2, far)
+        args = dict(mask=mask if with_mask else None, depth_prior=prior if with_depth else None, chunk=4096,
+                    rays=(rays[:, 0:3], rays[:, 3:6]), hardmask_coef=0.2, rgb_w=1.0, depth_w=0.1,
+                    mono=mono if with_patch else None, patch_num=4, patch_size=16, patch_w=0.001)
+        torch.manual_seed(7)
+        if fused:
+            out = V.render_loss(H, W, K, target, **args, **kw)
+        else:
+            a = dict(args)
+            out = V._render_loss_lines(H, W, K, target, a["mask"], a["depth_prior"], 4096, a["rays"], 0.2, far, 1.0, 0.1, a["mono"],
+                                       4 if with_patch else 0, 16, 0.001, None, kw)
+        loss, terms = out[0], out[1]
+        if opt is not None:
+            opt.zero_grad()
+        loss.backward()
+        grads = opt.flat_grad.clone() if opt is not None else torch.cat([p.grad.reshape(-1) for p in params])
+        res.append((loss.detach(), {k: v.item() for k, v in terms.items()}, out[2], out[5], out[6], grads))
+    (lf, tf, rgbf, depf, exf, gf), (lr, tr, rgbr, depr, exr, gr) = res
+    assert torch.equal(rgbf, rgbr) and torch.equal(depf, depr)
+    if Nf:
+        assert torch.equal(exf["rgb0"], exr["rgb0"]) and torch.equal(exf["depth0"], exr["depth0"])
+    for k, v in tr.items():
+        assert abs(tf[k] - v) <= 2e-7 * abs(v) + 1e-12, (k, tf[k], v)
+    assert abs(lf.item() - lr.item()) <= 3e-7 * abs(lr.item())
+    assert float(gr.abs().max()) > 0 and torch.equal(gf, gr)
+
+
+def test_render_loss_terms_vs_the_oracle(dev):
+    """The terms render_loss reports against the CPU oracle's masked losses / patch term evaluated on the maps the call returns
+    (O.masked_rgb_loss, O.masked_depth_loss, O.patch_depth_loss: the restatement tests/test_oracle_golden.py pins on the reference's
+    own outputs), assembled in the reference's order — 2e-6; under GLOBAL counts two half-batches add up to the whole."""
+    from consistentnerf_amd import distributed as D, run_nerf_view as V
+    B, far = 2048, 12.0
+    rays, target, prior, mask, mono = _batch(dev, B, 5, far)
+    coarse, _ = make_model(4, 128, 93, dev)
+    fine, _ = make_model(4, 128, 94, dev)
+    kw = _kwargs(coarse, fine, 32, 48, 0.0, 1.2, far)
+    H = W = 64
+    K = I.intrinsics(H, W, 50.0)
+    with torch.no_grad():
+        loss, terms, rgb, disp, acc, depth, extras = V.render_loss(H, W, K, target, mask=mask, depth_prior=prior, chunk=4096,
+                                                                   rays=(rays[:, 0:3], rays[:, 3:6]), depth_w=0.1, mono=mono, **kw)
+    c = lambda t: t.detach().cpu()  # noqa: E731
+    want = 0.0
+    for sfx, (col, dep) in (("", (rgb, depth)), ("0", (extras["rgb0"], extras["depth0"]))):
+        il = O.masked_rgb_loss(c(col), c(target), c(mask), 0.2)
+        dl = O.masked_depth_loss(c(dep), c(prior), c(mask), far)
+        pl = O.patch_depth_loss(c(dep), c(mono), 4, 256)
+        for k, v in (("img_loss", il), ("depth_loss", dl), ("patch_loss", pl)):
+            assert abs(terms[k + sfx].item() - float(v)) <= 2e-6 * abs(float(v)), (k + sfx, terms[k + sfx].item(), float(v))
+        want = want + 1.0 * il
+        want = want + 0.001 * pl
+        want = want + 0.1 * dl
+    assert abs(loss.item() - float(want)) <= 2e-6 * float(want)
+    counts = D.global_mask_counts(mask)
+    halves = 0.0
+    with torch.no_grad():
+        for sl, patch in ((slice(0, B // 2), True), (slice(B // 2, B), False)):
+            l_h = V.render_loss(H, W, K, target[sl], mask=mask[sl], depth_prior=prior[sl], chunk=4096,
+                                rays=(rays[sl, 0:3], rays[sl, 3:6]), depth_w=0.1, mono=mono if patch else None, counts=counts, **kw)[0]
+            halves += l_h.item()
+    assert abs(halves - loss.item()) <= 2e-6 * loss.item()
+
+
+def test_masked_loss_multi_workgroup_form(dev):
+    """cnerf_masked_loss beyond 16384 rays (one workgroup per 16384 + a fixed-order second stage) vs the single-workgroup kernel:
+    losses to fp64-association round-off, gradient seeds bit for bit; deterministic across launches; global counts honoured."""
+    from consistentnerf_amd import _lib, ops
+    import ctypes as C
+    B, far = 100_003, 7.0
+    g = torch.Generator(device=dev).manual_seed(3)
+    rgb, tgt = torch.rand(B, 3, device=dev, generator=g), torch.rand(B, 3, device=dev, generator=g)
+    depth, prior = torch.rand(B, device=dev, generator=g) * far, torch.rand(B, device=dev, generator=g) * far
+    mask = (torch.rand(B, device=dev, generator=g) < 0.6).float()
+    lib = _lib.load()
+    ws = torch.empty(lib.cnerf_loss_ws_floats() // 2, device=dev, dtype=torch.float64)
+    p = lambda t: C.c_void_p(0 if t is None else t.data_ptr())  # noqa: E731
+    for counts in (None, torch.tensor([70000.0, 50000.0], device=dev)):
+        outs = []
+        for w in (None, ws, ws):
+            loss, d_rgb, d_dep = torch.empty(2, device=dev), torch.empty_like(rgb), torch.empty(B, device=dev)
+            _lib.check(lib.cnerf_masked_loss(p(rgb), p(tgt), p(depth), p(prior), p(mask), B, far, 0.2, p(counts), 1.0, p(loss),
+                                             p(d_rgb), p(d_dep), p(w), None), "cnerf_masked_loss")
+            outs.append((loss, d_rgb, d_dep))
+        (l1, r1, d1), (l2, r2, d2), (l3, r3, d3) = outs
+        assert torch.equal(l2, l3) and torch.equal(r2, r3) and torch.equal(d2, d3)
+        assert torch.equal(r1, r2) and torch.equal(d1, d2)
+        assert float(((l1 - l2).abs() / l1.abs()).max()) <= 2e-7
+    # the Python surface picks the workspace form by itself
+    loss, d_rgb, _ = ops.masked_loss(rgb, tgt, depth, prior, mask, far, 0.2)
+    assert torch.equal(d_rgb, r2)
+
+
+# ------------------------------------------------------------------------------------------------ the step
+def test_c3_step_launches_and_graph(dev):
+    """The C3 step through the one-call surface (sample_patch_rays -> render_loss -> backward -> FusedAdam with clip 0.1): the same
+    loss and weights as the step written out with the separate entry points on the same batch, step after step."""
+    from consistentnerf_amd import raybank as RB, run_nerf as R, run_nerf_view as V
+    from consistentnerf_amd.optim import FusedAdam
+    H, W, far = 96, 128, 12.0
+    K = I.intrinsics(H, W, 100.0)
+    pose = I.camera_pose(10.0, -12.0, 4.0)
+    depth_img, image = I.analytic_scene(H, W, K, pose)
+    rs = np.random.RandomState(4)
+    img_t, dep_t = T(image, dev), T(depth_img.astype(np.float32), dev)
+    msk_t = T((rs.uniform(size=(H, W)) < 0.7).astype(np.float32), dev)
+    mono_t = T((1.0 / np.maximum(depth_img, 1e-3)).astype(np.float32), dev)
+    runs = []
+    for fused in (True, False):
+        coarse, _ = make_model(4, 128, 11, dev)
+        fine, _ = make_model(4, 128, 12, dev)
+        opt = FusedAdam(list(coarse.parameters()) + list(fine.parameters()), lr=5e-4, clip_value=0.1)
+        kw = _kwargs(coarse, fine, 32, 48, 1.0, 1.2, far)
+        torch.manual_seed(99)
+        np.random.seed(99)
+        losses = []
+        for i in range(4):
+            starts = RB.draw_patch_starts(H, W, 4, 16)
+            rays, target, sel, (d_prior, m, mono_s) = RB.sample_patch_rays(img_t, pose, H, W, K, 512, starts,
+                                                                           extras=(dep_t, msk_t, mono_t), render_kwargs=kw)
+            opt.zero_grad()
+            if fused:
+                loss = V.render_loss(H, W, K, target, mask=m, depth_prior=d_prior, chunk=8192, rays=rays, depth_w=0.1,
+                                     mono=mono_s, retraw=True, **kw)[0]
+                R.backward(loss)
+            else:
+                loss = V._render_loss_lines(H, W, K, target, m, d_prior, 8192, rays, 0.2, far, 1.0, 0.1, mono_s, 4, 16, 0.001, None,
+                                            dict(kw, retraw=True))[0]
+                loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        runs.append((losses, opt.flat_param.clone()))
+    (lf, wf), (lr, wr) = runs
+    assert np.allclose(lf, lr, rtol=3e-7, atol=0) and np.isfinite(lf).all()
+    assert torch.equal(wf, wr)

@@ -4,7 +4,7 @@ The PSNR-parity clause of the north star cannot be closed by comparing two free-
 decorrelate at the rate round-off is amplified (profiles/r03_psnr_*).  What CAN be asserted is the map one training step
 applies — (weights, Adam moments, batch, random streams) -> (loss, gradient, new weights) — at points ALONG a real trajectory:
 the HIP path trains the synthetic DTU-like scene at the true C2 shapes (scripts/psnr_parity.py::scene: 512x640 views, 4096-ray
-batches, 64 + 128 samples, D=8/W=256, the reference's pytest=True RNG hook), and at steps {0, 2, 17, 50, 100, 150} the state is
+batches, 64 + 128 samples, D=8/W=256, the reference's pytest=True RNG hook), and at steps {0, 2, 17, 50, 100, 150, 1000} the state is
 snapshotted and ONE oracle step is run on the CPU from exactly that state (O.query -> O.composite on both levels -> mse + mse ->
 autograd -> O.adam_step; reference: run_nerf.py:764-789, run_nerf.py:281, run_nerf_helpers.py:9-10).
 
@@ -32,7 +32,7 @@ Stated bounds:
                              A_max / max|g| (1 ... 30 here), the plain |d| / max|g| figure and the same two figures for the
                              reference's own fp32 arithmetic (g_ref32 - g_exact) are reported per tensor.
                              d loss / d raw (the compositing + loss backward alone) is compared the same way.
-  ReLU pattern differences   only where the oracle's own |z| < 1e-5, fewer than 1e-6 of all units
+  ReLU pattern differences   only where the oracle's own |z| < 1e-5, fewer than 1e-5 of all units (measured: 2.4e-6 at step 0)
   sigma-branch substitutions only where the kernel's |sigma| < 1e-5 (relu(sigma) of R:284 at every sample: a kink; at the LAST
                              sample a jump — reported separately as tail substitutions)
   Adam on the SAME gradient  new weights |d| <= 2e-7 (+ 2 ulp), moments 1e-6 relative to their max
@@ -56,7 +56,7 @@ from oracle import nerf_oracle as O
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SNAPSHOTS = (0, 2, 17, 50, 100, 150)
+SNAPSHOTS = (0, 2, 17, 50, 100, 150, 1000)     # round 5: + one late snapshot
 
 
 @pytest.fixture(scope="module")
@@ -93,7 +93,7 @@ def _adam_first_order_bound(dg, g, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8):
 EPS32 = 2.0 ** -24      # unit round-off of fp32
 
 
-def _oracle_step(dtype, w0, names, rays, tgt, z_c, z_f, masks_c, masks_f, raw_k, ncfg, want_abs=False, device=None):
+def _oracle_step(dtype, w0, names, rays, tgt, z_c, z_f, masks_c, masks_f, raw_k, ncfg, want_abs=False, device=None, loss_fn=None):
     """`device`: where the oracle's torch ops are evaluated.  None = the CPU (the reference arithmetic: what g_ref32 must be).  The
     float64 evaluation — whose only role is to be EXACT — may run the same oracle code on the GPU through stock ATen float64 kernels
     (30 s -> 2 s per snapshot); results come back on the CPU."""
@@ -101,17 +101,18 @@ def _oracle_step(dtype, w0, names, rays, tgt, z_c, z_f, masks_c, masks_f, raw_k,
         mv = lambda t: t.to(device)   # noqa: E731
         with torch.device(device):
             out = _oracle_step(dtype, [{k: mv(v) for k, v in d.items()} for d in w0], names, mv(rays), mv(tgt), mv(z_c), mv(z_f),
-                               [mv(m) for m in masks_c], [mv(m) for m in masks_f], tuple(mv(r) for r in raw_k), ncfg, want_abs)
+                               [mv(m) for m in masks_c], [mv(m) for m in masks_f], tuple(mv(r) for r in raw_k), ncfg, want_abs,
+                               loss_fn=None if loss_fn is None else loss_fn.to(device))
         torch.cuda.synchronize()
         res = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in out.items()}
         res["d_raw"] = {k: v.cpu() for k, v in out["d_raw"].items()}
         del out
         torch.cuda.empty_cache()
         return res
-    return _oracle_step_impl(dtype, w0, names, rays, tgt, z_c, z_f, masks_c, masks_f, raw_k, ncfg, want_abs)
+    return _oracle_step_impl(dtype, w0, names, rays, tgt, z_c, z_f, masks_c, masks_f, raw_k, ncfg, want_abs, loss_fn)
 
 
-def _oracle_step_impl(dtype, w0, names, rays, tgt, z_c, z_f, masks_c, masks_f, raw_k, ncfg, want_abs=False):
+def _oracle_step_impl(dtype, w0, names, rays, tgt, z_c, z_f, masks_c, masks_f, raw_k, ncfg, want_abs=False, loss_fn=None):
     """The oracle's training step on the KERNEL'S BRANCH (module docstring) in `dtype`: O.query -> O.composite on both levels ->
     mse + mse -> autograd.  raw_k = the kernel's (coarse, fine) raw outputs (fp32, CPU) for the tail-branch substitution.
     -> dict(loss, grad flat [dtype], flips, tail, A) with A = sum over samples of |dZ| |h| per gradient element (float64 runs)."""
@@ -144,7 +145,8 @@ def _oracle_step_impl(dtype, w0, names, rays, tgt, z_c, z_f, masks_c, masks_f, r
             # (value = the kernel's, derivative d/d sigma = 1 into the oracle's own graph: the sample keeps feeding the MLP backward)
             raw = torch.cat([raw[..., :3], torch.where(sub, so + (sk - so).detach(), so)[..., None]], -1)
             raw.register_hook(lambda g, k=k: d_raw.__setitem__(k, g.detach()))
-            loss = loss + O.mse(O.composite(raw, zz, d_)[0], tg)
+            comp = O.composite(raw, zz, d_)
+            loss = loss + (O.mse(comp[0], tg) if loss_fn is None else loss_fn(k, comp, tg, dtype))
         plist = [osd[k][n] for k in (0, 1) for n in names[k]]
         grads = torch.autograd.grad(loss, plist, allow_unused=True)
     finally:
@@ -341,3 +343,174 @@ def test_c2_teacher_forced_training_steps(dev, monkeypatch):
         assert row["adam_same_grad_dm_rel"] <= 1e-6 and row["adam_same_grad_dv_rel"] <= 1e-6, s_ + "Adam moments"
         assert row["dw_beyond_conditioning_bound"] == 0 and row["dw_frac_beyond_2e-6"] <= 1e-3, s_ + "updated weights"
     assert regime_rays > 0, "no snapshot had rays with |sigma_last| < 1e-2 (the R:281 regime the divergence probe blames)"
+
+
+# ------------------------------------------------------------------------------------------------ the ConsistentNeRF step
+class _C3Loss:
+    """The loss of one level of the ConsistentNeRF step in the ORACLE's functions (V:1645-1648 masked rgb, V:1678-1726 patch term,
+    V:1737 masked depth; accumulated in the reference's order): what run_nerf_view.render_loss folds into the compositing launches."""
+
+    def __init__(self, mask, prior, mono, far, coef=0.2, rgb_w=1.0, depth_w=0.1, patch_w=0.001):
+        self.mask, self.prior, self.mono, self.far = mask, prior, mono, far
+        self.coef, self.rgb_w, self.depth_w, self.patch_w = coef, rgb_w, depth_w, patch_w
+
+    def to(self, device):
+        return _C3Loss(self.mask.to(device), self.prior.to(device), self.mono.to(device), self.far, self.coef, self.rgb_w,
+                       self.depth_w, self.patch_w)
+
+    def __call__(self, k, comp, tg, dtype):
+        rgb, depth = comp[0], comp[4]
+        level = self.rgb_w * O.masked_rgb_loss(rgb, tg, self.mask, self.coef)
+        level = level + self.patch_w * O.patch_depth_loss(depth, self.mono.to(dtype), 4, 256)
+        return level + self.depth_w * O.masked_depth_loss(depth, self.prior.to(dtype), self.mask, self.far)
+
+
+C3_SNAPSHOTS = (0, 50)
+
+
+def test_c3_teacher_forced_step(dev, monkeypatch):
+    """the chaos-free step parity of the C2 test above for ConsistentNeRF's OWN step.  The HIP path trains the
+    C3 rig of bench.py (three 378x504 views, hard masks from the cross-view warp, 4096 random + 1024 patch rays per step, 64 + 128
+    samples, D=8/W=256, pytest streams) through the product surface — raybank.sample_patch_rays (one launch), run_nerf_view.render_loss
+    (masked rgb + depth on both levels + the monocular patch term folded into compositing), run_nerf.backward, FusedAdam with the
+    value clip 0.1 (V:1983) — and at steps {0, 50} ONE oracle step is run from the snapshotted state on the kernel's branch (its
+    depths, ReLU sign bits, sigma signs), in float64 (exact) and in fp32 on the CPU (the reference arithmetic): O.query -> O.composite
+    -> O.masked_rgb_loss / O.masked_depth_loss / O.patch_depth_loss -> autograd -> O.adam_step(clip=0.1).
+
+    Same bounds as the C2 test: loss 1e-6 relative; every gradient tensor within 1e-5 * A_max of the exact one (A = the absolute mass
+    of the element's sum; the reference's own fp32 figure reported beside it); d loss / d raw — here carrying the depth-loss and the
+    patch-term gradients into `raw` (g_depth of V:1737 at 5120 rays had no oracle comparison before) — 2e-5 rel-L2; pattern
+    differences only at the discontinuities; the Adam kernel with the clip on the same gradient 2e-7; the set of clipped elements
+    identical up to elements within 1e-5 * A of the clip value."""
+    sys.path.insert(0, ROOT)
+    import json
+    import bench
+    from consistentnerf_amd import ops, raybank as RB, run_nerf as R, run_nerf_view as V
+    sc = bench.c3_scene(dev)
+    H, W, K, far, kw, opt = sc["H"], sc["W"], sc["K"], sc["far"], sc["kw"], sc["opt"]
+    nets = [kw["network_fn"], kw["network_fine"]]
+    names = [[n for n, _ in m.named_parameters()] for m in nets]
+    sizes = [[p.numel() for _, p in m.named_parameters()] for m in nets]
+    seen = {}
+    orig_pair = ops.mlp_backward_pair
+
+    def spy(*a, **k):
+        seen["args"] = a
+        return orig_pair(*a, **k)
+    monkeypatch.setattr(ops, "mlp_backward_pair", spy)
+    ncfg = O.NetCfg(8, 256, output_ch=5)
+    torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
+    torch.manual_seed(5)
+    np.random.seed(5)
+    report = []
+    for i in range(max(C3_SNAPSHOTS) + 1):
+        v = i % 3
+        snap = i in C3_SNAPSHOTS
+        starts = RB.draw_patch_starts(H, W, 4, 16)
+        rays, target, sel, (d_prior, m, mono_s) = RB.sample_patch_rays(
+            sc["img_t"][v], sc["poses"][v], H, W, K, 4096, starts, extras=(sc["dep_t"][v], sc["msk_t"][v], sc["mono_t"][v]),
+            render_kwargs=kw)
+        if snap:
+            torch.cuda.synchronize()
+            w0 = [{k: t.detach().cpu().clone() for k, t in mdl.state_dict().items()} for mdl in nets]
+            m0, v0, p0 = opt.exp_avg.cpu().clone(), opt.exp_avg_sq.cpu().clone(), opt.flat_param.cpu().clone()
+            lr_i, step_i = opt.param_groups[0]["lr"], opt._step + 1
+        loss, terms, rgb, disp, acc, depth, extras = V.render_loss(
+            H, W, K, target, mask=m, depth_prior=d_prior, chunk=32768, rays=rays, hardmask_coef=0.2, depth_w=0.1, mono=mono_s,
+            patch_num=4, patch_size=16, patch_w=0.001, retraw=True, pytest=True, _debug=snap, **kw)
+        opt.zero_grad()
+        seen.pop("args", None)
+        R.backward(loss)
+        if snap:
+            assert "args" in seen, "the step did not take the merged coarse+fine backward"
+            fs, fp, fg, fB, fS, fst, fgr, cs, cp, cg, cB, cS, cst, cgr = seen.pop("args")
+            g_hip = opt.flat_grad.cpu().clone()
+            masks_f, masks_c = _masks_from_stash(fst, fB * fS), _masks_from_stash(cst, cB * cS)
+            d_raw_hip = (cg.detach().cpu().reshape(cB, cS, -1), fg.detach().cpu().reshape(fB, fS, -1))
+            del fst, cst, fg, cg
+            z_f, z_c = extras["_z_vals"].cpu(), extras["_z_coarse"].cpu()
+            raw_k = (extras["_raw_coarse"].detach().cpu(), extras["raw"].detach().cpu())
+            rows_c = rays._cnerf_packed.rows.cpu()
+        opt.step()
+        for g_ in opt.param_groups:
+            g_["lr"] = 5e-4 * (0.1 ** (i / 250000))
+        if not snap:
+            continue
+        torch.cuda.synchronize()
+        loss_hip, p1_hip = float(loss), opt.flat_param.cpu().clone()
+        lf = _C3Loss(m.cpu(), d_prior.cpu(), mono_s.cpu(), far)
+        common = (w0, names, rows_c, target.cpu(), z_c, z_f, masks_c, masks_f, raw_k, ncfg)
+        ex = _oracle_step(torch.float64, *common, want_abs=True, device=dev, loss_fn=lf)
+        r32 = _oracle_step(torch.float32, *common, loss_fn=lf)
+        del masks_c, masks_f
+        row = {"step": i, "loss_hip": loss_hip, "loss_oracle_f32": r32["loss"], "loss_oracle_f64": ex["loss"],
+               "loss_rel_f32": abs(loss_hip - r32["loss"]) / abs(r32["loss"]), "loss_rel_f64": abs(loss_hip - ex["loss"]) / abs(ex["loss"]),
+               "terms_hip": {k: float(t) for k, t in terms.items()}}
+        for tag, res in (("f64", ex), ("f32", r32)):
+            row[f"relu_flips_{tag}"] = int(sum(n for n, _ in res["flips"]))
+            row[f"relu_flip_max_abs_z_{tag}"] = max(z for _, z in res["flips"])
+            row[f"sigma_sign_substitutions_{tag}"] = int(sum(t[1] for t in res["tail"]))
+            row[f"tail_substitution_max_abs_sigma_{tag}"] = max(t[2] for t in res["tail"])
+        row["relu_flip_frac"] = max(row["relu_flips_f64"], row["relu_flips_f32"]) / (5120 * 256 * (8 * 256 + 128))
+        for k, tag in ((0, "coarse"), (1, "fine")):
+            e_, h_, r_ = ex["d_raw"][k], d_raw_hip[k].double(), r32["d_raw"][k].double()
+            row[f"d_raw_{tag}_hip_vs_exact_rel_l2"] = float((h_ - e_).norm() / e_.norm())
+            row[f"d_raw_{tag}_ref32_vs_exact_rel_l2"] = float((r_ - e_).norm() / e_.norm())
+        g_ex, g_32, A = ex["grad"], r32["grad"], ex["A"]
+        off, bad, dg_flat = 0, [], torch.zeros_like(g_hip)
+        row["K_hip_worst"] = row["K_ref32_worst"] = row["grad_hip_vs_exact_rel_max_worst"] = row["grad_ref32_vs_exact_rel_max_worst"] = 0.0
+        for k in (0, 1):
+            for nme, n in zip(names[k], sizes[k]):
+                a, b, e, aa = g_hip[off:off + n].double(), g_32[off:off + n].double(), g_ex[off:off + n], A[off:off + n]
+                dg_flat[off:off + n] = float((a - b).abs().max())
+                off += n
+                scale = float(e.abs().max())
+                if scale == 0:
+                    assert float(a.abs().max()) == 0 and float(b.abs().max()) == 0
+                    continue
+                amax = float(aa.max())
+                d_ex, r_ex = float((a - e).abs().max()), float((b - e).abs().max())
+                row["K_hip_worst"] = max(row["K_hip_worst"], d_ex / amax)
+                row["K_ref32_worst"] = max(row["K_ref32_worst"], r_ex / amax)
+                row["grad_hip_vs_exact_rel_max_worst"] = max(row["grad_hip_vs_exact_rel_max_worst"], d_ex / scale)
+                row["grad_ref32_vs_exact_rel_max_worst"] = max(row["grad_ref32_vs_exact_rel_max_worst"], r_ex / scale)
+                if d_ex > 1e-5 * amax:
+                    bad.append((("coarse." if k == 0 else "fine.") + nme, d_ex / amax, d_ex / scale))
+        assert off == g_hip.numel()
+        row["grad_bad"] = bad
+        # the value clip (V:1983): which elements it touches, kernel vs exact gradient
+        clipped_hip, clipped_ex = g_hip.abs() > 0.1, g_ex.abs() > 0.1
+        diff = clipped_hip != clipped_ex
+        row["clipped_elements_hip"], row["clipped_elements_exact"] = int(clipped_hip.sum()), int(clipped_ex.sum())
+        row["clip_set_differences"] = int(diff.sum())
+        row["clip_set_difference_max_distance"] = float((g_ex[diff].abs() - 0.1).abs().max()) if bool(diff.any()) else 0.0
+        p_same, m_same, v_same = p0.clone(), m0.clone(), v0.clone()
+        O.adam_step(p_same, g_hip, m_same, v_same, step_i, lr_i, clip=0.1)
+        row["adam_same_grad_dw"] = float((p_same - p1_hip).abs().max())
+        p_or, m_or, v_or = p0.clone(), m0.clone(), v0.clone()
+        O.adam_step(p_or, g_32, m_or, v_or, step_i, lr_i, clip=0.1)
+        dw = (p_or - p1_hip).abs()
+        bound = 2e-6 + 2.0 * _adam_first_order_bound(dg_flat, g_32.clamp(-0.1, 0.1), m0, v0, step_i, lr_i)
+        row["dw_max"], row["dw_frac_beyond_2e-6"] = float(dw.max()), float((dw > 2e-6).float().mean())
+        row["dw_beyond_conditioning_bound"] = int((dw > bound).sum())
+        report.append(row)
+        print("  " + " ".join(f"{k}={t:.3e}" if isinstance(t, float) else f"{k}={t}" for k, t in row.items() if k != "grad_bad"), flush=True)
+        del ex, r32
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "teacher_forced_c3.json"), "w") as f:
+        json.dump({"what": "tests/test_gpu_training_parity.py::test_c3_teacher_forced_step", "snapshots": list(C3_SNAPSHOTS),
+                   "rows": report}, f, indent=1)
+    for row in report:
+        s_ = f"step {row['step']}: "
+        assert row["loss_rel_f32"] <= 1e-6 and row["loss_rel_f64"] <= 1e-6, s_ + "loss on the kernel's branch"
+        for tag, zb in (("f64", 1e-4), ("f32", 1e-5)):
+            assert row[f"relu_flip_max_abs_z_{tag}"] < zb, s_ + "ReLU pattern differs away from zero"
+            assert row[f"tail_substitution_max_abs_sigma_{tag}"] < 1e-5, s_ + "sigma branch differs away from zero"
+        assert row["relu_flip_frac"] < 1e-5, s_ + "too many ReLU pattern differences"
+        assert not row["grad_bad"], s_ + f"gradient [tensor, |d| / A_max, |d| / max|g|]: {row['grad_bad']}"
+        for lv in ("coarse", "fine"):
+            assert row[f"d_raw_{lv}_hip_vs_exact_rel_l2"] <= 2e-5, s_ + f"d loss / d raw ({lv})"
+        assert row["clip_set_differences"] <= 4 and row["clip_set_difference_max_distance"] <= 1e-5, s_ + "clipped element set"
+        assert row["adam_same_grad_dw"] <= 2e-7 + 2 * 6e-8 * 4.0, s_ + "Adam kernel (clip 0.1) on the same gradient"
+        assert row["dw_beyond_conditioning_bound"] == 0 and row["dw_frac_beyond_2e-6"] <= 1e-3, s_ + "updated weights"

@@ -30,7 +30,7 @@ def test_header_symbols_all_exported(lib):
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r" T (cnerf_[a-z0-9_]+)", out))
     assert declared <= exported, declared - exported
-    assert lib.cnerf_abi_version() == 3
+    assert lib.cnerf_abi_version() == 4
     assert lib.cnerf_strerror(-2).decode().startswith("configuration")
 
 
@@ -387,6 +387,24 @@ def test_ticket_is_taken_after_the_partial_store_completed(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     # one publish site per compiled sample-count variant of the loss form (C = 1, 2, 3, 4, 8, 16)
     assert isa_ticket_check.check(str(tmp_path / "composite.s"), need_sites=6) == []
+
+
+def test_pixel_permutation_oracle_is_a_permutation():
+    """oracle/philox.py::permutation (the numpy restatement of csrc/sampler.hip's pixel draw; the GPU suite compares the kernel
+    with it bit for bit): a bijection of [0, n) for every n incl. non-powers of two and the degenerate sizes, a function of
+    (seed, offset) only, prefixes of one permutation, and uniform to a chi-square test."""
+    from oracle import philox as P
+    for n in (1, 2, 3, 4, 5, 16, 17, 255, 1000, 4097):
+        p = P.permutation(11, 8, n, n)
+        assert p.dtype == np.int64 and sorted(p.tolist()) == list(range(n)), n
+    a, b = P.permutation(5, 12, 190512, 4096), P.permutation(5, 12, 190512, 512)
+    assert np.array_equal(a[:512], b) and len(set(a.tolist())) == 4096 and a.max() < 190512
+    assert not np.array_equal(a, P.permutation(5, 16, 190512, 4096)) and not np.array_equal(a, P.permutation(6, 12, 190512, 4096))
+    cnt = np.zeros(32)
+    for off in range(0, 160, 4):
+        cnt += np.bincount(P.permutation(3, off, 190512, 4096) * 32 // 190512, minlength=32)
+    chi2 = float(((cnt - cnt.mean()) ** 2 / cnt.mean()).sum() / 31)
+    assert 0.3 < chi2 < 2.2, chi2
 
 
 def test_engine_query_probe_selects_the_plain_route_without_the_private_symbol(monkeypatch):
