@@ -252,6 +252,16 @@ def render_loss(H, W, K, target_s, mask=None, depth_prior=None, chunk=1024 * 32,
 
 
 # ----------------------------------------------------------------------------- in-loop consistency (a15)
+_LADDERS = {}
+
+
+def _threshold_ladder(thr0, dev):
+    key = (thr0, str(dev))
+    if key not in _LADDERS:
+        _LADDERS[key] = (torch.full((64,), thr0, dtype=torch.float32) * torch.pow(2.0, torch.arange(64, dtype=torch.float32))).to(dev)
+    return _LADDERS[key]
+
+
 def ss_consistency(rays_o, rays_d, depth_cas_s, pose_ref, K, image_ref, depth_ref, H, W, render_kwargs, chunk=1024 * 32,
                    occlusion_threshold=0.1, with_depth_loss=False):
     """The `args.ss_loss` block of run_nerf_view_test.train() (VT:905-938): the batch's depth-prior points
@@ -281,22 +291,19 @@ def ss_consistency(rays_o, rays_d, depth_cas_s, pose_ref, K, image_ref, depth_re
         raise ops.CnerfError("ss_consistency: no point of the batch projects into the reference view "
                              "(the reference loops forever here)")
     adiff = (pts_c_ref[..., -1].reshape(-1, 1) - rays_depth_ref.reshape(-1)[:, None]).abs()
-    mn = adiff.min()
-    thr = torch.full((), float(occlusion_threshold), device=dev)
-    for _ in range(64):                                    # thr * 2^k, first k with some |diff| below it; no host sync
-        thr = torch.where(mn < thr, thr, thr * 2)
+    # thr = occlusion_threshold * 2^k for the smallest k >= 0 that lets some |diff| pass (VT:921-925) — on the device, without the
+    # reference's host sync per doubling and without a launch per doubling either: the 64 candidate thresholds (exact in fp32:
+    # powers of two times the base) are a cached constant, k = the number of candidates <= min |diff|
+    cand = _threshold_ladder(float(occlusion_threshold), dev)
+    thr = cand[(adiff.min() >= cand).sum().clamp_(max=cand.numel() - 1)]
     mask = adiff < thr
     batch_rays_ref = torch.stack([rays_o_ref, rays_d_ref], 0)
-    rgb_ref, disp_ref, acc_ref, depth_pred_ref, extras_ref = render(H, W, K, chunk=chunk, rays=batch_rays_ref, retraw=True,
-                                                                    **render_kwargs)
-    tgt = rgb_target_ref.squeeze(0).permute(1, 0)
-    loss = img2mse(rgb_ref, tgt)
-    if with_depth_loss:
-        loss = loss + img2mse(depth_pred_ref, rays_depth_ref)
-    if 'rgb0' in extras_ref:
-        loss = loss + img2mse(extras_ref['rgb0'], tgt)
-        if with_depth_loss:
-            loss = loss + img2mse(extras_ref['depth0'], rays_depth_ref)
+    tgt = rgb_target_ref.squeeze(0).permute(1, 0).contiguous()
+    # the second render + its loss terms (VT:927-938): img2mse(rgb_ref, tgt) [+ img2mse(depth_pred_ref, rays_depth_ref)] on both
+    # levels = render_loss with no mask, un-normalised depths (far 1) and unit weights: every term rides in the compositing launches
+    loss, _terms, rgb_ref, disp_ref, acc_ref, depth_pred_ref, extras_ref = render_loss(
+        H, W, K, tgt, mask=None, depth_prior=rays_depth_ref.reshape(-1) if with_depth_loss else None, chunk=chunk,
+        rays=batch_rays_ref, hardmask_coef=0.0, depth_far=1.0, rgb_w=1.0, depth_w=1.0, mono=None, **dict(render_kwargs, retraw=True))
     return dict(loss=loss, mask_bound=mask_bound, mask=mask, threshold=thr, batch_rays_ref=batch_rays_ref,
                 rgb_target_ref=rgb_target_ref, rays_depth_ref=rays_depth_ref, rgb_ref=rgb_ref,
                 depth_pred_ref=depth_pred_ref, extras_ref=extras_ref)

@@ -166,7 +166,8 @@ def test_render_loss_equals_the_reference_lines(dev, Nf, with_depth, with_patch,
         if opt is not None:
             opt.zero_grad()
         loss.backward()
-        grads = opt.flat_grad.clone() if opt is not None else torch.cat([p.grad.reshape(-1) for p in params])
+        grads = opt.flat_grad.clone() if opt is not None else torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
+                                                                        for p in params])
         res.append((loss.detach(), {k: v.item() for k, v in terms.items()}, out[2], out[5], out[6], grads))
     (lf, tf, rgbf, depf, exf, gf), (lr, tr, rgbr, depr, exr, gr) = res
     assert torch.equal(rgbf, rgbr) and torch.equal(depf, depr)
