@@ -1211,6 +1211,30 @@ def main():
             extra["launches_per_step"] = launches_live if launches_live is not None else {
                 "total": None, "source": "needs the rocprofv3 pass (--pmc auto|on with rocprofv3 on PATH)"}
             out["extra"] = extra
+            # the legs' headline scalars once more as FLAT keys of `config` (the driver's record keeps the scalar fields of config /
+            # roofline / cpu_baseline and only lists the names of everything else: VERDICT r04 item 7)
+            def g(d, *ks):
+                for k in ks:
+                    d = d.get(k) if isinstance(d, dict) else None
+                return d
+            flat = {"leg_launches_per_step_c2": g(extra, "launches_per_step", "total"),
+                    "leg_aten_launches_per_step_c2": g(extra, "launches_per_step", "aten_and_runtime"),
+                    "leg_c4_shard_ms_per_step_graph": g(extra, "c4_shard", "ms_per_step_graph"),
+                    "leg_c4_shard_ms_per_step_eager": g(extra, "c4_shard", "ms_per_step_eager"),
+                    "leg_c4_shard_frac_of_peak_graph": g(extra, "c4_shard", "frac_of_peak_graph"),
+                    "leg_c2_bf16x3_ms_per_step": g(extra, "c2_bf16x3", "ms_per_step"),
+                    "leg_c2_bf16x3_speedup_vs_f32_step": g(extra, "c2_bf16x3", "speedup_vs_f32_step"),
+                    "leg_c5_frame_s": g(extra, "c5", "frame_s"),
+                    "leg_c3_ms_per_step": g(extra, "c3", "ms_per_step"),
+                    "leg_c3_frac_of_peak": g(extra, "c3", "roofline", "frac"),
+                    "leg_c3_launches_per_step": g(extra, "c3", "launches_per_step", "total"),
+                    "leg_c3_aten_launches_per_step": g(extra, "c3", "launches_per_step", "aten_and_runtime"),
+                    "leg_c3_ss_ms_per_step": g(extra, "c3_ss", "ms_per_step"),
+                    "leg_c3_ss_frac_of_peak": g(extra, "c3_ss", "roofline", "frac"),
+                    "leg_c3_ss_launches_per_step": g(extra, "c3_ss", "launches_per_step", "total")}
+            out["config"].update({k: (round(v, 4) if isinstance(v, float) else v) for k, v in flat.items()})
+            out["roofline"]["whole_step_frac"] = round(
+                per_rank * (NC + NC + NF) * 2 * (MAC_FWD + MAC_DGRAD + MAC_WGRAD) / (elapsed / a.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         emit()

@@ -240,9 +240,9 @@ def test_masked_loss_multi_workgroup_form(dev):
         assert torch.equal(l2, l3) and torch.equal(r2, r3) and torch.equal(d2, d3)
         assert torch.equal(r1, r2) and torch.equal(d1, d2)
         assert float(((l1 - l2).abs() / l1.abs()).max()) <= 2e-7
-    # the Python surface picks the workspace form by itself
-    loss, d_rgb, _ = ops.masked_loss(rgb, tgt, depth, prior, mask, far, 0.2)
-    assert torch.equal(d_rgb, r2)
+    # the Python surface picks the workspace form by itself (r2: the last iteration's = under those global counts)
+    loss, d_rgb, _ = ops.masked_loss(rgb, tgt, depth, prior, mask, far, 0.2, counts=counts)
+    assert torch.equal(d_rgb, r2) and torch.equal(loss, l2)
 
 
 # ------------------------------------------------------------------------------------------------ the step
