@@ -75,6 +75,24 @@ container's 8 cores train one CPU oracle in 2.5-7 h, so more seeds need another 
           (profiles/r04_psnr_parity_d16_{fp32,bf16x3}.json); a FAIL is a fail.  Criterion A is not part of D16 (A_s is not the CPU
           arithmetic; the same-init gap is reported only).  Consistency of the stand-in: on seeds 0-3 the ATen-GPU runs' PSNR are reported
           beside the CPU oracle's (they are different trajectories of the same chaotic map: no tolerance is claimed for that).
+
+Round 5, criterion D2000 (written and committed BEFORE any of its runs; VERDICT r04 item 3a: "parity at a convergence horizon").  Every
+parity run so far stops at 150 steps (held-out PSNR 25-28 dB); the HIP path reaches 35 dB in 3 000 steps with no second implementation
+beside it.  D2000 is criterion D16's design at a 13x longer horizon:
+  runs    per seed s in {0, 1, 2, 3}, true C2 size (512x640 views, 4096-ray batches, 64 + 128 samples, D=8/W=256), 2 000 steps,
+          milestones 500 / 1 000 / 2 000:
+            A_s, A'_s  the oracle's own code on stock ATen GPU kernels (`oracle_aten_gpu`) from the seed's weights and from
+                       ulp_nudge(weights, s)
+            H_s,j      the HIP path (exact fp32), j = 1..6 from ulp_nudge(weights, s + 1000 j); j = 0 (same init as A_s) is run and
+                       reported but enters no statistic of the verdict
+  test    T_bias (two-sided) and T_dist (one-sided) exactly as in criterion D (28^4 relabellings, 200 000 sampled, RNG seed 20260929),
+          Bonferroni level 0.05 / 3 = 0.0167 per milestone and statistic.
+  D2000   PASS iff no milestone has p(T_bias) < 0.0167 or p(T_dist) < 0.0167.  Criterion A is NOT part of the verdict (VERDICT r04 weak
+          1b: at C2 size no milestone keeps the same-init loss curves within 1e-3, so it passed vacuously in round 4; `twins
+          --no-criterion-a` removes it from `criterion_D_pass` and the JSON says so).  In addition, reported without a threshold: the
+          mean held-out PSNR of the two populations at 2 000 steps and the smallest effect the test could have detected (the 97.5th
+          percentile of |B_perm| at each milestone) — a PASS with a detectable effect of several dB would say little.
+          A FAIL is a fail; DESIGN.md states the outcome in one line.
 """
 import argparse
 import json
@@ -443,14 +461,14 @@ def run_twins(a):
                      "max_rel_loss_diff_up_to_hip_same_init": [float(rel[:m].max()) for m in ms],
                      "seconds": time.perf_counter() - t0})
         print(json.dumps(rows[-1]), flush=True)
-    out = twins_statistics(rows, ms)
+    out = twins_statistics(rows, ms, use_criterion_a=not getattr(a, "no_criterion_a", False))
     out.update({"size": a.size, "rays_per_step": B, "image": [H, W], "steps": steps, "runs": rows})
     with open(a.out, "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps({k: v for k, v in out.items() if k != "runs"}))
 
 
-def twins_statistics(rows, ms, n_perm=200000, rng_seed=20260929):
+def twins_statistics(rows, ms, n_perm=200000, rng_seed=20260929, use_criterion_a=True):
     """T_bias / T_dist / T_pair of the module docstring from the per-seed PSNR tables; pure numpy (unit-tested on the CPU)."""
     n_s, n_m = len(rows), len(ms)
     k = len(rows[0]["psnr_hip_draws"])
@@ -475,9 +493,11 @@ def twins_statistics(rows, ms, n_perm=200000, rng_seed=20260929):
     pairs = [(i, j) for i in range(n_r) for j in range(i + 1, n_r)]
     rs = np.random.RandomState(rng_seed)
     ge_B, ge_D = np.zeros(n_m), np.zeros(n_m)
-    for _ in range(n_perm):
+    absB = np.zeros((n_perm, n_m))
+    for it in range(n_perm):
         idx = [pairs[q] for q in rs.randint(0, len(pairs), n_s)]
         Bp, Dp = stats(idx)
+        absB[it] = np.abs(Bp)
         ge_B += np.abs(Bp) >= np.abs(B_obs) - 1e-12
         ge_D += Dp >= D_obs - 1e-12
     p_B, p_D = (ge_B + 1) / (n_perm + 1), (ge_D + 1) / (n_perm + 1)
@@ -495,7 +515,7 @@ def twins_statistics(rows, ms, n_perm=200000, rng_seed=20260929):
     track = np.array([r["max_rel_loss_diff_up_to_hip_same_init"] for r in rows]).max(0) <= 1e-3
     crit_a = bool(all(np.abs(gap0[:, m]).max() <= 0.02 for m in range(n_m) if track[m]))
     alpha = 0.05 / n_m
-    crit_d = bool(crit_a and (p_B >= alpha).all() and (p_D >= alpha).all())
+    crit_d = bool((crit_a or not use_criterion_a) and (p_B >= alpha).all() and (p_D >= alpha).all())
     return {
         "criteria_fixed_before_the_runs": "scripts/psnr_parity.py docstring, 'Round 4' block (commit precedes every twin result)",
         "milestones": ms, "seeds": [r["seed"] for r in rows], "hip_draws_per_seed": k, "permutations": n_perm,
@@ -505,6 +525,9 @@ def twins_statistics(rows, ms, n_perm=200000, rng_seed=20260929):
         "criterion_A": {"milestones_tracking": [m for m, t in zip(ms, track) if t],
                         "max_abs_gap_same_init_dB": np.abs(gap0).max(0).tolist(), "pass": crit_a},
         "bonferroni_alpha_per_milestone": alpha,
+        "criterion_A_part_of_the_verdict": bool(use_criterion_a),
+        "detectable_abs_bias_dB_97_5_percentile_of_the_null": np.percentile(absB, 97.5, axis=0).tolist(),
+        "mean_psnr_oracle_runs_dB": runs[:, :2].mean((0, 1)).tolist(), "mean_psnr_hip_draws_dB": runs[:, 2:].mean((0, 1)).tolist(),
         "criterion_D_pass": crit_d,
     }
 
@@ -602,6 +625,7 @@ def main():
     tw.add_argument("--draws", type=int, default=6)
     tw.add_argument("--size", default="c2")
     tw.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "psnr_twins.json"))
+    tw.add_argument("--no-criterion-a", action="store_true", help="criterion D2000: the same-init clause is not part of the verdict")
     a = ap.parse_args()
     if a.side == "twins":
         return run_twins(a)
