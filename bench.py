@@ -593,7 +593,7 @@ def c3_ss_step_fn(sc):
                               occlusion_threshold=0.1, with_depth_loss=True)
         opt.zero_grad()
         lp, _, _ = V.ss_primary_losses(rgb, depth, extras, target, d_prior, ss["mask_bound"], ss["mask"], with_depth_loss=True,
-                                       coins=[int(c) for c in rs.randint(0, 2, 4)])
+                                       coins=[int(c) for c in rs.randint(0, 2, 4)], sel=ss["sel"])
         loss = ss["loss"] + lp
         loss.backward()
         opt.step()

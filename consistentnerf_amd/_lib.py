@@ -67,6 +67,11 @@ class ClossTail(C.Structure):
                 ("P", C.c_int32), ("n", C.c_int32)]
 
 
+class SsWarp(C.Structure):
+    """struct cnerf_ss_warp"""
+    _fields_ = [("ref", RayGen), ("w2c", C.c_float * 12), ("flip", C.c_int32), ("image_ch", C.c_int32), ("thr0", C.c_float)]
+
+
 class PixelBatch(C.Structure):
     """struct cnerf_pixel_batch"""
     _fields_ = [("H", C.c_int32), ("W", C.c_int32), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
@@ -141,6 +146,7 @@ SIGNATURES = {
     "cnerf_warp_points": (_i, [_vp, _i64, C.POINTER(_f), _f, _f, _f, _f, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "cnerf_hard_mask_pair": (_i, [_i, _i, _f, _f, _f, _f, C.POINTER(_f), C.POINTER(_f), _vp, _vp, _f, _i, _vp,
                                   _vp, _vp]),
+    "cnerf_ss_ref_rays": (_i, [C.POINTER(SsWarp), _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cnerf_mse": (_i, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "cnerf_mse_ws_floats": (_i64, [_i64]),
     "cnerf_mse_ws": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),
@@ -174,7 +180,7 @@ def load():
         except AttributeError as e:
             raise CnerfError(f"libcnerf_hip.so does not export {name}") from e
         fn.restype, fn.argtypes = res, args
-    if lib.cnerf_abi_version() != 4:
+    if lib.cnerf_abi_version() != 5:
         raise CnerfError("libcnerf_hip.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

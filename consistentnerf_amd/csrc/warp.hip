@@ -2,7 +2,7 @@
 // get_ref_rays / get_test_label (V:576-669) and the mask loop of train() (V:994-1046).
 // One thread per world point / target pixel; per-5120-pixel chunk threshold search is one workgroup
 // with an LDS min-reduction (replaces a host-synchronising `while mask.sum()==0` loop per chunk).
-#include "common.hpp"
+#include "raygen.hpp"
 
 namespace {
 
@@ -108,6 +108,133 @@ __global__ __launch_bounds__(256) void hard_mask_k(int H, int W, float fx, float
   }
 }
 
+
+// ---- a15: the in-loop consistency block's ray construction as ONE launch (VT:905-925 + get_ref_rays VT:451-501) ---------------
+// For the N rays of the batch: P = rays_o + depth * rays_d (VT:905), projection into the reference camera (`project`, no axis flip in
+// the VT variant), strict bounds -> mask_bound; the in-bounds points, COMPACTED in batch order (what the reference's boolean
+// indexing `x[mask]` does with a host sync each), define rays of the reference camera through the snapped pixels: direction
+// ((px - cx) / fx, (py - cy) / fy, 1) rotated by c2w (get_rays_ref V:553-574), origin = the camera centre; colour / depth prior
+// of the reference view at the pixel; |z_cam - D_ref| and from its minimum the occlusion threshold thr0 * 2^k (smallest k that
+// lets one point pass: the reference's `while mask.sum() == 0` doubling, VT:921-925, a host sync per iteration there).
+// One workgroup of 1024 threads walks the batch in chunks (ballot + popcount scan: the compaction keeps batch order and is
+// deterministic); a second sweep applies the threshold.  Also written: the [M, 8|11] rows render() would assemble from the new
+// rays (raygen.hpp: the arithmetic of pack_rays_k) and sel[N] = mask_bound AND occlusion mask per PRIMARY ray (what
+// `x[mask_bound][mask]` selects, VT:941-969) as a 0/1 weight.
+struct SsDev {
+  Mat34 w2c;
+  RayGenDev cam;            // the reference camera + the bounds / flags of the render() the rays are for
+  int H, W, flip, image_ch;
+  float thr0;
+};
+
+__global__ __launch_bounds__(1024) void ss_ref_rays_k(SsDev a, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                      const float* __restrict__ depth, int64_t N, const float* __restrict__ image,
+                                                      const float* __restrict__ depth_ref, float* __restrict__ rows,
+                                                      float* __restrict__ rays_od, float* __restrict__ target,
+                                                      float* __restrict__ depth_tgt, float* __restrict__ depth_diff,
+                                                      uint8_t* __restrict__ inb, uint8_t* __restrict__ mask,
+                                                      float* __restrict__ sel, int32_t* __restrict__ rank, int32_t* __restrict__ meta) {
+  __shared__ int wcnt[16];
+  __shared__ float wmin[16];
+  __shared__ int wnan[16];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int base = 0;                      // in-bounds points in front of this chunk (workgroup-uniform)
+  float amin = __builtin_inff();
+  int anynan = 0;
+  for (int64_t c0 = 0; c0 < N; c0 += 1024) {
+    const int64_t i = c0 + tid;
+    Proj p = {};
+    bool in = false;
+    if (i < N) {
+      const float dep = depth[i];
+      p = project(rays_o[3 * i] + dep * rays_d[3 * i], rays_o[3 * i + 1] + dep * rays_d[3 * i + 1],
+                  rays_o[3 * i + 2] + dep * rays_d[3 * i + 2], a.w2c, a.cam.fx, a.cam.fy, a.cam.cx, a.cam.cy, a.H, a.W, a.flip);
+      in = p.inb;
+    }
+    const unsigned long long bal = __ballot(in);
+    if (lane == 0) wcnt[wv] = __popcll(bal);
+    __syncthreads();
+    int off = base, tot = 0;
+    for (int w = 0; w < 16; ++w) {
+      off += w < wv ? wcnt[w] : 0;
+      tot += wcnt[w];
+    }
+    if (in) {
+      const int64_t j = off + __popcll(bal & ((1ull << lane) - 1ull));
+      const float d0 = (p.px - a.cam.cx) / a.cam.fx, d1 = (p.py - a.cam.cy) / a.cam.fy, d2 = 1.f;   // VT:491
+      const float dx = d0 * a.cam.r[0] + d1 * a.cam.r[1] + d2 * a.cam.r[2];                        // directions @ c2w[:3,:3].T (V:566)
+      const float dy = d0 * a.cam.r[3] + d1 * a.cam.r[4] + d2 * a.cam.r[5];
+      const float dz = d0 * a.cam.r[6] + d1 * a.cam.r[7] + d2 * a.cam.r[8];
+      if (rays_od) {
+        float* ro = rays_od + j * 3;
+        float* rd = rays_od + (N + j) * 3;
+        ro[0] = a.cam.t[0]; ro[1] = a.cam.t[1]; ro[2] = a.cam.t[2];
+        rd[0] = dx; rd[1] = dy; rd[2] = dz;
+      }
+      if (rows) {
+        float o[3], d[3], v[3];
+        cn_finish_ray(a.cam.t[0], a.cam.t[1], a.cam.t[2], dx, dy, dz, a.cam.vd, a.cam.ndc, a.cam.ax, a.cam.ay, o, d, v);
+        float* out = rows + j * (a.cam.vd ? 11 : 8);
+        out[0] = o[0]; out[1] = o[1]; out[2] = o[2]; out[3] = d[0]; out[4] = d[1]; out[5] = d[2];
+        out[6] = a.cam.near; out[7] = a.cam.far;
+        if (a.cam.vd) { out[8] = v[0]; out[9] = v[1]; out[10] = v[2]; }
+      }
+      const int64_t pix = (int64_t)(int)p.py * a.W + (int)p.px;
+      if (target) {
+        const float* q = image + pix * a.image_ch;
+        target[3 * j] = q[0]; target[3 * j + 1] = q[1]; target[3 * j + 2] = q[2];
+      }
+      const float dr = depth_ref[pix];
+      if (depth_tgt) depth_tgt[j] = dr;
+      const float ad = fabsf(p.zc - dr);
+      depth_diff[j] = ad;
+      if (ad != ad) anynan = 1;
+      amin = ad < amin ? ad : amin;
+      rank[i] = (int32_t)j;
+    } else if (i < N) {
+      rank[i] = -1;
+    }
+    if (i < N && inb) inb[i] = in ? 1 : 0;
+    base += tot;
+    __syncthreads();   // wcnt is rewritten by the next chunk
+  }
+  // minimum of |diff| over the in-bounds points (torch.min: NaN wins)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float t = __shfl_xor(amin, o, 64);
+    amin = t < amin ? t : amin;
+    anynan |= __shfl_xor(anynan, o, 64);
+  }
+  if (lane == 0) { wmin[wv] = amin; wnan[wv] = anynan; }
+  __syncthreads();   // (also: every depth_diff / rank store of this workgroup is visible below)
+  amin = wmin[0];
+  anynan = wnan[0];
+  for (int w = 1; w < 16; ++w) {
+    amin = wmin[w] < amin ? wmin[w] : amin;
+    anynan |= wnan[w];
+  }
+  const int M = base;
+  // thr = thr0 * 2^k, smallest k >= 0 with min|diff| < thr (VT:921-925 doubles until something passes); a NaN minimum compares
+  // false against every candidate -> k stops at the cap like the cached ladder of round 4 (63 doublings)
+  float thr = a.thr0;
+  int k = 0;
+  if (anynan) {
+    k = 0;
+  } else {
+    while (!(amin < thr) && k < 63) { thr = 2.f * thr; ++k; }
+  }
+  if (tid == 0) {
+    meta[0] = M; meta[1] = k; meta[2] = __float_as_int(thr); meta[3] = anynan;
+  }
+  if (mask)
+    for (int64_t j = tid; j < M; j += 1024) mask[j] = depth_diff[j] < thr ? 1 : 0;
+  if (sel)
+    for (int64_t i = tid; i < N; i += 1024) {
+      const int32_t j = rank[i];
+      sel[i] = (j >= 0 && depth_diff[j] < thr) ? 1.f : 0.f;
+    }
+}
+
 }  // namespace
 
 extern "C" int cnerf_warp_points(const float* P, int64_t N, const float* w2c_host, float fx, float fy, float cx,
@@ -131,6 +258,26 @@ extern "C" int cnerf_hard_mask_pair(int H, int W, float fx, float fy, float cx, 
   hipLaunchKernelGGL(hard_mask_k, dim3((unsigned)cn_div_up(npix, chunk)), dim3(256), 0, cn_stream(stream), H, W, fx,
                      fy, cx, cy, load34(c2w_tgt_host), load34(w2c_ref_host), depth_tgt, depth_ref, thr0, chunk, mask,
                      thr_out);
+  CN_CHECK_LAUNCH();
+  return CNERF_OK;
+}
+
+extern "C" int cnerf_ss_ref_rays(const cnerf_ss_warp* c, const float* rays_o, const float* rays_d, const float* depth, int64_t N,
+                                 const float* image, const float* depth_ref, float* rows, float* rays_od, float* target,
+                                 float* depth_tgt, float* depth_diff, uint8_t* inb, uint8_t* mask, float* sel, int32_t* rank,
+                                 int32_t* meta, void* stream) {
+  if (!c || !rays_o || !rays_d || !depth || !depth_ref || !depth_diff || !rank || !meta || N <= 0 || N >= (1ll << 31) ||
+      c->ref.H < 2 || c->ref.W < 2 || !(c->thr0 > 0.f) || (target && (!image || c->image_ch < 3)))
+    return CNERF_E_ARG;
+  SsDev a = {};
+  cnerf_raygen rg = c->ref;
+  rg.first = 0;
+  int rc = cn_make_raygen(&rg, &a.cam);
+  if (rc) return rc;
+  a.w2c = load34(c->w2c);
+  a.H = c->ref.H; a.W = c->ref.W; a.flip = c->flip; a.image_ch = c->image_ch; a.thr0 = c->thr0;
+  hipLaunchKernelGGL(ss_ref_rays_k, dim3(1), dim3(1024), 0, cn_stream(stream), a, rays_o, rays_d, depth, N, image, depth_ref, rows,
+                     rays_od, target, depth_tgt, depth_diff, inb, mask, sel, rank, meta);
   CN_CHECK_LAUNCH();
   return CNERF_OK;
 }

@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import Closs, ClossTail, CnerfError, Net, PixelBatch, Ptrs, RayGen, RenderCfg, RenderGrads, RenderOut, Rng
+from ._lib import Closs, ClossTail, CnerfError, Net, PixelBatch, Ptrs, RayGen, RenderCfg, RenderGrads, RenderOut, Rng, SsWarp
 
 Tensor = torch.Tensor
 
@@ -764,6 +764,59 @@ def warp_points(P: Tensor, w2c, K, H: int, W: int, flip: bool):
                                              float(K[1][2]), H, W, int(flip), _p(Xc), _p(px), _p(py), _p(inb),
                                              _stream()), "cnerf_warp_points")
     return Xc, px, py, inb.bool()
+
+_PINNED_META = {}
+
+
+def _pinned_meta(dev):
+    """A small ring of pinned int32[4] buffers per device (pinned allocations cost ~100 us each: never per step)."""
+    ring = _PINNED_META.get(dev.index)
+    if ring is None:
+        ring = _PINNED_META[dev.index] = [[torch.empty(4, dtype=torch.int32).pin_memory() for _ in range(8)], 0]
+    ring[1] = (ring[1] + 1) % len(ring[0])
+    return ring[0][ring[1]]
+
+
+def ss_ref_rays(rays_o: Tensor, rays_d: Tensor, depth: Tensor, w2c_ref, c2w_ref, K, H: int, W: int, image: Tensor, depth_ref: Tensor,
+                thr0: float, near: float, far: float, use_viewdirs: bool, ndc: bool, ndc_coef=(0.0, 0.0), flip: bool = False,
+                want_rows: bool = True):
+    """cnerf_ss_ref_rays (VT:905-925): one launch + ONE 16-byte read-back (the ray count M of the second render; the reference
+    synchronises at every boolean index and every threshold doubling) -> dict(M, k, thr (python float), rows [M, 8|11] | None,
+    rays_od [2, M, 3] (views of a [2, N, 3] buffer), target [M, 3], depth_tgt [M], depth_diff [M], inb [N] uint8, mask [M] uint8,
+    sel [N] float, rank [N] int32).  image [H, W, >=3] and depth_ref [H, W] live on the device; w2c_ref / c2w_ref are host 3x4|4x4."""
+    rays_o, rays_d, depth = _chk(rays_o.reshape(-1, 3), "rays_o"), _chk(rays_d.reshape(-1, 3), "rays_d"), _chk(depth.reshape(-1), "depth")
+    image, depth_ref = _chk(image, "image"), _chk(depth_ref, "depth_ref")
+    N, dev = rays_o.shape[0], rays_o.device
+    if image.dim() != 3 or image.shape[0] != H or image.shape[1] != W or image.shape[2] < 3 or depth_ref.numel() != H * W:
+        raise CnerfError(f"ss_ref_rays: image must be [{H}, {W}, >=3] and depth_ref [{H}, {W}]")
+    if rays_d.shape[0] != N or depth.shape[0] != N or N == 0:
+        raise CnerfError("ss_ref_rays: rays_o / rays_d / depth must describe the same (non-empty) batch")
+    cfg = SsWarp()
+    r = cfg.ref
+    r.H, r.W, r.fx, r.fy, r.cx, r.cy = int(H), int(W), float(K[0][0]), float(K[1][1]), float(K[0][2]), float(K[1][2])
+    r.c2w = _f4(c2w_ref.detach().cpu().numpy() if isinstance(c2w_ref, torch.Tensor) else c2w_ref)
+    r.near, r.far, r.use_viewdirs, r.ndc = float(near), float(far), int(use_viewdirs), int(ndc)
+    r.ndc_ax, r.ndc_ay, r.first = float(ndc_coef[0]), float(ndc_coef[1]), 0
+    cfg.w2c = _f4(w2c_ref.detach().cpu().numpy() if isinstance(w2c_ref, torch.Tensor) else w2c_ref)
+    cfg.flip, cfg.image_ch, cfg.thr0 = int(flip), int(image.shape[2]), float(thr0)
+    rows = torch.empty(N, 11 if use_viewdirs else 8, device=dev) if want_rows else None
+    od = torch.empty(2, N, 3, device=dev)
+    target, dtgt, diff = torch.empty(N, 3, device=dev), torch.empty(N, device=dev), torch.empty(N, device=dev)
+    inb, mask = torch.empty(N, device=dev, dtype=torch.uint8), torch.empty(N, device=dev, dtype=torch.uint8)
+    sel, rank = torch.empty(N, device=dev), torch.empty(N, device=dev, dtype=torch.int32)
+    meta = torch.empty(4, device=dev, dtype=torch.int32)
+    _lib.check(_lib.load().cnerf_ss_ref_rays(C.byref(cfg), _p(rays_o), _p(rays_d), _p(depth), N, _p(image), _p(depth_ref), _p(rows),
+                                             _p(od), _p(target), _p(dtgt), _p(diff), _p(inb), _p(mask), _p(sel), _p(rank), _p(meta),
+                                             _stream()), "cnerf_ss_ref_rays")
+    host = _pinned_meta(dev)
+    host.copy_(meta, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream())
+    ev.synchronize()                      # the ONE host wait of the block: the second render's launch dimensions need M
+    M, k = int(host[0]), int(host[1])
+    thr = float(np.int32(int(host[2])).view(np.float32))
+    return dict(M=M, k=k, thr=thr, rows=None if rows is None else rows[:M], rays_od=od[:, :M], target=target[:M], depth_tgt=dtgt[:M],
+                depth_diff=diff[:M], inb=inb, mask=mask[:M], sel=sel, rank=rank)
 
 
 def hard_mask_pair(H, W, K, c2w_tgt, w2c_ref, depth_tgt: Tensor, depth_ref: Tensor, thr0: float, chunk: int,

@@ -19,8 +19,8 @@ import torch
 from . import ops
 from . import run_nerf as _R
 from .run_nerf import (batchify, batchify_rays, raw2outputs, run_network)  # noqa: F401
-from .run_nerf_helpers import (NeRF, get_embedder, get_rays, get_rays_np, img2mse, mse2psnr, ndc_rays,  # noqa: F401
-                               sample_pdf, to8b)
+from .run_nerf_helpers import (NeRF, get_embedder, get_rays, get_rays_np, img2mse, mse2psnr, ndc_coefficients,  # noqa: F401
+                               ndc_rays, sample_pdf, to8b)
 
 
 def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far=1., use_viewdirs=False,
@@ -252,16 +252,6 @@ def render_loss(H, W, K, target_s, mask=None, depth_prior=None, chunk=1024 * 32,
 
 
 # ----------------------------------------------------------------------------- in-loop consistency (a15)
-_LADDERS = {}
-
-
-def _threshold_ladder(thr0, dev):
-    key = (thr0, str(dev))
-    if key not in _LADDERS:
-        _LADDERS[key] = (torch.full((64,), thr0, dtype=torch.float32) * torch.pow(2.0, torch.arange(64, dtype=torch.float32))).to(dev)
-    return _LADDERS[key]
-
-
 def ss_consistency(rays_o, rays_d, depth_cas_s, pose_ref, K, image_ref, depth_ref, H, W, render_kwargs, chunk=1024 * 32,
                    occlusion_threshold=0.1, with_depth_loss=False):
     """The `args.ss_loss` block of run_nerf_view_test.train() (VT:905-938): the batch's depth-prior points
@@ -272,45 +262,52 @@ def ss_consistency(rays_o, rays_d, depth_cas_s, pose_ref, K, image_ref, depth_re
     the device — the reference's `while mask.sum() == 0` loop costs a host sync per iteration.
 
     rays_o, rays_d [N, 3], depth_cas_s [N], pose_ref [3, 4] (c2w), image_ref [H, W, 3], depth_ref [H, W].
-    Returns a dict: loss (the four VT:930-938 terms), mask_bound [1, N], mask [M, 1], threshold (0-d tensor, the one that
-    produced `mask`), batch_rays_ref [2, M, 3], rgb_target_ref [1, 3, M], rays_depth_ref [1, 1, M], and the second
+    Returns a dict: loss (the four VT:930-938 terms), mask_bound [1, N], mask [M, 1], sel [N] (1.0 where mask_bound AND the
+    occlusion mask hold: the selection `x[mask_bound][mask]` as a ray weight, for ss_primary_losses), threshold (0-d tensor, the one
+    that produced `mask`), batch_rays_ref [2, M, 3], rgb_target_ref [1, 3, M], rays_depth_ref [1, 1, M], and the second
     render's rgb_ref, depth_pred_ref, extras_ref."""
     dev = rays_o.device
-    point_samples_w = rays_o + depth_cas_s[:, None] * rays_d
     c2w_ref = torch.eye(4)
     c2w_ref[:3, :4] = torch.as_tensor(np.asarray(pose_ref.cpu() if isinstance(pose_ref, torch.Tensor) else pose_ref),
                                       dtype=torch.float32)[:3, :4]
     w2c_ref = torch.inverse(c2w_ref)                       # 4x4 on the host, as VT:910
-    from .raybank import _host_to_device          # (small host matrices go up without stalling the host on the stream)
-    Kt = _host_to_device(np.asarray(K.cpu() if isinstance(K, torch.Tensor) else K), torch.float32, dev)
-    img = torch.as_tensor(image_ref, dtype=torch.float32).to(dev)[None].permute(0, 3, 1, 2)
-    dep = torch.as_tensor(depth_ref, dtype=torch.float32).to(dev)[None]
-    rgb_target_ref, rays_depth_ref, pts_c_ref, rays_o_ref, rays_d_ref, mask_bound = get_ref_rays(
-        _host_to_device(w2c_ref, torch.float32, dev)[None], _host_to_device(c2w_ref, torch.float32, dev)[None], Kt[None], point_samples_w[None, :, None, :], img, dep, variant="VT")
-    if rays_o_ref.shape[0] == 0:
+    img = torch.as_tensor(image_ref, dtype=torch.float32).to(dev)
+    dep = torch.as_tensor(depth_ref, dtype=torch.float32).to(dev)
+    # ONE launch for VT:905-925 (round 5, second half): the warp, the compaction of the in-bounds points (`x[mask]` in the reference:
+    # a host sync per boolean index), the reference rays + the rows render() packs from them, the gathered colours / depth priors,
+    # |z - D_ref|, the doubling rule's threshold and both masks; one 16-byte read-back (the second render's ray count)
+    near, far = render_kwargs.get('near', 0.), render_kwargs.get('far', 1.)
+    vd, ndc = bool(render_kwargs.get('use_viewdirs', False)), bool(render_kwargs.get('ndc', True))
+    scalar_bounds = not (torch.is_tensor(near) or torch.is_tensor(far))
+    o = ops.ss_ref_rays(rays_o, rays_d, depth_cas_s, w2c_ref.numpy(), c2w_ref.numpy(), K, H, W, img, dep, float(occlusion_threshold),
+                        float(near) if scalar_bounds else 0., float(far) if scalar_bounds else 1., vd, ndc,
+                        ndc_coefficients(H, W, K[0][0]) if ndc else (0., 0.), flip=False, want_rows=scalar_bounds)
+    if o["M"] == 0:
         raise ops.CnerfError("ss_consistency: no point of the batch projects into the reference view "
                              "(the reference loops forever here)")
-    adiff = (pts_c_ref[..., -1].reshape(-1, 1) - rays_depth_ref.reshape(-1)[:, None]).abs()
-    # thr = occlusion_threshold * 2^k for the smallest k >= 0 that lets some |diff| pass (VT:921-925) — on the device, without the
-    # reference's host sync per doubling and without a launch per doubling either: the 64 candidate thresholds (exact in fp32:
-    # powers of two times the base) are a cached constant, k = the number of candidates <= min |diff|
-    cand = _threshold_ladder(float(occlusion_threshold), dev)
-    thr = cand[(adiff.min() >= cand).sum().clamp_(max=cand.numel() - 1)]
-    mask = adiff < thr
-    batch_rays_ref = torch.stack([rays_o_ref, rays_d_ref], 0)
-    tgt = rgb_target_ref.squeeze(0).permute(1, 0).contiguous()
+    batch_rays_ref = o["rays_od"]
+    if o["rows"] is not None:
+        from .raybank import PackedRays
+        batch_rays_ref._cnerf_packed = PackedRays(o["rows"], H, W, K[0][0], near, far, vd, ndc)
+    tgt = o["target"]
+    rgb_target_ref = tgt.t()[None]                         # [1, 3, M] like img[:, :, yi, xi] (a view)
+    rays_depth_ref = o["depth_tgt"][None, None]            # [1, 1, M]
+    mask_bound = o["inb"].view(torch.bool)[None]
+    mask = o["mask"].view(torch.bool)[:, None]
+    thr = torch.tensor(o["thr"], dtype=torch.float32)
     # the second render + its loss terms (VT:927-938): img2mse(rgb_ref, tgt) [+ img2mse(depth_pred_ref, rays_depth_ref)] on both
     # levels = render_loss with no mask, un-normalised depths (far 1) and unit weights: every term rides in the compositing launches
     loss, _terms, rgb_ref, disp_ref, acc_ref, depth_pred_ref, extras_ref = render_loss(
-        H, W, K, tgt, mask=None, depth_prior=rays_depth_ref.reshape(-1) if with_depth_loss else None, chunk=chunk,
+        H, W, K, tgt, mask=None, depth_prior=o["depth_tgt"] if with_depth_loss else None, chunk=chunk,
         rays=batch_rays_ref, hardmask_coef=0.0, depth_far=1.0, rgb_w=1.0, depth_w=1.0, mono=None, **dict(render_kwargs, retraw=True))
-    return dict(loss=loss, mask_bound=mask_bound, mask=mask, threshold=thr, batch_rays_ref=batch_rays_ref,
+    return dict(loss=loss, mask_bound=mask_bound, mask=mask, threshold=thr, batch_rays_ref=batch_rays_ref, sel=o["sel"],
                 rgb_target_ref=rgb_target_ref, rays_depth_ref=rays_depth_ref, rgb_ref=rgb_ref,
                 depth_pred_ref=depth_pred_ref, extras_ref=extras_ref)
 
 
 
-def ss_primary_losses(rgb, depth_pred, extras, target_s, depth_cas_s, mask_bound, mask, with_depth_loss=False, coins=None):
+def ss_primary_losses(rgb, depth_pred, extras, target_s, depth_cas_s, mask_bound, mask, with_depth_loss=False, coins=None,
+                      sel=None):
     """The primary render's loss terms under `args.ss_loss` (VT:941-969), consumers of `ss_consistency`'s masks: each term
     is restricted to the rays `[mask_bound.squeeze()][mask.squeeze()]` (projected into the reference view AND passing the
     occlusion test) when its `random.randint(0, 1)` coin is 1, and is the plain mean (rgb) / absent (depth) otherwise.
@@ -319,11 +316,14 @@ def ss_primary_losses(rgb, depth_pred, extras, target_s, depth_cas_s, mask_bound
     term to the FINE rgb when its coin is 0 (VT:959) is kept.  Depth terms are un-normalised MSEs (no /far), as in VT.
     Returns (loss, img_loss, img_loss0); img_loss0 is None when the render has no coarse outputs.
 
-    The double boolean selection becomes one 0/1 ray weight (no host sync, no gathers) fed to the masked-loss kernel."""
+    The double boolean selection becomes one 0/1 ray weight (no host sync, no gathers) fed to the masked-loss kernel; pass
+    `sel=ss_consistency(...)['sel']` to take the one its launch wrote instead of re-deriving it from the two masks."""
     import random
     draw = (lambda: random.randint(0, 1)) if coins is None else iter(list(coins)).__next__
     mb, mk = mask_bound.reshape(-1).bool(), mask.reshape(-1).bool()
-    if mk.numel() == 0:
+    if sel is not None:    # ss_consistency's own launch already formed it (`sel` of its result)
+        sel = sel.reshape(-1).to(torch.float32)
+    elif mk.numel() == 0:
         sel = torch.zeros(mb.shape, device=rgb.device, dtype=torch.float32)
     else:   # sel[i] = mask_bound[i] and mask[rank of i among the in-bounds rays]
         pos = (torch.cumsum(mb.long(), 0) - 1).clamp_(min=0, max=mk.numel() - 1)

@@ -21,7 +21,8 @@
 extern "C" {
 #endif
 
-#define CNERF_ABI_VERSION 4   /* 4: + cnerf_sample_pixels (one-launch training batch of an image), the ConsistentNeRF losses folded into
+#define CNERF_ABI_VERSION 5   /* 5: + cnerf_ss_ref_rays (the in-loop consistency block's warp / compaction / reference rays / occlusion mask as one
+                                * launch); every v4 entry point unchanged.   4: + cnerf_sample_pixels (one-launch training batch of an image), the ConsistentNeRF losses folded into
                                 * compositing (cnerf_closs, *_closs, cnerf_closs_finish); cnerf_masked_loss uses its workspace for
                                 * batches > 16384 rays; every v3 entry point unchanged.   3: + in-kernel uniform streams (cnerf_rng, *_rng) and compositing with img2mse folded in (*_mse);
                                 * every v2 entry point unchanged.   2: cnerf_adam_step takes its hyper-parameters as double; the *_pair, *_cam, *_bf entry points */
@@ -397,6 +398,35 @@ int cnerf_warp_points(const float* P, int64_t N, const float* w2c_host, float fx
 int cnerf_hard_mask_pair(int H, int W, float fx, float fy, float cx, float cy, const float* c2w_tgt_host,
                          const float* w2c_ref_host, const float* depth_tgt, const float* depth_ref,
                          float thr0, int chunk, uint8_t* mask, float* thr_out, void* stream);
+
+/* ---- a15: the in-loop consistency block's ray construction as ONE launch (run_nerf_view_test.py:905-925 with get_ref_rays
+ *      :451-501 and get_rays_ref run_nerf_view.py:553-574) -------------------------------------------------------------------------
+ * The batch's depth-prior points rays_o + depth * rays_d [N] (:905) are projected into the reference camera (cfg->w2c = the
+ * inverse of cfg->ref.c2w, computed by the caller as :910 does; flip = 0 for this variant, 1 = the OpenGL->OpenCV flip of
+ * run_nerf_view.py:596); the M in-bounds ones, COMPACTED in batch order (the reference's `x[mask]`, a host synchronisation each),
+ * give:
+ *   rays_od[2][N][3] (first M rows of each half)  the rays of the reference camera through the snapped pixels: origin = camera centre,
+ *                    direction = ((px - cx) / fx, (py - cy) / fy, 1) @ c2w[:3,:3]^T                                  (:491-493)
+ *   rows[M][8|11]    the rows render() assembles from those rays for cfg->ref.near / far / use_viewdirs / ndc (run_nerf.py:100-125)
+ *   target[M][3], depth_tgt[M]   colour (image[H][W][image_ch]) and depth prior (depth_ref[H][W]) of the reference view there  (:495-497)
+ *   depth_diff[M]    |z in the reference camera - depth_tgt|                                                          (:923)
+ *   mask[M]          depth_diff < thr, thr = thr0 * 2^k with the smallest k >= 0 that lets one point pass (:921-925: doubled until
+ *                    mask.sum() > 0, a host synchronisation per doubling in the reference; k <= 63)
+ *   inb[N]           mask_bound;   rank[N] = row of ray i among the M (or -1);   sel[N] = 1.0 where inb AND mask[rank] — the rays
+ *                    `x[mask_bound.squeeze()][mask.squeeze()]` selects in the primary render's terms (:941-969) — else 0.0
+ *   meta[4]          M, k, the bits of thr (float), 1 if some depth_diff is NaN (then k = 0, as torch.min propagates NaN)
+ * depth_diff, rank and meta are required (workspaces of the second sweep); rows, rays_od, target, depth_tgt, inb, mask, sel may be
+ * NULL.  One workgroup, deterministic.  M = 0 is reported, not an error (the reference loops forever there). */
+typedef struct cnerf_ss_warp {
+  cnerf_raygen ref;      /* the reference camera and the bounds / flags of the render() call the rays are built for */
+  float w2c[12];         /* world-to-camera [3,4] of the reference view, row-major (HOST) */
+  int32_t flip;
+  int32_t image_ch;      /* floats per pixel of `image` (>= 3) */
+  float thr0;            /* args.occlusion_threshold */
+} cnerf_ss_warp;
+int cnerf_ss_ref_rays(const cnerf_ss_warp* cfg, const float* rays_o, const float* rays_d, const float* depth, int64_t N,
+                      const float* image, const float* depth_ref, float* rows, float* rays_od, float* target, float* depth_tgt,
+                      float* depth_diff, uint8_t* inb, uint8_t* mask, float* sel, int32_t* rank, int32_t* meta, void* stream);
 
 /* img2mse (run_nerf_helpers.py:9): loss[0] = mean((x - y)^2) over n elements; d_x (nullable) = 2 (x - y) / n, the
  * gradient of the loss w.r.t. x.  One launch, fixed summation order. */

@@ -1286,6 +1286,53 @@ def test_patch_depth_term_golden(dev):
     assert torch.equal(l2, loss) and np.array_equal(d2.cpu().numpy(), got, equal_nan=True)
 
 
+@pytest.mark.parametrize("N,thr0,ndc", [(1280, 0.1, False), (4096, 1e-6, False), (5000, 0.05, True), (1, 0.1, False)])
+def test_ss_ref_rays_one_launch_equals_the_lines(dev, N, thr0, ndc):
+    """cnerf_ss_ref_rays (VT:905-925 as ONE launch) against the same block composed launch by launch the way round 4 ran it —
+    `get_ref_rays(variant="VT")` (warp kernel + boolean indexing + gathers), |z - D_ref|, the doubling rule on a ladder, the double
+    boolean selection via cumsum — on a random batch: masks, compaction order, gathered colours / depths, threshold bit for bit;
+    ray directions 1e-6 (the lines' `directions @ c2w.T` is a rocBLAS GEMM); the packed rows == cnerf_pack_rays of the rays."""
+    from consistentnerf_amd import ops, run_nerf_view as V
+    from consistentnerf_amd.run_nerf_helpers import ndc_coefficients
+    g = golden("warp")
+    Hh, Ww = g["images"][1].shape[:2]
+    K = g["K"]
+    rs = np.random.RandomState(N)
+    ro = T(np.tile(g["poses"][0][:3, 3], (N, 1)) + rs.normal(0, 0.05, (N, 3)).astype(np.float32), dev)
+    rd = T(rs.normal(0, 1, (N, 3)).astype(np.float32) * 0.3 + g["poses"][0][:3, :3] @ np.array([0, 0, -1], np.float32), dev)
+    dpt = T(rs.uniform(1.0, 6.0, N).astype(np.float32), dev)
+    c2w = np.eye(4, dtype=np.float32); c2w[:3, :4] = g["poses"][1]
+    w2c = torch.inverse(torch.from_numpy(c2w)).numpy()
+    img, dep = T(g["images"][1], dev), T(g["depths"][1], dev)
+    near, far = 0.5, 7.0
+    coef = ndc_coefficients(Hh, Ww, K[0][0]) if ndc else (0., 0.)
+    o = ops.ss_ref_rays(ro, rd, dpt, w2c, c2w, K, Hh, Ww, img, dep, thr0, near, far, True, ndc, coef)
+    # the lines
+    Pw = ro + dpt[:, None] * rd
+    rgb_l, d_l, Xc_l, ro_l, rd_l, mb_l = V.get_ref_rays(T(w2c, dev)[None], T(c2w, dev)[None], T(K, dev)[None], Pw[None, :, None, :],
+                                                        img.permute(2, 0, 1)[None], dep[None], variant="VT")
+    M = int(mb_l.sum().item())
+    assert o["M"] == M and np.array_equal(o["inb"].cpu().numpy().astype(bool), mb_l.reshape(-1).cpu().numpy())
+    if M == 0:
+        return
+    assert torch.equal(o["target"], rgb_l[0].t().contiguous()) and torch.equal(o["depth_tgt"], d_l.reshape(-1))
+    adiff = (Xc_l[..., -1].reshape(-1) - d_l.reshape(-1)).abs()
+    assert torch.equal(o["depth_diff"], adiff)
+    cand = torch.full((64,), thr0, dtype=torch.float32) * torch.pow(2.0, torch.arange(64, dtype=torch.float32))
+    k = int((adiff.min().cpu() >= cand).sum().clamp(max=63))
+    assert o["k"] == k and np.float32(o["thr"]) == cand[k].numpy()
+    mk = adiff < cand[k].to(dev)
+    assert mk.any() and torch.equal(o["mask"].bool(), mk)
+    pos = (torch.cumsum(mb_l.reshape(-1).long(), 0) - 1).clamp_(min=0)
+    assert torch.equal(o["sel"], (mb_l.reshape(-1) & mk[pos]).float())
+    assert torch.equal(o["rank"].long()[mb_l.reshape(-1)], torch.arange(M, device=dev))
+    assert torch.equal(o["rays_od"][0], ro_l)
+    err = (o["rays_od"][1] - rd_l).abs().max().item()
+    assert err <= 1e-6 * rd_l.abs().max().item(), err
+    rows = ops.pack_rays(o["rays_od"][0].contiguous(), o["rays_od"][1].contiguous(), near, far, True, ndc, coef)
+    assert torch.equal(o["rows"], rows)
+
+
 def test_in_loop_consistency_golden(dev):
     """a15 (VT:905-938): warp of the batch's depth-prior points into a reference view, occlusion threshold doubling,
     second render on the warped rays, the four loss terms and their weight gradients — against the reference's own
