@@ -505,7 +505,14 @@ __device__ __forceinline__ void wgrad_body_bf3(WgNetC& a, WgJobC& jb, float* lds
               }
             }
           }
-          if (dma && j < 8 && k == 3) { piece(dsl, dbuf, 2 * j); piece(dsl, dbuf, 2 * j + 1); }
+          // the 16 DMA pieces of the next slab: two per tile pair in the first eight (>= 8 tile pairs per K-step), four per tile
+          // pair when the wave owns only four (the 2 x 2 narrow GEMMs)
+          if (AN * AK >= 8) {
+            if (dma && j < 8 && k == 3) { piece(dsl, dbuf, 2 * j); piece(dsl, dbuf, 2 * j + 1); }
+          } else {
+            if (dma && k == 1) { piece(dsl, dbuf, 4 * j); piece(dsl, dbuf, 4 * j + 1); }
+            if (dma && k == 3) { piece(dsl, dbuf, 4 * j + 2); piece(dsl, dbuf, 4 * j + 3); }
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -609,6 +616,7 @@ __device__ __forceinline__ void wgrad_one(WgArgsC& args, float* lds, const int v
       case 4 * 8 + 4: wgrad_disp_bf3<4, 4>(a, jb, lds, vb); return;
       case 4 * 8 + 2: wgrad_disp_bf3<4, 2>(a, jb, lds, vb); return;
       case 2 * 8 + 4: wgrad_disp_bf3<2, 4>(a, jb, lds, vb); return;
+      case 2 * 8 + 2: wgrad_disp_bf3<2, 2>(a, jb, lds, vb); return;
       default: break;
     }
   }
@@ -786,7 +794,11 @@ bool add_net_jobs(const NetGeom& g, int netidx, const float* stash, const float*
     if (best_gk == 0 || best_an == 3 || best_ak == 3 || ntn > 8 || ntk > 8 || nj >= MAX_WG_JOBS) { ok = false; return; }
     // the opt-in bf16x3 body takes the wide GEMMs (>= 8 tiles per wave: 86 % of the MACs at D=8/W=256) whose two slab buffers
     // fit the LDS; the narrow ones (heads, gamma columns) stay exact fp32 in the same grid
-    const bool wide = (best_an == 4 && best_ak == 4) || (best_an == 4 && best_ak == 2) || (best_an == 2 && best_ak == 4);
+    // (round 5: + the 2 x 2 jobs — the two 256 x 63 GEMMs of the encoding columns, 62 % of the narrow GEMMs' CU time; CNERF_BF3_NARROW=0
+    //  keeps them exact fp32 as in round 4, for the A/B measurement)
+    static const bool narrow22 = !(getenv("CNERF_BF3_NARROW") && atoi(getenv("CNERF_BF3_NARROW")) == 0);
+    const bool wide = (best_an == 4 && best_ak == 4) || (best_an == 4 && best_ak == 2) || (best_an == 2 && best_ak == 4) ||
+                      (narrow22 && best_an == 2 && best_ak == 2);
     const bool fits = 2 * (4 * ntn + 4 * ntk) * OCTF <= LDS_FLOATS;
     a.job[nj++] = WgJob{netidx, xcol, ycol, N, K, n_lo, tensor, ld, col0, bias_tensor, best_gk ? best_gk : 2, best_an,
                         best_ak, 1, 0, 0, (bf3 && wide && fits) ? 1 : 0};

@@ -93,6 +93,15 @@ beside it.  D2000 is criterion D16's design at a 13x longer horizon:
           mean held-out PSNR of the two populations at 2 000 steps and the smallest effect the test could have detected (the 97.5th
           percentile of |B_perm| at each milestone) — a PASS with a detectable effect of several dB would say little.
           A FAIL is a fail; DESIGN.md states the outcome in one line.
+
+Round 5, extension D2000-bf16x3 (written and committed BEFORE any of its runs; at this point phase 1 of D2000 — the oracle twins — is
+running and no HIP run at this horizon exists in either arithmetic).  The same criterion, statistics, seeds, draws, milestones and
+Bonferroni level as D2000, evaluated a second time with the HIP runs in the opt-in bf16x3 training arithmetic
+(CNERF_TRAIN_PRECISION=bf16x3: the MLP GEMMs of the step that have a bf16x3 kernel on three bf16 planes per operand, 6 cross terms, fp32
+accumulation; the heads and the 128 x 27 view-direction GEMM of the weight gradients stay exact fp32) against
+the SAME oracle file (profiles/r05_psnr_oracle_aten_gpu_2000.npz).  Reported as profiles/r05_psnr_parity_2000_bf16x3.json next to the
+fp32 verdict; it carries the second bench line's "fp32-equivalent" claim at the convergence horizon and nothing else (the headline
+stays exact fp32).  A FAIL is a fail.
 """
 import argparse
 import json
