@@ -108,6 +108,7 @@ SIGNATURES = {
     "cnerf_closs_ws_floats": (_i64, [_i64]),
     "cnerf_composite_fwd_closs": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i64, _i, _i, _ClossP, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cnerf_closs_finish": (_i, [C.POINTER(ClossTail), _vp, _vp, _vp, _vp]),
+    "cnerf_closs_finish_ss": (_i, [C.POINTER(ClossTail), C.POINTER(C.c_int32), _vp, _vp, _vp]),
     "cnerf_composite_bwd_closs": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i64, _i, _i, _ClossP, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _i64,
                                        _vp, _vp]),
     "cnerf_sample_pixels": (_i, [C.POINTER(PixelBatch), _vp, _RngP, _vp, C.POINTER(_vp), _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -191,6 +191,8 @@ struct ClossTail {
   float* patch_d[2];         // [P * n] per level or nullptr
   float* terms;              // [8]: loss, img_loss, depth_loss, patch_loss, img_loss0, depth_loss0, patch_loss0, -
   float* stats;              // [2][4]: w1, w0, wd, - per level
+  int ss;                    // 1: the in-loop consistency step's primary terms (VT:941-969), per-term coins below
+  int coin[4];               // rgb, depth, rgb0, depth0: 1 = the term over the selected rays (mask == 1), 0 = the reference's other branch
 };
 
 __global__ __launch_bounds__(T) void closs_tail_k(ClossTail a) {
@@ -214,6 +216,45 @@ __global__ __launch_bounds__(T) void closs_tail_k(ClossTail a) {
   }
   __syncthreads();
   if (threadIdx.x != 0) return;
+  if (a.ss) {
+    // VT:941-969 — the primary render's terms under `--ss_loss`, mask = the rays `[mask_bound][mask]` selects (cnerf_ss_ref_rays'
+    // `sel`), each term behind its own random.randint(0, 1) coin:
+    //   img_loss  = coin ? img2mse(rgb[sel], target[sel])      : img2mse(rgb, target)                       (:942)
+    //   depth     = coin ? img2mse(depth[sel], prior[sel])      : 0                     (un-normalised: far = 1)   (:950-952)
+    //   img_loss0 = coin ? img2mse(rgb0[sel], target[sel])      : img2mse(rgb, target)  (the FINE rgb: the reference's line :959)
+    //   depth0    = coin ? img2mse(depth0[sel], prior[sel])     : 0                                          (:966-968)
+    // accumulated in that order (loss += each).  The fallback of :959 sends its gradient to the fine level's colours.
+    const double s1 = tot[0][0], s0 = tot[0][1], N1 = tot[0][3], Nall = tot[0][3] + tot[0][4];
+    const float plain = (float)((s1 + s0) / (3.0 * Nall));
+    const float wall = (float)(2.0 / (3.0 * Nall)), wsel = (float)(2.0 / (3.0 * N1));
+    const float il = a.coin[0] ? (float)(s1 / (3.0 * N1)) : plain;
+    float w1 = a.coin[0] ? wsel : wall, w0 = a.coin[0] ? 0.f : wall;
+    float loss = il, dl = 0.f;
+    const bool dep = a.has_depth && a.coin[1];
+    if (dep) { dl = (float)(tot[0][2] / N1); loss = loss + dl; }
+    a.terms[1] = il; a.terms[2] = dl; a.terms[3] = 0.f;
+    a.stats[2] = dep ? (float)(2.0 / N1) / a.far : 0.f;
+    a.stats[3] = 0.f;
+    a.terms[4] = a.terms[5] = a.terms[6] = 0.f;
+    if (levels == 2) {
+      const double N1c = tot[1][3];
+      const float il0 = a.coin[2] ? (float)(tot[1][0] / (3.0 * N1c)) : plain;
+      loss = loss + il0;
+      float dl0 = 0.f;
+      const bool dep0 = a.has_depth && a.coin[3];
+      if (dep0) { dl0 = (float)(tot[1][2] / N1c); loss = loss + dl0; }
+      a.terms[4] = il0; a.terms[5] = dl0;
+      a.stats[4] = a.coin[2] ? (float)(2.0 / (3.0 * N1c)) : 0.f;
+      a.stats[5] = 0.f;
+      a.stats[6] = dep0 ? (float)(2.0 / N1c) / a.far : 0.f;
+      a.stats[7] = 0.f;
+      if (!a.coin[2]) { w1 += wall; w0 += wall; }
+    }
+    a.stats[0] = w1; a.stats[1] = w0;
+    a.terms[0] = loss;
+    a.terms[7] = 0.f;
+    return;
+  }
   float loss = 0.f;
   for (int lv = 0; lv < levels; ++lv) {
     const double s1 = tot[lv][0], s0 = tot[lv][1], sd = tot[lv][2];
@@ -409,7 +450,8 @@ extern "C" int cnerf_patch_depth_loss(const float* depth_pred, const float* mono
   return CNERF_OK;
 }
 
-extern "C" int cnerf_closs_finish(const cnerf_closs_sum* t, float* terms, float* stats, float* patch_d, void* stream) {
+namespace {
+int closs_finish_impl(const cnerf_closs_sum* t, const int32_t* ss_coins, float* terms, float* stats, float* patch_d, void* stream) {
   if (!t || !terms || !stats || !t->ws_last || t->B <= 0 || t->P < 0 || t->P > 8 || (t->P > 0 && (t->n <= 0 || !t->mono || !t->depth_last)) ||
       (t->P > 0 && t->ws_coarse && !t->depth_coarse) || (t->has_depth && !(t->far > 0.f)) || (int64_t)t->P * t->n > t->B ||
       ((uintptr_t)t->ws_last & 7) != 0 || ((uintptr_t)t->ws_coarse & 7) != 0)
@@ -424,7 +466,20 @@ extern "C" int cnerf_closs_finish(const cnerf_closs_sum* t, float* terms, float*
   a.patch_d[0] = (patch_d && t->P > 0) ? patch_d : nullptr;
   a.patch_d[1] = (patch_d && t->P > 0 && t->ws_coarse) ? patch_d + (int64_t)t->P * t->n : nullptr;
   a.terms = terms; a.stats = stats;
+  a.ss = ss_coins ? 1 : 0;
+  for (int k = 0; k < 4; ++k) a.coin[k] = ss_coins ? (ss_coins[k] != 0) : 0;
   hipLaunchKernelGGL(closs_tail_k, dim3(1), dim3(T), 0, cn_stream(stream), a);
   CN_CHECK_LAUNCH();
   return CNERF_OK;
+}
+}  // namespace
+
+extern "C" int cnerf_closs_finish(const cnerf_closs_sum* t, float* terms, float* stats, float* patch_d, void* stream) {
+  return closs_finish_impl(t, nullptr, terms, stats, patch_d, stream);
+}
+
+extern "C" int cnerf_closs_finish_ss(const cnerf_closs_sum* t, const int32_t* coins4, float* terms, float* stats, void* stream) {
+  // (no patch term and no sharded counts in this mode: the reference's block has neither)
+  if (!coins4 || !t || t->P != 0 || t->counts) return CNERF_E_ARG;
+  return closs_finish_impl(t, coins4, terms, stats, nullptr, stream);
 }

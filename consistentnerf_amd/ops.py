@@ -597,6 +597,7 @@ class ClossSpec:
     P: int = 0
     n: int = 256
     counts: Optional[Tensor] = None
+    ss_coins: Optional[tuple] = None      # (rgb, depth, rgb0, depth0) draws of VT:941-969: the in-loop consistency step's primary terms
 
     def c(self) -> Closs:
         return Closs(self.target.data_ptr(), None if self.mask is None else self.mask.data_ptr(),
@@ -615,8 +616,11 @@ class ClossSpec:
         P = int(self.P) if mono is not None else 0
         if P > 0 and (mono.numel() < P * self.n or P * self.n > B or P > 8):
             raise CnerfError(f"closs: the patch term needs P <= 8 patches of n rays inside the batch (P={P}, n={self.n}, B={B})")
+        coins = None if self.ss_coins is None else tuple(int(bool(c)) for c in self.ss_coins)
+        if coins is not None and (len(coins) != 4 or P > 0 or self.counts is not None or m is None):
+            raise CnerfError("closs: ss_coins takes 4 draws, a selection mask, no patch term and no global counts")
         return ClossSpec(t, m, pr, float(self.far), float(self.coef), float(self.rgb_w), float(self.depth_w), float(self.patch_w),
-                         mono, P, int(self.n), _chk(self.counts, "counts"))
+                         mono, P, int(self.n), _chk(self.counts, "counts"), coins)
 
 
 def composite_forward_closs(raw: Tensor, z: Tensor, rays: Tensor, noise: Optional[Tensor], white_bkgd: bool, L: ClossSpec):
@@ -647,7 +651,11 @@ def closs_finish(L: ClossSpec, B: int, ws_last: Tensor, ws_coarse: Optional[Tens
     t = ClossTail(a(ws_last), a(ws_coarse), int(B), a(L.counts), L.coef, L.far, L.rgb_w, L.depth_w, L.patch_w,
                   int(L.prior is not None), a(depth_last) if L.P > 0 else None,
                   a(depth_coarse) if (L.P > 0 and levels == 2) else None, a(L.mono) if L.P > 0 else None, L.P, L.n)
-    _lib.check(_lib.load().cnerf_closs_finish(C.byref(t), _p(terms), _p(stats), _p(patch_d), _stream()), "cnerf_closs_finish")
+    if L.ss_coins is not None:
+        coins = (C.c_int32 * 4)(*L.ss_coins)
+        _lib.check(_lib.load().cnerf_closs_finish_ss(C.byref(t), coins, _p(terms), _p(stats), _stream()), "cnerf_closs_finish_ss")
+    else:
+        _lib.check(_lib.load().cnerf_closs_finish(C.byref(t), _p(terms), _p(stats), _p(patch_d), _stream()), "cnerf_closs_finish")
     return terms, stats, patch_d
 
 

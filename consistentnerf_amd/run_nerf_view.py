@@ -218,7 +218,7 @@ def _render_loss_lines(H, W, K, target_s, mask, depth_prior, chunk, rays, coef, 
 
 
 def render_loss(H, W, K, target_s, mask=None, depth_prior=None, chunk=1024 * 32, rays=None, hardmask_coef=0.2, depth_far=None,
-                rgb_w=1.0, depth_w=1.0, mono=None, patch_num=4, patch_size=16, patch_w=0.001, counts=None, **kwargs):
+                rgb_w=1.0, depth_w=1.0, mono=None, patch_num=4, patch_size=16, patch_w=0.001, counts=None, _ss_coins=None, **kwargs):
     """The loss of one run_nerf_view.train() step as ONE call (V:1636-1865 with the terms this package builds):
 
         rgb, disp, acc, depth_pred, extras = render(H, W, K, chunk=, rays=batch_rays, retraw=True, **render_kwargs_train)
@@ -241,6 +241,17 @@ def render_loss(H, W, K, target_s, mask=None, depth_prior=None, chunk=1024 * 32,
     ok = (rays is not None and 0 < n <= chunk and tgt is not None and tgt.is_cuda and tgt.dtype == torch.float32 and tgt.shape[0] == n
           and kwargs.get('c2w') is None and P <= 8 and P * ps2 <= n and not torch.is_tensor(kwargs.get('near'))
           and not torch.is_tensor(kwargs.get('far')))
+    if _ss_coins is not None:       # the in-loop consistency step's primary terms (ss_step_loss): VT:941-969 on render()'s maps
+        if not ok or mask is None:
+            rgb, disp, acc, depth, extras = render(H, W, K, chunk=chunk, rays=rays, **kwargs)
+            loss, il, il0 = ss_primary_losses(rgb, depth, extras, target_s, depth_prior, None, None,
+                                              with_depth_loss=depth_prior is not None, coins=_ss_coins_lines(_ss_coins, depth_prior is not None),
+                                              sel=mask)
+            return loss, dict(loss=loss.detach(), img_loss=il.detach(), img_loss0=None if il0 is None else il0.detach()), rgb, disp, acc, depth, extras
+        spec = ops.ClossSpec(tgt, mask, depth_prior, 1.0, 0.0, 1.0, 1.0, 0.0, None, 0, ps2, None, tuple(_ss_coins))
+        rgb, disp, acc, depth, extras = render(H, W, K, chunk=chunk, rays=rays, _target=spec, **kwargs)
+        loss, t = extras.pop('loss'), extras.pop('loss_terms')
+        return loss, {k: t[i] for i, k in enumerate(_TERM_NAMES)}, rgb, disp, acc, depth, extras
     if not ok:
         return _render_loss_lines(H, W, K, target_s, mask, depth_prior, chunk, rays, hardmask_coef, far, rgb_w, depth_w, mono, P,
                                   patch_size, patch_w, counts, kwargs)
@@ -252,20 +263,9 @@ def render_loss(H, W, K, target_s, mask=None, depth_prior=None, chunk=1024 * 32,
 
 
 # ----------------------------------------------------------------------------- in-loop consistency (a15)
-def ss_consistency(rays_o, rays_d, depth_cas_s, pose_ref, K, image_ref, depth_ref, H, W, render_kwargs, chunk=1024 * 32,
-                   occlusion_threshold=0.1, with_depth_loss=False):
-    """The `args.ss_loss` block of run_nerf_view_test.train() (VT:905-938): the batch's depth-prior points
-    `rays_o + depth_cas_s * rays_d` are warped into the reference view (`get_ref_rays`, VT variant), the in-bounds ones
-    define rays of the reference camera through the snapped pixels; those rays are rendered (a second full render pass)
-    and compared with the reference view's colours (and depth prior).  The occlusion mask |z_ref_cam - D_ref| < thr uses
-    the reference's doubling rule (thr = occlusion_threshold * 2^k, smallest k that lets some point pass) evaluated on
-    the device — the reference's `while mask.sum() == 0` loop costs a host sync per iteration.
-
-    rays_o, rays_d [N, 3], depth_cas_s [N], pose_ref [3, 4] (c2w), image_ref [H, W, 3], depth_ref [H, W].
-    Returns a dict: loss (the four VT:930-938 terms), mask_bound [1, N], mask [M, 1], sel [N] (1.0 where mask_bound AND the
-    occlusion mask hold: the selection `x[mask_bound][mask]` as a ray weight, for ss_primary_losses), threshold (0-d tensor, the one
-    that produced `mask`), batch_rays_ref [2, M, 3], rgb_target_ref [1, 3, M], rays_depth_ref [1, 1, M], and the second
-    render's rgb_ref, depth_pred_ref, extras_ref."""
+def _ss_rays(rays_o, rays_d, depth_cas_s, pose_ref, K, image_ref, depth_ref, H, W, render_kwargs, occlusion_threshold):
+    """VT:905-925 as ONE launch (ops.ss_ref_rays) + one 16-byte read-back -> the dictionary ss_consistency returns, minus the
+    second render."""
     dev = rays_o.device
     c2w_ref = torch.eye(4)
     c2w_ref[:3, :4] = torch.as_tensor(np.asarray(pose_ref.cpu() if isinstance(pose_ref, torch.Tensor) else pose_ref),
@@ -273,9 +273,9 @@ def ss_consistency(rays_o, rays_d, depth_cas_s, pose_ref, K, image_ref, depth_re
     w2c_ref = torch.inverse(c2w_ref)                       # 4x4 on the host, as VT:910
     img = torch.as_tensor(image_ref, dtype=torch.float32).to(dev)
     dep = torch.as_tensor(depth_ref, dtype=torch.float32).to(dev)
-    # ONE launch for VT:905-925 (round 5, second half): the warp, the compaction of the in-bounds points (`x[mask]` in the reference:
-    # a host sync per boolean index), the reference rays + the rows render() packs from them, the gathered colours / depth priors,
-    # |z - D_ref|, the doubling rule's threshold and both masks; one 16-byte read-back (the second render's ray count)
+    # the warp, the compaction of the in-bounds points (`x[mask]` in the reference: a host sync per boolean index), the reference
+    # rays + the rows render() packs from them, the gathered colours / depth priors, |z - D_ref|, the doubling rule's threshold and
+    # both masks
     near, far = render_kwargs.get('near', 0.), render_kwargs.get('far', 1.)
     vd, ndc = bool(render_kwargs.get('use_viewdirs', False)), bool(render_kwargs.get('ndc', True))
     scalar_bounds = not (torch.is_tensor(near) or torch.is_tensor(far))
@@ -290,20 +290,42 @@ def ss_consistency(rays_o, rays_d, depth_cas_s, pose_ref, K, image_ref, depth_re
         from .raybank import PackedRays
         batch_rays_ref._cnerf_packed = PackedRays(o["rows"], H, W, K[0][0], near, far, vd, ndc)
     tgt = o["target"]
-    rgb_target_ref = tgt.t()[None]                         # [1, 3, M] like img[:, :, yi, xi] (a view)
-    rays_depth_ref = o["depth_tgt"][None, None]            # [1, 1, M]
-    mask_bound = o["inb"].view(torch.bool)[None]
-    mask = o["mask"].view(torch.bool)[:, None]
-    thr = torch.tensor(o["thr"], dtype=torch.float32)
-    # the second render + its loss terms (VT:927-938): img2mse(rgb_ref, tgt) [+ img2mse(depth_pred_ref, rays_depth_ref)] on both
-    # levels = render_loss with no mask, un-normalised depths (far 1) and unit weights: every term rides in the compositing launches
-    loss, _terms, rgb_ref, disp_ref, acc_ref, depth_pred_ref, extras_ref = render_loss(
-        H, W, K, tgt, mask=None, depth_prior=o["depth_tgt"] if with_depth_loss else None, chunk=chunk,
-        rays=batch_rays_ref, hardmask_coef=0.0, depth_far=1.0, rgb_w=1.0, depth_w=1.0, mono=None, **dict(render_kwargs, retraw=True))
-    return dict(loss=loss, mask_bound=mask_bound, mask=mask, threshold=thr, batch_rays_ref=batch_rays_ref, sel=o["sel"],
-                rgb_target_ref=rgb_target_ref, rays_depth_ref=rays_depth_ref, rgb_ref=rgb_ref,
-                depth_pred_ref=depth_pred_ref, extras_ref=extras_ref)
+    return dict(mask_bound=o["inb"].view(torch.bool)[None], mask=o["mask"].view(torch.bool)[:, None], sel=o["sel"],
+                threshold=torch.tensor(o["thr"], dtype=torch.float32), batch_rays_ref=batch_rays_ref,
+                rgb_target_ref=tgt.t()[None],                      # [1, 3, M] like img[:, :, yi, xi] (a view)
+                rays_depth_ref=o["depth_tgt"][None, None],         # [1, 1, M]
+                _tgt=tgt, _depth_tgt=o["depth_tgt"])
 
+
+def _ss_second_render(info, H, W, K, render_kwargs, chunk, with_depth_loss):
+    """The second render + its loss terms (VT:927-938): img2mse(rgb_ref, tgt) [+ img2mse(depth_pred_ref, rays_depth_ref)] on both
+    levels = render_loss with no mask, un-normalised depths (far 1) and unit weights: every term rides in the compositing launches."""
+    loss, _terms, rgb_ref, disp_ref, acc_ref, depth_pred_ref, extras_ref = render_loss(
+        H, W, K, info["_tgt"], mask=None, depth_prior=info["_depth_tgt"] if with_depth_loss else None, chunk=chunk,
+        rays=info["batch_rays_ref"], hardmask_coef=0.0, depth_far=1.0, rgb_w=1.0, depth_w=1.0, mono=None,
+        **dict(render_kwargs, retraw=True))
+    info.update(rgb_ref=rgb_ref, depth_pred_ref=depth_pred_ref, extras_ref=extras_ref)
+    return loss
+
+
+def ss_consistency(rays_o, rays_d, depth_cas_s, pose_ref, K, image_ref, depth_ref, H, W, render_kwargs, chunk=1024 * 32,
+                   occlusion_threshold=0.1, with_depth_loss=False):
+    """The `args.ss_loss` block of run_nerf_view_test.train() (VT:905-938): the batch's depth-prior points
+    `rays_o + depth_cas_s * rays_d` are warped into the reference view (`get_ref_rays`, VT variant), the in-bounds ones
+    define rays of the reference camera through the snapped pixels; those rays are rendered (a second full render pass)
+    and compared with the reference view's colours (and depth prior).  The occlusion mask |z_ref_cam - D_ref| < thr uses
+    the reference's doubling rule (thr = occlusion_threshold * 2^k, smallest k that lets some point pass) evaluated on
+    the device — the reference's `while mask.sum() == 0` loop costs a host sync per iteration.  Round 5: everything in front of
+    the second render is ONE launch (cnerf_ss_ref_rays) and one 16-byte read-back.
+
+    rays_o, rays_d [N, 3], depth_cas_s [N], pose_ref [3, 4] (c2w), image_ref [H, W, 3], depth_ref [H, W].
+    Returns a dict: loss (the four VT:930-938 terms), mask_bound [1, N], mask [M, 1], sel [N] (1.0 where mask_bound AND the
+    occlusion mask hold: the selection `x[mask_bound][mask]` as a ray weight, for ss_primary_losses), threshold (0-d tensor, the one
+    that produced `mask`), batch_rays_ref [2, M, 3], rgb_target_ref [1, 3, M], rays_depth_ref [1, 1, M], and the second
+    render's rgb_ref, depth_pred_ref, extras_ref."""
+    info = _ss_rays(rays_o, rays_d, depth_cas_s, pose_ref, K, image_ref, depth_ref, H, W, render_kwargs, occlusion_threshold)
+    info["loss"] = _ss_second_render(info, H, W, K, render_kwargs, chunk, with_depth_loss)
+    return info
 
 
 def ss_primary_losses(rgb, depth_pred, extras, target_s, depth_cas_s, mask_bound, mask, with_depth_loss=False, coins=None,
@@ -320,14 +342,15 @@ def ss_primary_losses(rgb, depth_pred, extras, target_s, depth_cas_s, mask_bound
     `sel=ss_consistency(...)['sel']` to take the one its launch wrote instead of re-deriving it from the two masks."""
     import random
     draw = (lambda: random.randint(0, 1)) if coins is None else iter(list(coins)).__next__
-    mb, mk = mask_bound.reshape(-1).bool(), mask.reshape(-1).bool()
     if sel is not None:    # ss_consistency's own launch already formed it (`sel` of its result)
         sel = sel.reshape(-1).to(torch.float32)
-    elif mk.numel() == 0:
-        sel = torch.zeros(mb.shape, device=rgb.device, dtype=torch.float32)
-    else:   # sel[i] = mask_bound[i] and mask[rank of i among the in-bounds rays]
-        pos = (torch.cumsum(mb.long(), 0) - 1).clamp_(min=0, max=mk.numel() - 1)
-        sel = (mb & mk[pos]).to(torch.float32)
+    else:
+        mb, mk = mask_bound.reshape(-1).bool(), mask.reshape(-1).bool()
+        if mk.numel() == 0:
+            sel = torch.zeros(mb.shape, device=rgb.device, dtype=torch.float32)
+        else:   # sel[i] = mask_bound[i] and mask[rank of i among the in-bounds rays]
+            pos = (torch.cumsum(mb.long(), 0) - 1).clamp_(min=0, max=mk.numel() - 1)
+            sel = (mb & mk[pos]).to(torch.float32)
 
     def masked(c, d):      # (masked rgb mse, masked depth mse) of one level in one launch
         return hardmask_losses(c, target_s, sel, 0.0, d, depth_cas_s if d is not None else None, 1.0)
@@ -349,3 +372,39 @@ def ss_primary_losses(rgb, depth_pred, extras, target_s, depth_cas_s, mask_bound
         if c_dep0:
             loss = loss + lm0[1]
     return loss, img_loss, img_loss0
+
+
+def _ss_coins_lines(coins4, with_depth):
+    """(rgb, depth, rgb0, depth0) -> the draws in ss_primary_losses' call order."""
+    c = [int(bool(x)) for x in coins4]
+    return c if with_depth else [c[0], c[2]]
+
+
+def ss_step_loss(H, W, K, batch_rays, target_s, depth_cas_s, pose_ref, image_ref, depth_ref, render_kwargs, chunk=1024 * 32,
+                 occlusion_threshold=0.1, with_depth_loss=False, coins=None):
+    """The whole loss of one `--ss_loss` step of run_nerf_view_test.train() (VT:899-969) as ONE call, at the standard of
+    render_loss: the warp / compaction / reference-ray launch FIRST (it depends on the batch only), then the primary render with its
+    terms — each behind its `random.randint(0, 1)` coin, restricted to the rays `[mask_bound][mask]` — folded into its compositing
+    launches (mask = the launch's `sel`; cnerf_closs_finish_ss), then the second render on the warped rays with its four terms
+    folded the same way.  coins = (rgb, depth, rgb0, depth0) or None to draw them here with `random.randint` in the reference's
+    order (two draws without the depth loss).  -> (loss, info): info carries ss_consistency's dictionary (`mask_bound`, `mask`,
+    `sel`, `threshold`, `batch_rays_ref`, the second render's maps) plus the primary render's `rgb`, `disp`, `acc`, `depth_pred`,
+    `extras`, `img_loss`, `img_loss0` and the two partial losses `loss_primary`, `loss_ref`.
+    Values: the reference's lines up to summation order (the loss adds the second render's terms first there; here last)."""
+    import random
+    rays_o, rays_d = batch_rays[0], batch_rays[1]
+    info = _ss_rays(rays_o, rays_d, depth_cas_s, pose_ref, K, image_ref, depth_ref, H, W, render_kwargs, occlusion_threshold)
+    if coins is None:
+        c_rgb = random.randint(0, 1)
+        c_dep = random.randint(0, 1) if with_depth_loss else 0
+        c_rgb0 = random.randint(0, 1) if render_kwargs.get('N_importance', 0) > 0 else 0
+        c_dep0 = random.randint(0, 1) if (with_depth_loss and render_kwargs.get('N_importance', 0) > 0) else 0
+        coins = (c_rgb, c_dep, c_rgb0, c_dep0)
+    lp, terms, rgb, disp, acc, depth, extras = render_loss(
+        H, W, K, target_s, mask=info["sel"], depth_prior=depth_cas_s.reshape(-1) if with_depth_loss else None, chunk=chunk,
+        rays=batch_rays, depth_far=1.0, mono=None, _ss_coins=tuple(coins), **dict(render_kwargs, retraw=True))
+    ls = _ss_second_render(info, H, W, K, render_kwargs, chunk, with_depth_loss)
+    loss = ls + lp
+    info.update(loss=loss, loss_primary=lp, loss_ref=ls, rgb=rgb, disp=disp, acc=acc, depth_pred=depth, extras=extras,
+                img_loss=terms.get("img_loss"), img_loss0=terms.get("img_loss0"), coins=tuple(coins))
+    return loss, info

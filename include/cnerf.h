@@ -22,7 +22,7 @@ extern "C" {
 #endif
 
 #define CNERF_ABI_VERSION 5   /* 5: + cnerf_ss_ref_rays (the in-loop consistency block's warp / compaction / reference rays / occlusion mask as one
-                                * launch); every v4 entry point unchanged.   4: + cnerf_sample_pixels (one-launch training batch of an image), the ConsistentNeRF losses folded into
+                                * launch), cnerf_closs_finish_ss (its primary terms folded into compositing); every v4 entry point unchanged.   4: + cnerf_sample_pixels (one-launch training batch of an image), the ConsistentNeRF losses folded into
                                 * compositing (cnerf_closs, *_closs, cnerf_closs_finish); cnerf_masked_loss uses its workspace for
                                 * batches > 16384 rays; every v3 entry point unchanged.   3: + in-kernel uniform streams (cnerf_rng, *_rng) and compositing with img2mse folded in (*_mse);
                                 * every v2 entry point unchanged.   2: cnerf_adam_step takes its hyper-parameters as double; the *_pair, *_cam, *_bf entry points */
@@ -255,6 +255,14 @@ int cnerf_composite_fwd_closs(const float* raw, int raw_ch, const float* z, cons
                               int64_t B, int S, int white_bkgd, const cnerf_closs* L, float* rgb, float* disp, float* acc,
                               float* depth, float* weights, float* workspace, void* stream);
 int cnerf_closs_finish(const cnerf_closs_sum* t, float* terms, float* stats, float* patch_d, void* stream);
+/* The same tail for the PRIMARY render of the in-loop consistency step (run_nerf_view_test.py:941-969): the levels' compositing
+ * launches ran with mask = cnerf_ss_ref_rays' `sel` (the rays `x[mask_bound][mask]` selects), prior = the batch's depth priors and
+ * far = 1; coins4 = the four random.randint(0, 1) draws in the reference's order (rgb, depth, rgb0, depth0): a term is the mean over
+ * the selected rays when its coin is 1, else img2mse(rgb, target_s) for the two colour terms (ALSO for the coarse one: the
+ * reference's line :959 falls back to the FINE rgb; its gradient goes to the fine level's seed weights) and absent for the depth
+ * terms; loss = img_loss + depth + img_loss0 + depth0 in that order.  terms / stats as cnerf_closs_finish (no patch term, no
+ * global counts: P must be 0, counts NULL). */
+int cnerf_closs_finish_ss(const cnerf_closs_sum* t, const int32_t* coins4, float* terms, float* stats, void* stream);
 int cnerf_composite_bwd_closs(const float* raw, int raw_ch, const float* z, const float* rays, int ray_stride, const float* noise,
                               int64_t B, int S, int white_bkgd, const cnerf_closs* L, const float* rgb, const float* depth,
                               const float* stats, const float* g_loss, float rgb_w, float depth_w, float patch_w,

@@ -1333,6 +1333,66 @@ def test_ss_ref_rays_one_launch_equals_the_lines(dev, N, thr0, ndc):
     assert torch.equal(o["rows"], rows)
 
 
+@pytest.mark.parametrize("coins,with_depth", [((1, 1, 1, 1), True), ((0, 0, 0, 0), True), ((1, 0, 0, 1), True), ((0, 1, 1, 0), True),
+                                              ((1, 1, 0, 0), True), ((1, 0, 1, 0), False), ((0, 0, 0, 0), False)])
+def test_ss_step_loss_one_call_equals_the_lines(dev, coins, with_depth):
+    """run_nerf_view.ss_step_loss (VT:899-969 as one call: the primary render's four coin-gated terms folded into its compositing
+    launches through cnerf_closs_finish_ss, the second render's folded as before) against the same step written as the
+    reference's lines — render, ss_consistency, ss_primary_losses (masked-loss / img2mse launches + autograd) — on the `ssloss`
+    fixture's scene and networks: loss 2e-6 relative, every parameter gradient 2e-6 of the tensor's largest (the folded form sums
+    per-workgroup fp64 partials and merges the coarse colour term's fallback into one seed weight: summation order only), incl.
+    the reference's fallback of the COARSE colour term to the FINE rgb (coin 0, VT:959)."""
+    from consistentnerf_amd import run_nerf_view as V
+    g = golden("ssloss")
+    Hh, Ww, far = 32, 40, 7.0
+    K, poses = g["K"], g["poses"]
+    ro, rd = O.get_rays_np(Hh, Ww, K, poses[0][:3, :4])
+    coarse, _ = make_model(4, 128, True, 5, 31, dev)
+    fine, _ = make_model(4, 128, True, 5, 32, dev)
+    kw = _kwargs(coarse, fine, 16, 16, 0.0, False, 0.0, False)
+    kw.update(near=2.0, far=far, ndc=False, use_viewdirs=True)
+    sel, r = g["a.sel"], int(g["a.ref_index"])
+    rays = torch.stack([T(ro.reshape(-1, 3)[sel], dev), T(rd.reshape(-1, 3)[sel], dev)], 0)
+    tgt = T(g["images"][0].reshape(-1, 3)[sel].astype(np.float32), dev)
+    prior = T(g["depths"][0].reshape(-1)[sel], dev)
+    params = [p for m in (coarse, fine) for p in m.parameters()]
+
+    def grads():
+        out = [None if p.grad is None else p.grad.detach().clone() for p in params]
+        for p in params:
+            p.grad = None
+        return out
+
+    rgb, disp, acc, depth, extras = V.render(Hh, Ww, K, chunk=4096, rays=rays, retraw=True, **kw)
+    ss = V.ss_consistency(rays[0], rays[1], prior, poses[r], K, g["images"][r], g["depths"][r], Hh, Ww, kw, chunk=4096,
+                          occlusion_threshold=0.1, with_depth_loss=with_depth)
+    lines_coins = list(coins) if with_depth else [coins[0], coins[2]]
+    lp, il, il0 = V.ss_primary_losses(rgb, depth, extras, tgt, prior, ss["mask_bound"], ss["mask"], with_depth_loss=with_depth,
+                                      coins=lines_coins)
+    loss_l = ss["loss"] + lp
+    loss_l.backward()
+    g_l = grads()
+    loss_o, info = V.ss_step_loss(Hh, Ww, K, rays, tgt, prior, poses[r], g["images"][r], g["depths"][r], kw, chunk=4096,
+                                  occlusion_threshold=0.1, with_depth_loss=with_depth, coins=coins)
+    loss_o.backward()
+    g_o = grads()
+    assert torch.equal(info["mask"], ss["mask"]) and torch.equal(info["sel"], ss["sel"])
+    assert torch.equal(info["rgb"], rgb) and torch.equal(info["depth_pred"], depth) and torch.equal(info["rgb_ref"], ss["rgb_ref"])
+    ll, lo = loss_l.item(), loss_o.item()
+    print(f"  coins {coins}: loss lines {ll:.8f} one call {lo:.8f}; img_loss {il.item():.8f} / {info['img_loss'].item():.8f}")
+    assert abs(lo - ll) <= 2e-6 * abs(ll)
+    assert abs(info["img_loss"].item() - il.item()) <= 2e-6 * abs(il.item())
+    assert abs(info["img_loss0"].item() - il0.item()) <= 2e-6 * abs(il0.item())
+    assert abs(info["loss_ref"].item() - ss["loss"].item()) <= 1e-7 * abs(ss["loss"].item())
+    worst = 0.0
+    for a, b in zip(g_l, g_o):
+        assert (a is None) == (b is None)
+        if a is not None:
+            worst = max(worst, (a - b).abs().max().item() / max(a.abs().max().item(), 1e-30))
+    print(f"  worst relative gradient difference {worst:.2e}")
+    assert worst <= 2e-6
+
+
 def test_in_loop_consistency_golden(dev):
     """a15 (VT:905-938): warp of the batch's depth-prior points into a reference view, occlusion threshold doubling,
     second render on the warped rays, the four loss terms and their weight gradients — against the reference's own
