@@ -361,6 +361,34 @@ def get_ref_rays(w2c: Tensor, c2w: Tensor, K: Tensor, P: Tensor, img: Tensor, de
     return rgb_ref, depth_ref, (Xc[inb] if masked_points else Xc), rays_o, rays_d, inb
 
 
+def ss_block(rays_o: Tensor, rays_d: Tensor, depth_cas_s: Tensor, c2w_ref: Tensor, K: Tensor, img: Tensor, depth: Tensor,
+             occlusion_threshold: float = 0.1):
+    """The `args.ss_loss` block in front of the second render (run_nerf_view_test.py VT:905-925): the batch's depth-prior points
+    (VT:905) -> get_ref_rays of the VT variant (no axis flip, masked points, VT:451-501) -> the occlusion mask with the threshold
+    doubled until one point passes (VT:921-925).  img [3,H,W], depth [H,W], c2w_ref [3,4].  Returns a dict: mask_bound [1,N],
+    mask [M,1], thr (the threshold that produced the mask), thr_next (the variable's value when the loop exits: 2 thr),
+    rays_ref [2,M,3], rgb_target_ref [1,3,M], rays_depth_ref [1,1,M], sel [N] (float: the rays `x[mask_bound][mask]` selects,
+    VT:941-969).  M = 0 loops forever in the reference; here it raises."""
+    P = rays_o + depth_cas_s[:, None] * rays_d
+    c2w = torch.eye(4)
+    c2w[:3, :4] = c2w_ref[:3, :4]
+    w2c = torch.inverse(c2w)
+    rgb_ref, depth_ref, Xc_m, ro, rd, inb = get_ref_rays(w2c, c2w, K, P, img, depth, flip=False, masked_points=True)
+    if ro.shape[0] == 0:
+        raise ValueError("no point of the batch projects into the reference view")
+    thr = float(occlusion_threshold)
+    mask = torch.ones(ro.shape[0], 1) < 0
+    thr_used = thr
+    while mask.sum() == 0:
+        diff = Xc_m[..., -1].unsqueeze(-1) - depth_ref.reshape(-1)[:, None]
+        mask = diff.abs() < thr
+        thr_used, thr = thr, 2 * thr
+    sel = torch.zeros(inb.shape[0])
+    sel[inb] = mask.reshape(-1).to(torch.float32)
+    return dict(mask_bound=inb[None], mask=mask, thr=thr_used, thr_next=thr, rays_ref=torch.stack([ro, rd], 0),
+                rgb_target_ref=rgb_ref[None], rays_depth_ref=depth_ref[None, None], sel=sel)
+
+
 # ----------------------------------------------------------------------------------------------
 # a13  hard-mask assembly                                                      V:994-1046
 # ----------------------------------------------------------------------------------------------

@@ -288,6 +288,31 @@ def test_train_10_steps_view_variant():
             assert np.abs(p.detach().reshape(-1)[::7].numpy() - g[f"final.{tag}.{k}.sub"]).max() <= 2e-5, (tag, k)
 
 
+def test_ss_block_golden():
+    """VT:905-925 (the in-loop consistency block in front of the second render) against the reference's own statements (`ssloss`):
+    masks and gathered targets exact, the exit value of the doubled threshold, the reference rays 1e-6 — for a threshold that
+    passes at once (a) and one that needs doublings (b)."""
+    g = golden("ssloss")
+    Hh, Ww = g["images"].shape[1:3]
+    ro, rd = O.get_rays_np(Hh, Ww, g["K"], g["poses"][0][:3, :4])
+    for tag, thr in (("a", 0.1), ("b", 1e-4)):
+        sel, r = g[tag + ".sel"], int(g[tag + ".ref_index"])
+        out = O.ss_block(T(ro.reshape(-1, 3)[sel]), T(rd.reshape(-1, 3)[sel]), T(g["depths"][0].reshape(-1)[sel]), T(g["poses"][r]),
+                         T(g["K"]), T(g["images"][r]).permute(2, 0, 1), T(g["depths"][r]), thr)
+        assert np.array_equal(out["mask_bound"].numpy(), g[tag + ".mask_bound"])
+        assert np.array_equal(out["mask"].numpy(), g[tag + ".mask"])
+        assert abs(out["thr_next"] - float(g[tag + ".thr_next"])) <= 1e-12 * float(g[tag + ".thr_next"])
+        if tag == "b":
+            assert out["thr"] > thr          # this case needs the doubling
+        assert np.array_equal(out["rgb_target_ref"].numpy(), g[tag + ".rgb_target_ref"])
+        assert np.array_equal(out["rays_depth_ref"].numpy(), g[tag + ".rays_depth_ref"])
+        close(out["rays_ref"], g[tag + ".rays_ref"], rtol=0, atol=1e-6)
+        mb, mk = g[tag + ".mask_bound"].reshape(-1), g[tag + ".mask"].reshape(-1)
+        want = np.zeros(mb.shape[0], np.float32)
+        want[mb] = mk
+        assert np.array_equal(out["sel"].numpy(), want)
+
+
 def test_ss_primary_losses():
     """VT:941-969: the coin-flip masked consumers of the in-loop consistency masks."""
     g = golden("ssloss_primary")
