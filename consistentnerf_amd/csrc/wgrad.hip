@@ -794,9 +794,10 @@ bool add_net_jobs(const NetGeom& g, int netidx, const float* stash, const float*
     if (best_gk == 0 || best_an == 3 || best_ak == 3 || ntn > 8 || ntk > 8 || nj >= MAX_WG_JOBS) { ok = false; return; }
     // the opt-in bf16x3 body takes the wide GEMMs (>= 8 tiles per wave: 86 % of the MACs at D=8/W=256) whose two slab buffers
     // fit the LDS; the narrow ones (heads, gamma columns) stay exact fp32 in the same grid
-    // (round 5: + the 2 x 2 jobs — the two 256 x 63 GEMMs of the encoding columns, 62 % of the narrow GEMMs' CU time; CNERF_BF3_NARROW=0
-    //  keeps them exact fp32 as in round 4, for the A/B measurement)
-    static const bool narrow22 = !(getenv("CNERF_BF3_NARROW") && atoi(getenv("CNERF_BF3_NARROW")) == 0);
+    // (round 5: the 2 x 2 jobs — the two 256 x 63 GEMMs of the encoding columns, 62 % of the narrow GEMMs' CU time — CAN take the
+    //  bf16x3 body (CNERF_BF3_NARROW=1).  Measured level: wgrad 5.97-6.01 ms with, 5.98-6.06 without (profiles/r05_bf3_narrow_ab.txt):
+    //  with two slab buffers these short jobs wait for their DMA whatever the arithmetic.  Default off: they stay exact fp32.)
+    static const bool narrow22 = getenv("CNERF_BF3_NARROW") && atoi(getenv("CNERF_BF3_NARROW")) != 0;
     const bool wide = (best_an == 4 && best_ak == 4) || (best_an == 4 && best_ak == 2) || (best_an == 2 && best_ak == 4) ||
                       (narrow22 && best_an == 2 && best_ak == 2);
     const bool fits = 2 * (4 * ntn + 4 * ntk) * OCTF <= LDS_FLOATS;

@@ -952,8 +952,14 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
         if _target is None:
             rgb_map, disp_map, acc_map, weights, depth_map = _CompositeFn.apply(raw, z_vals, rays, noise, bool(white_bkgd))
         elif isinstance(_target, ops.ClossSpec):
+            rc = raw_coarse
+            if _target.ss_coins is not None and not (_target.ss_coins[2] or (_target.prior is not None and _target.ss_coins[3])):
+                # VT:959 / VT:966 with both coarse coins 0: no term of this render depends on the coarse network (its colour term
+                # falls back to the FINE rgb, its depth term is absent) — as in the reference's graph, the coarse level then has no
+                # backward at all (left attached, its dgrad + wgrad would run on zero seeds: 16 % of the step for nothing)
+                rc = raw_coarse.detach()
             loss, terms, rgb_map, disp_map, acc_map, weights, depth_map = _RenderClossFn.apply(
-                raw, raw_coarse, z_vals, z_coarse, rays, noise, noise_coarse, bool(white_bkgd), _target, rgb_map_0, depth_map_0, ws_c)
+                raw, rc, z_vals, z_coarse, rays, noise, noise_coarse, bool(white_bkgd), _target, rgb_map_0, depth_map_0, ws_c)
         else:
             loss, rgb_map, disp_map, acc_map, weights, depth_map = _RenderLossFn.apply(
                 raw, raw_coarse, z_vals, z_coarse, rays, noise, noise_coarse, bool(white_bkgd), _target, rgb_map_0, loss_c)

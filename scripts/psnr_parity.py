@@ -98,7 +98,8 @@ Round 5, extension D2000-bf16x3 (written and committed BEFORE any of its runs; a
 running and no HIP run at this horizon exists in either arithmetic).  The same criterion, statistics, seeds, draws, milestones and
 Bonferroni level as D2000, evaluated a second time with the HIP runs in the opt-in bf16x3 training arithmetic
 (CNERF_TRAIN_PRECISION=bf16x3: the MLP GEMMs of the step that have a bf16x3 kernel on three bf16 planes per operand, 6 cross terms, fp32
-accumulation; the heads and the 128 x 27 view-direction GEMM of the weight gradients stay exact fp32) against
+accumulation; the narrow GEMMs of the weight gradients — heads, encoding and view-direction columns, 14 % of its MACs — stay exact fp32:
+round 4's kernels, unchanged) against
 the SAME oracle file (profiles/r05_psnr_oracle_aten_gpu_2000.npz).  Reported as profiles/r05_psnr_parity_2000_bf16x3.json next to the
 fp32 verdict; it carries the second bench line's "fp32-equivalent" claim at the convergence horizon and nothing else (the headline
 stays exact fp32).  A FAIL is a fail.
