@@ -1,7 +1,6 @@
 // Stand-alone positional encoding (Embedder.embed, H:15-45) for callers that use the embedder object
 // directly; the render path never materialises encodings (they are generated inside mlp_fwd.hip).
 #include "common.hpp"
-#include "sincos.hpp"
 
 namespace {
 __global__ void embed_k(const float* __restrict__ x, int64_t M, int L, float* __restrict__ out) {
@@ -16,7 +15,7 @@ __global__ void embed_k(const float* __restrict__ x, int64_t M, int L, float* __
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
       float sn, cs;
-      cn_sincos(v[d] * f, &sn, &cs);   // the ONE definition the fused forward kernels use too (encode.hpp)
+      sincosf(v[d] * f, &sn, &cs);
       o[3 + 6 * l + d] = sn;
       o[3 + 6 * l + 3 + d] = cs;
     }

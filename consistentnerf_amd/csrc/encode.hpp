@@ -1,7 +1,6 @@
 // Positional encoding of one point into an LDS tile (shared by the fp32 and the bf16-plane forward kernels).
 #pragma once
 #include "mlp_common.hpp"
-#include "sincos.hpp"
 
 // gamma(v) of this lane's point into the LDS tile T[m][0..chp): half-wave hh takes the frequencies l = hh, hh+2, ...
 // (one sincos per coordinate: both channels of the pair), half-wave 0 the identity channels, half-wave 1 the zero
@@ -24,7 +23,7 @@ __device__ __forceinline__ void encode(float* T, const float (&v)[3], int L, int
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
       float sn, cs;
-      cn_sincos(v[d] * f, &sn, &cs);   // one range reduction for the pair (sincos.hpp)
+      sincosf(v[d] * f, &sn, &cs);   // one range reduction for the pair (same values as sinf / cosf)
       put(3 + 6 * l + d, sn);
       put(3 + 6 * l + 3 + d, cs);
     }
