@@ -712,6 +712,17 @@ def c3_ss_leg(dev, steps=10):
     # MFMA work actually launched per step: both renders' ray-samples (the second render's ray count varies: in-bounds warped rays)
     pts = sum(r["points"] * r["launches"] for r in table if r["kernel"] == "mlp_wgrad") / steps
     tf = pts * 2 * (MAC_FWD + MAC_DGRAD + MAC_WGRAD) / dt / 1e12
+    # (the second render's ray count differs from step to step: one row per kernel here, sizes pooled — the launch-size-resolved
+    #  table would be ~40 rows of this line)
+    pooled = {}
+    for r in table:
+        a = pooled.setdefault(r["kernel"], {"kernel": r["kernel"], "launches": 0, "ms": 0.0, "points": 0})
+        a["launches"] += r["launches"]; a["ms"] += r["launches"] * r["avg_ms"]; a["points"] += r["launches"] * r["points"]
+    fl = {"mlp_fwd_train": 2 * MAC_FWD, "mlp_dgrad": 2 * MAC_DGRAD, "mlp_wgrad": 2 * MAC_WGRAD}
+    table = [{"kernel": a["kernel"], "launches_per_step": a["launches"] / steps, "ms_per_step": round(a["ms"] / steps, 4),
+              "points_per_step": a["points"] / steps,
+              "frac": round(fl[a["kernel"]] * a["points"] / (a["ms"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if a["kernel"] in fl else None,
+              "share_of_step": round(a["ms"] / (dt * steps * 1e3), 4)} for a in pooled.values()]
     out = {"ms_per_step": dt * 1e3, "ms_per_step_reference_lines": dt_lines * 1e3, "steps": steps, "rays_primary": 4096,
            "rays_second_render_last_step": step.rays_second,
            "ray_samples_per_step_avg": pts, "ray_samples_per_s": pts / dt, "final_loss": float(loss.item()),
