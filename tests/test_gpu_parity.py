@@ -1393,6 +1393,56 @@ def test_ss_step_loss_one_call_equals_the_lines(dev, coins, with_depth):
     assert worst <= 2e-6
 
 
+@pytest.mark.parametrize("case", ["single_level", "chunked_fallback"])
+def test_ss_step_loss_other_routes(dev, case):
+    """ss_step_loss off its main route: a render without a fine network (one level: cnerf_closs_finish_ss with one workspace), and a
+    batch larger than `chunk` (the folded form does not apply: render + ss_primary_losses on the launch's `sel`) — both against the
+    reference's lines (render, ss_consistency, ss_primary_losses)."""
+    from consistentnerf_amd import run_nerf_view as V
+    g = golden("ssloss")
+    Hh, Ww, far = 32, 40, 7.0
+    K, poses = g["K"], g["poses"]
+    ro, rd = O.get_rays_np(Hh, Ww, K, poses[0][:3, :4])
+    coarse, _ = make_model(4, 128, True, 5, 31, dev)
+    fine, _ = make_model(4, 128, True, 5, 32, dev)
+    one = case == "single_level"
+    kw = _kwargs(coarse, None if one else fine, 16, 0 if one else 16, 0.0, False, 0.0, False)
+    kw.update(near=2.0, far=far, ndc=False, use_viewdirs=True)
+    chunk = 4096 if one else 64
+    sel, r = g["a.sel"], int(g["a.ref_index"])
+    rays = torch.stack([T(ro.reshape(-1, 3)[sel], dev), T(rd.reshape(-1, 3)[sel], dev)], 0)
+    tgt = T(g["images"][0].reshape(-1, 3)[sel].astype(np.float32), dev)
+    prior = T(g["depths"][0].reshape(-1)[sel], dev)
+    params = [p for m in ((coarse,) if one else (coarse, fine)) for p in m.parameters()]
+
+    def grads():
+        out = [None if p.grad is None else p.grad.detach().clone() for p in params]
+        for p in params:
+            p.grad = None
+        return out
+
+    coins = (1, 1, 0, 0) if one else (1, 0, 1, 1)
+    rgb, disp, acc, depth, extras = V.render(Hh, Ww, K, chunk=chunk, rays=rays, retraw=True, **kw)
+    ss = V.ss_consistency(rays[0], rays[1], prior, poses[r], K, g["images"][r], g["depths"][r], Hh, Ww, kw, chunk=chunk,
+                          occlusion_threshold=0.1, with_depth_loss=True)
+    lp, il, il0 = V.ss_primary_losses(rgb, depth, extras, tgt, prior, ss["mask_bound"], ss["mask"], with_depth_loss=True,
+                                      coins=list(coins[:2]) if one else list(coins))
+    (ss["loss"] + lp).backward()
+    g_l = grads()
+    loss_o, info = V.ss_step_loss(Hh, Ww, K, rays, tgt, prior, poses[r], g["images"][r], g["depths"][r], kw, chunk=chunk,
+                                  occlusion_threshold=0.1, with_depth_loss=True, coins=coins)
+    loss_o.backward()
+    g_o = grads()
+    ll, lo = (ss["loss"] + lp).item(), loss_o.item()
+    print(f"  {case}: loss lines {ll:.8f} one call {lo:.8f}")
+    assert abs(lo - ll) <= 2e-6 * abs(ll)
+    assert (il0 is None) == one
+    for a, b in zip(g_l, g_o):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert (a - b).abs().max().item() <= 2e-6 * max(a.abs().max().item(), 1e-30)
+
+
 def test_in_loop_consistency_golden(dev):
     """a15 (VT:905-938): warp of the batch's depth-prior points into a reference view, occlusion threshold doubling,
     second render on the warped rays, the four loss terms and their weight gradients — against the reference's own
