@@ -26,7 +26,11 @@ def _materialize_on_tensor_route(p):
     def hook(g):
         if g is None:        # (the direct route hands autograd no gradient; the engine still runs the hook of the leaf)
             return None
-        if p.grad is None:   # the caller detached the view (model.zero_grad(), p.grad = None): AccumulateGrad simply SETS it
+        if p.grad is None or p.grad.data_ptr() != p._cnerf_view_ptr:
+            # the caller detached the view (model.zero_grad(), p.grad = None): AccumulateGrad SETS a tensor of its own, and ADDS
+            # to it on every further backward before step() (gradient accumulation) — the state stays DETACHED until
+            # materialize_grad() / zero_grad() bring the view back (it used to flip to LIVE on the second backward,
+            # after which the direct route overwrote the first gradient and Adam stepped on a stale flat buffer)
             p._cnerf_grad_state = GRAD_DETACHED
             return None
         if p._cnerf_grad_state == GRAD_DROPPED:
@@ -65,6 +69,7 @@ class FusedAdam:
                 p.data = self.flat_param[o:o + n].view(p.shape)
                 p.grad = self.flat_grad[o:o + n].view(p.shape)
                 p._cnerf_direct_grad = True     # _MlpFn.backward accumulates into this view directly
+                p._cnerf_view_ptr = p.grad.data_ptr()   # (the direct route is taken only while .grad IS this view)
                 p._cnerf_grad_state = GRAD_ZERO
                 if p.requires_grad:      # (a frozen parameter gets no gradient from either route)
                     p.register_hook(_materialize_on_tensor_route(p))
@@ -87,9 +92,10 @@ class FusedAdam:
         set_to_none=False: zero now.  Code that reads `flat_grad` itself before step() (gradient-norm logging, a hand-written
         all-reduce) must call materialize_grad() first: until then the views of parameters no backward reached hold stale values."""
         for p, o in zip(self.params, self._offsets):
-            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
+            if p.grad is None or p.grad.data_ptr() != p._cnerf_view_ptr:
                 p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
-                if p._cnerf_grad_state == GRAD_DETACHED:      # (its gradient lived in autograd's own tensor: the view is stale)
+                # (its gradient lived in autograd's own tensor, or nowhere: whatever the view holds is stale)
+                if p._cnerf_grad_state in (GRAD_DETACHED, GRAD_LIVE):
                     p._cnerf_grad_state = GRAD_DROPPED
         if set_to_none:
             for p in self.params:
@@ -104,18 +110,20 @@ class FusedAdam:
         """Gradients dropped by zero_grad() and not overwritten by a backward since become zeros (one fill per contiguous run)."""
         runs = []
         for p, o in zip(self.params, self._offsets):
-            if p._cnerf_grad_state == GRAD_DETACHED:
-                view = self.flat_grad[o:o + p.numel()].view(p.shape)
-                if p.grad is not None and p.grad.data_ptr() != view.data_ptr():
-                    with torch.no_grad():
-                        view.copy_(p.grad)
-                    p.grad = view
-                    p._cnerf_grad_state = GRAD_LIVE
-                elif p.grad is None:
-                    p.grad = view
+            # keyed on WHERE .grad points, not on the state flag: a gradient that lives in a tensor of autograd's own (the caller
+            # set p.grad = None before the backward) is copied into the view whatever the flag says
+            if p.grad is None:
+                p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
+                if p._cnerf_grad_state in (GRAD_DETACHED, GRAD_LIVE):   # detached and no backward since: nothing to step on
                     p._cnerf_grad_state = GRAD_DROPPED
-                else:
-                    p._cnerf_grad_state = GRAD_LIVE
+            elif p.grad.data_ptr() != p._cnerf_view_ptr:
+                view = self.flat_grad[o:o + p.numel()].view(p.shape)
+                with torch.no_grad():
+                    view.copy_(p.grad)
+                p.grad = view
+                p._cnerf_grad_state = GRAD_LIVE
+            elif p._cnerf_grad_state == GRAD_DETACHED:
+                p._cnerf_grad_state = GRAD_LIVE
             if p._cnerf_grad_state == GRAD_DROPPED:
                 p._cnerf_grad_state = GRAD_ZERO
                 if runs and runs[-1][1] == o:

@@ -233,17 +233,19 @@ def _link_levels(raw_coarse, raw_fine):
 
 
 def _direct_ok(needs, params):
-    return all(needs) and all(getattr(p, "_cnerf_direct_grad", False) and p.grad is not None and p.grad.is_contiguous()
-                              for p in params)
+    # .grad must BE FusedAdam's view of the flat gradient: after `p.grad = None` autograd attaches a tensor of its own, and a
+    # direct write into that one would bypass (and, on the overwrite route, destroy) what the optimiser steps on
+    return all(needs) and all(getattr(p, "_cnerf_direct_grad", False) and p.grad is not None
+                              and p.grad.data_ptr() == p._cnerf_view_ptr and p.grad.is_contiguous() for p in params)
 
 
 def _take_dropped(*param_lists):
     """The direct route is about to write these parameters' views of FusedAdam's flat gradient.  True when none of them holds a
     live gradient (all dropped by zero_grad(), or still zero): the wgrad reduction then OVERWRITES (accumulate=0) and the fill
     launch of an eager zero_grad never happens.  In a mixed state the dropped views are zeroed here and the reduction adds."""
-    from .optim import GRAD_DROPPED, GRAD_LIVE
+    from .optim import GRAD_DETACHED, GRAD_DROPPED, GRAD_LIVE
     ps = [p for params in param_lists for p in params]
-    fresh = all(p._cnerf_grad_state != GRAD_LIVE for p in ps)
+    fresh = all(p._cnerf_grad_state not in (GRAD_LIVE, GRAD_DETACHED) for p in ps)
     for p in ps:
         if not fresh and p._cnerf_grad_state == GRAD_DROPPED:
             p.grad.zero_()

@@ -914,6 +914,71 @@ def test_direct_accumulation_into_flat_grads(dev):
     assert float(opt.flat_grad.abs().max()) == 0.0
 
 
+def test_detached_gradients_accumulate_over_two_backwards_then_step(dev):
+    """FusedAdam, `p.grad = None` (model.zero_grad()), TWO backwards, step().  The first backward leaves the
+    gradient in a tensor of autograd's own; the second used to take the direct route into that foreign tensor with
+    accumulate=0 (the first gradient lost) and Adam then stepped on the stale flat buffer.  Now: the direct route is taken only
+    while .grad IS the flat view, both backwards add up, materialize_grad() copies the sum into the flat buffer, and the
+    updated weights equal those of the plain two-backward accumulation into attached views."""
+    from consistentnerf_amd import run_nerf_view as V
+    from consistentnerf_amd.optim import FusedAdam
+
+    def build():
+        coarse, fine, rays = _c2(dev, 128)
+        opt = FusedAdam(list(coarse.parameters()) + list(fine.parameters()), lr=5e-4)
+        return coarse, fine, rays, opt
+    tgt = torch.rand(128, 3, device=dev)
+
+    def run(coarse, fine, rays, scale):
+        kw = _kwargs(coarse, fine, 64, 128, 0.0, False, 0.0, False)
+        out = V.render_rays(rays, **kw)
+        (scale * (((out["rgb_map"] - tgt) ** 2).sum() + ((out["rgb0"] - tgt) ** 2).sum())).backward()
+    # reference: views stay attached, zero_grad(), two backwards (direct route, accumulate), step
+    c0, f0, rays, o0 = build()
+    o0.zero_grad()
+    run(c0, f0, rays, 2.0)
+    o0.step()                                             # (a warm step: the flat views now hold a LIVE gradient of another scale)
+    o0.zero_grad()
+    run(c0, f0, rays, 1.0)
+    run(c0, f0, rays, 0.5)
+    g_ref = o0.flat_grad.clone()
+    o0.step()
+    # detached: p.grad = None on every parameter, the same two backwards, step
+    c1, f1, rays1, o1 = build()
+    o1.zero_grad()
+    run(c1, f1, rays1, 2.0)
+    o1.step()
+    for m in (c1, f1):
+        m.zero_grad(set_to_none=True)                     # the flat views keep the warm step's gradient: stale from here on
+    assert all(p.grad is None for p in o1.params)
+    run(c1, f1, rays1, 1.0)
+    first = [p.grad.clone() for p in o1.params if p.grad is not None]
+    assert first and all(p.grad is None or p.grad.data_ptr() != p._cnerf_view_ptr for p in o1.params)
+    run(c1, f1, rays1, 0.5)
+    second = [p.grad for p in o1.params if p.grad is not None]
+    a_max = max(float(a.abs().max()) for a in first)
+    assert max(float((b - 1.5 * a).abs().max()) for a, b in zip(first, second)) <= 2e-6 * a_max, "the second backward did not ADD"
+    o1.materialize_grad()
+    assert all(p.grad.data_ptr() == p._cnerf_view_ptr for p in o1.params)
+    reached = torch.zeros_like(o1.flat_grad, dtype=torch.bool)
+    for p, o in zip(o1.params, o1._offsets):
+        if p.requires_grad and float(g_ref[o:o + p.numel()].abs().max()) > 0:
+            reached[o:o + p.numel()] = True
+    s = float(g_ref.abs().max())
+    assert float((o1.flat_grad - g_ref)[reached].abs().max()) <= 2e-6 * s
+    assert float(o1.flat_grad[~reached].abs().max()) == 0.0, "a parameter no backward reached steps on stale values"
+    o1.step()
+    assert float((o1.flat_param - o0.flat_param).abs().max()) <= 1e-6
+    # and once more through zero_grad(): views re-attached, the direct route is back and overwrites
+    o1.zero_grad()
+    run(c1, f1, rays1, 1.0)
+    o0.zero_grad()
+    run(c0, f0, rays, 1.0)
+    assert all(p.grad.data_ptr() == p._cnerf_view_ptr for p in o1.params)
+    o0.materialize_grad(); o1.materialize_grad()
+    assert float((o1.flat_grad - o0.flat_grad).abs().max()) <= 2e-5 * float(o0.flat_grad.abs().max())
+
+
 # ------------------------------------------------------------------------------------------------
 # secondary surface: NeRF.forward on pre-embedded inputs (H:107-130) and the corners of the compiled envelope
 @pytest.mark.parametrize("D,W,vd,och", [(8, 256, True, 5), (4, 128, False, 5)])
@@ -2487,6 +2552,41 @@ def test_bench_gpus_2_launched_plainly_is_its_own_launcher(dev):
         lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
         assert r.returncode != 0 and len(lines) == 1 and "error" in json.loads(lines[0]), (r.returncode, lines)
         assert "Traceback" not in r.stderr
+
+
+def test_bench_default_line_is_small_and_complete(dev, tmp_path):
+    """VERDICT r05 item 1 on the REAL line: `python bench.py --steps 3 --warmup 1` (every leg, the PMC passes, the CPU baseline —
+    the shape of the driver's N = 1 command) prints exactly one stdout line of at most bench.LINE_LIMIT (< 6 KB) bytes that carries
+    the contract keys, `roofline` (bound, achieved, peak, frac, traffic, the kernel table, whole_step_frac), `cpu_baseline` and the
+    flat leg_* scalars; the legs' detail is in the side file the line names."""
+    import json
+    import subprocess
+    import sys
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                            "CNERF_FORCE_DIST", "CNERF_DIST_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1"], capture_output=True, text=True,
+                       env=env, timeout=1500, cwd=str(tmp_path))
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, [ln[:200] for ln in lines], r.stderr[-3000:])
+    assert len(lines[0].encode()) <= bench.LINE_LIMIT < 6144, len(lines[0])
+    o = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "detail"):
+        assert k in o, k
+    assert o["n_gpus"] == 1 and o["steps"] == 3 and o["value"] > 1e6 and o["dtype"] == "f32" and "extra" not in o
+    rf = o["roofline"]
+    assert rf["bound"] == "mfma" and rf["peak"] == bench.PEAK_FP32_MFMA_TFLOPS and 0.3 < rf["frac"] <= 1.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and len(rf["kernels"]) == 4 and 0.3 < rf["whole_step_frac"] <= 1.0
+    assert rf["traffic"] is None or rf["traffic"] > 1e9
+    cb = o["cpu_baseline"]
+    assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] == "port" and cb["sample"]
+    cfg = o["config"]
+    for k in ("leg_c4_shard_ms_per_step_graph", "leg_c5_frame_s", "leg_c3_ms_per_step", "leg_c3_ss_ms_per_step", "leg_c3_frac_of_peak"):
+        assert isinstance(cfg.get(k), (int, float)), (k, cfg.get(k))
+    detail = json.load(open(os.path.join(str(tmp_path), o["detail"])))
+    assert detail["value"] == o["value"] and "hbm_kernels" in detail["extra"] and "c3_ss" in detail["extra"]
 
 
 def test_bench_gpus_2_default_legs_line_first_then_the_side_leg(dev):

@@ -639,3 +639,63 @@ def test_philox_streams_are_uniform_and_uncorrelated():
         assert abs(r) < 5 / np.sqrt(m), (name, r)
     # 24-bit grid, like ATen's CPU torch.rand for float32
     assert np.all(a * 2 ** 24 == np.round(a * 2 ** 24))
+
+
+def test_bench_line_stays_under_the_limit_in_the_worst_case():
+    """the driver could not parse round 5's 20-27 KB stdout line.  bench.compact_line() is what goes to stdout
+    now; whatever the legs put into the full result object (per-kernel tables, launch lists, prose) the line stays under
+    bench.LINE_LIMIT bytes, keeps every contract key, `roofline` / `cpu_baseline` with their numbers, the flat leg_* scalars, and
+    names the side file.  Worst case built here: every object the bench can attach, inflated well beyond anything it produced."""
+    import json
+    import bench
+    prose = "x" * 4000
+    rows = [{"kernel": f"mlp_kernel_with_a_long_template_name<{i}, true, true>", "points": 1048576, "launches": 200, "avg_ms": 8.87931234,
+             "tflops": 140.151234, "frac": 0.89101234, "share_of_step": 0.33851234, "basis": prose} for i in range(12)]
+    legs = {k: {"ms_per_step": 33.2, "roofline": {"frac": 0.87, "kernels": rows}, "launches_per_step": {"total": 15, "kernels": {r["kernel"]: 1 for r in rows}},
+                "what": prose} for k in ("c4_shard", "c2_bf16x3", "c5", "c3", "c3_ss")}
+    legs["hbm_kernels"] = [{"kernel": f"k{i}", "basis": prose, "gbps": 1234.5} for i in range(40)]
+    out = {"metric": "train_ray_samples_per_sec", "value": 39972806.64650532, "unit": "ray-samples/s", "n_gpus": 8, "steps": 200, "warmup": 20,
+           "ms_per_step": 26.232233560003806, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+           "data": "synthetic", "hip_graph": False, "route": {"backward": "merged", "note": prose, "wgrad_launches_per_step": 1.0},
+           "config": dict({"workload": "DTU scan8 3-view " + prose, "loss_entry": prose, "random_streams": prose, "rays_per_gpu": 4096,
+                           "global_batch": 32768, "ray_samples_per_ray": 256, "device": "gfx950:sramecc+:xnack-", "cus": 256,
+                           "parallelism": "ray-shard dp8, RCCL all-reduce of the flat fp32 grad", "final_loss": 0.164232},
+                          **{f"leg_scalar_{i}": 1.23456789 * i for i in range(24)}),
+           "roofline": {"bound": "mfma", "kernel": "mlp_wgrad (M=1048576 points)", "achieved": 140.15, "peak": 157.3, "unit": "TFLOP/s",
+                        "frac": 0.891, "traffic": 24318790220, "traffic_source": prose, "avg_launch_ms": 8.8793, "whole_step_frac": 0.8866,
+                        "kernels": rows, "kernels_measured": prose,
+                        "pmc": {"traffic": 24318790220, "FETCH_SIZE_bytes_x2": 24010364646, "WRITE_SIZE_bytes": 308425574, "source": prose,
+                                "launches": {"kernels": {r["kernel"]: 3 for r in rows}}}},
+           "cpu_baseline": {"value": 81139.5, "unit": "ray-samples/s", "cores": 32, "kind": "port", "physical_cores": 128,
+                            "value_physical_cores": 19479.5, "sample": prose, "inference_sample": prose, "sample_physical_cores": prose,
+                            "single_thread_value": 29988.7, "inference_value": 203271.0},
+           "dist": {"rccl_ranks": 8, "ranks": 8, "backend": "nccl", "messages_per_step": 1.0, "slice_bytes": [4766776] * 64,
+                    "bytes_per_step": 4766776, "one_over_world": prose, "allreduce_exposed_ms": 0.1234, "measured": prose},
+           "extra": legs}
+    assert len(json.dumps(out)) > 200000
+    line = bench.compact_line(out, "gpurun_out/bench_detail_8gpus.json")
+    blob = json.dumps(line)
+    assert len(blob) <= bench.LINE_LIMIT < 6144, len(blob)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "dist", "detail"):
+        assert k in line, k
+    assert "extra" not in line
+    assert line["value"] == out["value"] and line["ms_per_step"] == out["ms_per_step"]
+    rf = line["roofline"]
+    assert rf["bound"] == "mfma" and rf["frac"] == 0.891 and rf["traffic"] == 24318790220 and rf["peak"] == 157.3 and rf["achieved"] == 140.15
+    assert rf["whole_step_frac"] == 0.8866 and 1 <= len(rf["kernels"]) <= 4 and "basis" not in rf["kernels"][0]
+    cb = line["cpu_baseline"]
+    assert cb["value"] == 81139.5 and cb["cores"] == 32 and cb["kind"] == "port" and 0 < len(cb["sample"]) <= 200
+    assert line["config"]["workload"].startswith("DTU scan8 3-view") and line["config"]["rays_per_gpu"] == 4096
+    assert all(f"leg_scalar_{i}" in line["config"] for i in range(24))
+    assert line["dist"]["ranks"] == 8 and len(line["dist"]["slice_bytes"]) <= 8
+    # a realistic object passes through the first (least lossy) form: strings intact up to 200 characters, 4 kernel rows, route kept
+    small = dict(out, config={"workload": "DTU scan8 3-view (synthetic)", "rays_per_gpu": 4096}, route={"backward": "merged"})
+    small["roofline"] = dict(out["roofline"], traffic_source="rocprofv3 --pmc passes of this command", kernels_measured="timed region")
+    small["cpu_baseline"] = dict(out["cpu_baseline"], sample="5 warm steps of 1024 rays", inference_sample="fwd", sample_physical_cores="3 steps")
+    small["dist"] = dict(out["dist"], one_over_world="folded into adam_k", measured="HIP events")
+    l2 = bench.compact_line(small, None)
+    assert len(l2["roofline"]["kernels"]) == 4 and l2["route"] == {"backward": "merged"} and "detail" not in l2
+    assert len(json.dumps(l2)) <= bench.LINE_LIMIT
+    # and a degenerate object (an error line) still comes out
+    assert bench.compact_line({"metric": "m", "value": None, "error": "boom"})["error"] == "boom"
