@@ -56,7 +56,7 @@ class Rng(C.Structure):
 
 class Closs(C.Structure):
     """struct cnerf_closs"""
-    _fields_ = [("target", C.c_void_p), ("mask", C.c_void_p), ("prior", C.c_void_p), ("far", C.c_float)]
+    _fields_ = [("target", C.c_void_p), ("mask", C.c_void_p), ("prior", C.c_void_p), ("far", C.c_float), ("seg_row", C.c_int64)]
 
 
 class ClossTail(C.Structure):
@@ -109,12 +109,14 @@ SIGNATURES = {
     "cnerf_composite_fwd_closs": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i64, _i, _i, _ClossP, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cnerf_closs_finish": (_i, [C.POINTER(ClossTail), _vp, _vp, _vp, _vp]),
     "cnerf_closs_finish_ss": (_i, [C.POINTER(ClossTail), C.POINTER(C.c_int32), _vp, _vp, _vp]),
+    "cnerf_closs_finish_ss2": (_i, [C.POINTER(ClossTail), C.POINTER(C.c_int32), _i64, _vp, _vp, _vp, _vp]),
     "cnerf_composite_bwd_closs": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i64, _i, _i, _ClossP, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _i64,
                                        _vp, _vp]),
     "cnerf_sample_pixels": (_i, [C.POINTER(PixelBatch), _vp, _RngP, _vp, C.POINTER(_vp), _vp, _vp, _vp, _vp, _vp, _vp]),
     "cnerf_embed": (_i, [_vp, _i64, _i, _vp, _vp]),
     "cnerf_mlp_stash_floats": (_i64, [_NetP, _i64]),
     "cnerf_mlp_fwd": (_i, [_NetP, _vp, _vp, _vp, _i, _vp, _vp, _i64, _i, _vp, _vp, _vp]),
+    "cnerf_mlp_fwd_live": (_i, [_NetP, _vp, _vp, _i, _vp, _i64, _i, _vp, _vp, _vp, _vp]),
     "cnerf_mlp_fwd_embedded": (_i, [_NetP, _vp, _vp, _i64, _vp, _vp, _vp]),
     "cnerf_packed_bf_bytes": (_i64, [_NetP, _i]),
     "cnerf_pack_weights_bf": (_i, [_NetP, _PtrsP, _i, _vp, _vp]),
@@ -125,6 +127,9 @@ SIGNATURES = {
     "cnerf_mlp_bwd_ws_floats": (_i64, [_NetP, _i64]),
     "cnerf_mlp_bwd": (_i, [_NetP, _vp, _vp, _i64, _i, _vp, _vp, _PtrsP, _i, _vp]),
     "cnerf_mlp_bwd_pair": (_i, [_NetP, _vp, _vp, _i64, _i, _vp, _vp, _PtrsP, _NetP, _vp, _vp, _i64, _i, _vp, _vp, _PtrsP, _i, _vp]),
+    "cnerf_mlp_bwd_live": (_i, [_NetP, _vp, _vp, _i64, _i, _vp, _vp, _PtrsP, _i, _vp, _vp]),
+    "cnerf_mlp_bwd_pair_live": (_i, [_NetP, _vp, _vp, _i64, _i, _vp, _vp, _PtrsP, _NetP, _vp, _vp, _i64, _i, _vp, _vp, _PtrsP, _i, _vp,
+                                     _vp]),
     "cnerf_mlp_dgrad_pair": (_i, [_NetP, _vp, _vp, _i64, _i, _vp, _vp, _NetP, _vp, _vp, _i64, _i, _vp, _vp, _vp]),
     "cnerf_mlp_wgrad_pair": (_i, [_NetP, _i64, _i, _vp, _vp, _PtrsP, _NetP, _i64, _i, _vp, _vp, _PtrsP, _i, _vp]),
     "cnerf_mlp_dgrad": (_i, [_NetP, _vp, _vp, _i64, _i, _vp, _vp, _vp]),
@@ -148,6 +153,8 @@ SIGNATURES = {
     "cnerf_hard_mask_pair": (_i, [_i, _i, _f, _f, _f, _f, C.POINTER(_f), C.POINTER(_f), _vp, _vp, _f, _i, _vp,
                                   _vp, _vp]),
     "cnerf_ss_ref_rays": (_i, [C.POINTER(SsWarp), _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cnerf_ss_batch": (_i, [C.POINTER(SsWarp), _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                            _vp, _vp, _vp]),
     "cnerf_mse": (_i, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "cnerf_mse_ws_floats": (_i64, [_i64]),
     "cnerf_mse_ws": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),
@@ -181,7 +188,7 @@ def load():
         except AttributeError as e:
             raise CnerfError(f"libcnerf_hip.so does not export {name}") from e
         fn.restype, fn.argtypes = res, args
-    if lib.cnerf_abi_version() != 5:
+    if lib.cnerf_abi_version() != 6:
         raise CnerfError("libcnerf_hip.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

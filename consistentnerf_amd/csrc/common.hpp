@@ -76,3 +76,8 @@ struct NetGeom {
 };
 
 int cn_make_geom(const cnerf_net* net, NetGeom* g);
+
+// Rays (= waves) per workgroup of the loss-folding compositing launches (composite.hip) — and therefore the unit of their
+// per-workgroup partial sums, which the loss tails (loss.hip) index: ONE definition for both files.
+constexpr int CN_CLOSS_RAYS_PER_WG = 8;
+

@@ -15,7 +15,7 @@ constexpr int WAVES = 4;
 // level's term, `img_loss + img_loss0` in fp32 like R:775) and re-arms the counter.  Backward: the seed d loss / d rgb_map =
 // (2 / n) (rgb_map - target) * g[0] is formed per ray in registers — same operations, same order as img2mse's own backward, so the
 // fused and the separate paths agree bit for bit.
-constexpr int MSE_WAVES = 8;              // rays per workgroup of the loss form
+constexpr int MSE_WAVES = CN_CLOSS_RAYS_PER_WG;   // rays per workgroup of the loss form (common.hpp: loss.hip indexes the partials)
 constexpr unsigned MSE_GROUP = 64;        // workgroups per first-level ticket counter
 constexpr unsigned MSE_CTR_STRIDE = 64;   // uint32 words between counters (256 B: one counter per cache line / channel)
 constexpr unsigned MSE_CTR_WORDS = 16384; // the caller's zeroed counter block: top counter + up to 255 group counters
@@ -54,7 +54,8 @@ struct ClossBwd {
   const float* tgt;
   const float* mask;
   const float* prior;
-  const float* stats;    // device [3]: w1, w0, wd (closs_tail_k)
+  const float* stats;    // device [3]: w1, w0, wd (closs_tail_k); with seg_row > 0: [2][4], the second set for rays >= seg_row
+  int64_t seg_row;       // 0, or the first ray of the batch's second segment (cnerf_closs::seg_row: the one-render a15 step)
   const float* g;        // upstream gradient of the total loss (device scalar) or nullptr = 1
   const float* patch_d;  // [n_patch] d patch_loss / d depth of this level, or nullptr
   int64_t n_patch;
@@ -337,13 +338,14 @@ __global__ __launch_bounds__(WAVES * 64) void composite_bwd_k(const float* __res
   if (cl.rgb) {    // the masked rgb / depth seeds (+ the patch term's) of this level, formed here (see ClossBwd)
     const float g0 = cl.g ? cl.g[0] : 1.f;
     const float m = cl.mask ? cl.mask[b] : 1.f;
-    const float w = m == 1.f ? cl.stats[0] : (m == 0.f ? cl.stats[1] : 0.f);
+    const float* const st = cl.stats + ((cl.seg_row > 0 && b >= cl.seg_row) ? 4 : 0);
+    const float w = m == 1.f ? st[0] : (m == 0.f ? st[1] : 0.f);
     const float g_rgb_l = cl.rgb_w * g0;
     gr += (w * (cl.rgb[b * 3 + 0] - cl.tgt[b * 3 + 0])) * g_rgb_l;
     gg += (w * (cl.rgb[b * 3 + 1] - cl.tgt[b * 3 + 1])) * g_rgb_l;
     gb += (w * (cl.rgb[b * 3 + 2] - cl.tgt[b * 3 + 2])) * g_rgb_l;
     if (cl.prior) {
-      const float dd = m == 1.f ? cl.stats[2] * (cl.depth[b] / cl.far - cl.prior[b] / cl.far) : 0.f;
+      const float dd = m == 1.f ? st[2] * (cl.depth[b] / cl.far - cl.prior[b] / cl.far) : 0.f;
       gd += dd * (cl.depth_w * g0);
     }
     if (cl.patch_d && b < cl.n_patch) gd += cl.patch_d[b] * (cl.patch_w * g0);
@@ -535,6 +537,7 @@ extern "C" int cnerf_composite_bwd_closs(const float* raw, int raw_ch, const flo
     return CNERF_E_ARG;
   ClossBwd c;
   c.rgb = rgb; c.depth = depth; c.tgt = L->target; c.mask = L->mask; c.prior = L->prior; c.stats = stats; c.g = g_loss;
+  c.seg_row = L->seg_row > 0 && L->seg_row < B ? L->seg_row : 0;
   c.patch_d = n_patch_rays > 0 ? patch_d : nullptr; c.n_patch = n_patch_rays; c.far = L->far; c.rgb_w = rgb_w; c.depth_w = depth_w;
   c.patch_w = patch_w;
   return dispatch_c(S, [&](auto cc) -> int {

@@ -191,8 +191,12 @@ struct ClossTail {
   float* patch_d[2];         // [P * n] per level or nullptr
   float* terms;              // [8]: loss, img_loss, depth_loss, patch_loss, img_loss0, depth_loss0, patch_loss0, -
   float* stats;              // [2][4]: w1, w0, wd, - per level
-  int ss;                    // 1: the in-loop consistency step's primary terms (VT:941-969), per-term coins below
+  int ss;                    // 1: the in-loop consistency step's primary terms (VT:941-969), per-term coins below;
+                             // 2: the WHOLE step as one render (cnerf_closs_finish_ss2): partials [0, nparts1) = the primary rays,
+                             //    [nparts1, nparts) = the warped rays of the second render (VT:927-938) + padding
   int coin[4];               // rgb, depth, rgb0, depth0: 1 = the term over the selected rays (mask == 1), 0 = the reference's other branch
+  int nparts1;               // ss == 2: workgroups of the first segment
+  const float* counts3;      // ss == 2: GLOBAL (selected primary rays, primary rays, warped rays) of a batch sharded over ranks, or nullptr
 };
 
 __global__ __launch_bounds__(T) void closs_tail_k(ClossTail a) {
@@ -213,6 +217,71 @@ __global__ __launch_bounds__(T) void closs_tail_k(ClossTail a) {
     const float share = patch_wave(a.depth[lv] + (int64_t)p * a.n, a.mono + (int64_t)p * a.n, a.P, a.n, 1.f,
                                    a.patch_d[lv] ? a.patch_d[lv] + (int64_t)p * a.n : nullptr, lane);
     if (lane == 0) pshare[lv][p] = share;
+  }
+  if (a.ss == 2) {
+    // The one-render form of the whole `--ss_loss` step (VT:899-969): rays [0, 8 nparts1) are the primary batch (mask = sel, prior =
+    // depth_cas_s), rays from there on the second render's warped rays (mask = 1 on the live rows, 0 on the padding; target / prior =
+    // the reference view's colours / depth prior at the snapped pixels).  Segment sums in index order, like the sums above.
+    __shared__ double seg[2][2][5];
+    for (int lv = 0; lv < levels; ++lv)
+      for (int sg = 0; sg < 2; ++sg)
+        for (int k = 0; k < 5; ++k) {
+          const int lo = sg ? a.nparts1 : 0, hi = sg ? a.nparts : a.nparts1;
+          double s = 0.0;
+          for (int i = lo + (int)threadIdx.x; i < hi; i += T) s += a.part[lv][(int64_t)k * a.nparts + i];
+          s = block_sum(s, sh);
+          if (threadIdx.x == 0) seg[lv][sg][k] = s;
+        }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    // second render first, as the reference accumulates (VT:930-938): img2mse(rgb_ref, target_ref) [+ img2mse(depth_ref, prior_ref)]
+    // then the coarse level's two; then the primary render's four coin-gated terms (VT:941-969, see the ss == 1 branch below)
+    const double M = a.counts3 ? (double)a.counts3[2] : seg[0][1][3];
+    float loss = 0.f;
+    float ref_t[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int lv = 0; lv < levels; ++lv) {          // level 0 = the last (fine) level: its terms come first in the reference
+      const float il = (float)(seg[lv][1][0] / (3.0 * M));
+      loss = loss + il;
+      ref_t[2 * lv] = il;
+      float dl = 0.f;
+      if (a.has_depth) { dl = (float)(seg[lv][1][2] / M); loss = loss + dl; }
+      ref_t[2 * lv + 1] = dl;
+      float* st = a.stats + 8 * lv + 4;            // segment 2 of this level: live rows weigh 2 / (3 M) and 2 / M, padding rows 0
+      st[0] = (float)(2.0 / (3.0 * M)); st[1] = 0.f; st[2] = a.has_depth ? (float)(2.0 / M) / a.far : 0.f; st[3] = 0.f;
+    }
+    const double s1 = seg[0][0][0], s0 = seg[0][0][1];
+    const double N1 = a.counts3 ? (double)a.counts3[0] : seg[0][0][3];
+    const double Nall = a.counts3 ? (double)a.counts3[1] : seg[0][0][3] + seg[0][0][4];
+    const float plain = (float)((s1 + s0) / (3.0 * Nall));
+    const float wall = (float)(2.0 / (3.0 * Nall)), wsel = (float)(2.0 / (3.0 * N1));
+    const float il = a.coin[0] ? (float)(s1 / (3.0 * N1)) : plain;
+    float w1 = a.coin[0] ? wsel : wall, w0 = a.coin[0] ? 0.f : wall;
+    loss = loss + il;
+    float dl = 0.f;
+    const bool dep = a.has_depth && a.coin[1];
+    if (dep) { dl = (float)(seg[0][0][2] / N1); loss = loss + dl; }
+    a.terms[1] = il; a.terms[2] = dl; a.terms[3] = 0.f;
+    a.stats[2] = dep ? (float)(2.0 / N1) / a.far : 0.f;
+    a.stats[3] = 0.f;
+    a.terms[4] = a.terms[5] = a.terms[6] = 0.f;
+    if (levels == 2) {
+      const float il0 = a.coin[2] ? (float)(seg[1][0][0] / (3.0 * N1)) : plain;
+      loss = loss + il0;
+      float dl0 = 0.f;
+      const bool dep0 = a.has_depth && a.coin[3];
+      if (dep0) { dl0 = (float)(seg[1][0][2] / N1); loss = loss + dl0; }
+      a.terms[4] = il0; a.terms[5] = dl0;
+      a.stats[8] = a.coin[2] ? (float)(2.0 / (3.0 * N1)) : 0.f;
+      a.stats[9] = 0.f;
+      a.stats[10] = dep0 ? (float)(2.0 / N1) / a.far : 0.f;
+      a.stats[11] = 0.f;
+      if (!a.coin[2]) { w1 += wall; w0 += wall; }
+    }
+    a.stats[0] = w1; a.stats[1] = w0;
+    a.terms[0] = loss;
+    a.terms[7] = (float)M;
+    a.terms[8] = ref_t[0]; a.terms[9] = ref_t[1]; a.terms[10] = ref_t[2]; a.terms[11] = ref_t[3];
+    return;
   }
   __syncthreads();
   if (threadIdx.x != 0) return;
@@ -451,7 +520,8 @@ extern "C" int cnerf_patch_depth_loss(const float* depth_pred, const float* mono
 }
 
 namespace {
-int closs_finish_impl(const cnerf_closs_sum* t, const int32_t* ss_coins, float* terms, float* stats, float* patch_d, void* stream) {
+int closs_finish_impl(const cnerf_closs_sum* t, const int32_t* ss_coins, float* terms, float* stats, float* patch_d, void* stream,
+                      int64_t seg_row = 0, const float* counts3 = nullptr) {
   if (!t || !terms || !stats || !t->ws_last || t->B <= 0 || t->P < 0 || t->P > 8 || (t->P > 0 && (t->n <= 0 || !t->mono || !t->depth_last)) ||
       (t->P > 0 && t->ws_coarse && !t->depth_coarse) || (t->has_depth && !(t->far > 0.f)) || (int64_t)t->P * t->n > t->B ||
       ((uintptr_t)t->ws_last & 7) != 0 || ((uintptr_t)t->ws_coarse & 7) != 0)
@@ -459,15 +529,17 @@ int closs_finish_impl(const cnerf_closs_sum* t, const int32_t* ss_coins, float* 
   ClossTail a;
   a.part[0] = reinterpret_cast<const double*>(t->ws_last);
   a.part[1] = reinterpret_cast<const double*>(t->ws_coarse);
-  a.nparts = (int)((t->B + 7) / 8);       // composite.hip MSE_WAVES rays per workgroup
+  a.nparts = (int)cn_div_up(t->B, (int64_t)CN_CLOSS_RAYS_PER_WG);
   a.counts = t->counts; a.coef = t->coef; a.far = t->has_depth ? t->far : 1.f; a.rgb_w = t->rgb_w; a.depth_w = t->depth_w;
   a.patch_w = t->patch_w; a.has_depth = t->has_depth;
   a.depth[0] = t->depth_last; a.depth[1] = t->depth_coarse; a.mono = t->mono; a.P = t->P; a.n = t->n;
   a.patch_d[0] = (patch_d && t->P > 0) ? patch_d : nullptr;
   a.patch_d[1] = (patch_d && t->P > 0 && t->ws_coarse) ? patch_d + (int64_t)t->P * t->n : nullptr;
   a.terms = terms; a.stats = stats;
-  a.ss = ss_coins ? 1 : 0;
+  a.ss = ss_coins ? (seg_row > 0 ? 2 : 1) : 0;
   for (int k = 0; k < 4; ++k) a.coin[k] = ss_coins ? (ss_coins[k] != 0) : 0;
+  a.nparts1 = (int)(seg_row / CN_CLOSS_RAYS_PER_WG);
+  a.counts3 = counts3;
   hipLaunchKernelGGL(closs_tail_k, dim3(1), dim3(T), 0, cn_stream(stream), a);
   CN_CHECK_LAUNCH();
   return CNERF_OK;
@@ -482,4 +554,12 @@ extern "C" int cnerf_closs_finish_ss(const cnerf_closs_sum* t, const int32_t* co
   // (no patch term and no sharded counts in this mode: the reference's block has neither)
   if (!coins4 || !t || t->P != 0 || t->counts) return CNERF_E_ARG;
   return closs_finish_impl(t, coins4, terms, stats, nullptr, stream);
+}
+
+extern "C" int cnerf_closs_finish_ss2(const cnerf_closs_sum* t, const int32_t* coins4, int64_t seg_row, const float* counts3,
+                                      float* terms12, float* stats16, void* stream) {
+  // the levels' compositing launches ran over ONE batch of t->B rays = [primary | warped + padding] cut at seg_row (a multiple of the
+  // 8 rays of a compositing workgroup, so that every partial belongs to one segment)
+  if (!coins4 || !t || t->P != 0 || t->counts || seg_row <= 0 || seg_row >= t->B || seg_row % CN_CLOSS_RAYS_PER_WG != 0) return CNERF_E_ARG;
+  return closs_finish_impl(t, coins4, terms12, stats16, nullptr, stream, seg_row, counts3);
 }

@@ -14,7 +14,7 @@ int cn_wgrad_launch(const NetGeom& g, const float* stash, const float* G, int64_
                     int nsplit, const cnerf_ptrs* grads, int accumulate, hipStream_t st, int bf3 = 0);
 int cn_wgrad_launch_n(int n, const NetGeom* const* g, const float* const* stash, const float* const* G, const int64_t* Mp,
                       float* const* partials, const int* nsplit, const cnerf_ptrs* const* grads, int accumulate,
-                      hipStream_t st, int bf3 = 0);
+                      hipStream_t st, int bf3 = 0, const int* live = nullptr, const int* live_mul = nullptr);
 int cn_wgrad_nsplit(int64_t Mp);
 int64_t cn_param_floats(const NetGeom& g);
 
@@ -29,12 +29,15 @@ struct BwdLevel {
   const float* stash;
   float* G;
   int64_t M, Mp;
+  int64_t live_mul;   // points per ray of this level (with BwdArgs::live), 0 = no gating
 };
 
 struct BwdArgs {
   NetGeom g;
   BwdLevel lv[2];
   unsigned nb0;
+  const int* live;    // device count of LIVE rays or nullptr: tiles at or beyond live * live_mul points retire at once (their raw
+                      // outputs were zeros, their gradient tile rows are never read: wgrad clips its point ranges the same way)
 };
 
 #define CN_CONST __attribute__((address_space(4)))
@@ -55,6 +58,7 @@ __global__ __launch_bounds__(64) void mlp_dgrad_k(BwdArgs args_by_value) {
   const int64_t p = p0 + m;
   const int nvalid = a.M - p0 < 32 ? (int)(a.M - p0) : 32;
   const int64_t pc = p < a.M ? p : a.M - 1;
+  if (args.live != nullptr && a.live_mul > 0 && p0 >= (int64_t)args.live[0] * a.live_mul) return;   // padding rays (cnerf_mlp_bwd_live)
   CN_TINIT(1)
   const APanel AP{make_rsrc(a.packed, (unsigned)(g.total * 4)), (m * 8 + 4 * hh) * 4};
   // this workgroup's stash tile row (sign bits) and gradient tile row (tile-major, mlp_common.hpp); lanes of padding
@@ -227,21 +231,26 @@ extern "C" int64_t cnerf_mlp_bwd_ws_floats(const cnerf_net* net, int64_t M) {
   return (int64_t)g.g_rows * Mp + (int64_t)cn_wgrad_nsplit(Mp) * cn_round_up(cn_param_floats(g), 64);
 }
 
-extern "C" int cnerf_mlp_dgrad(const cnerf_net* net, const float* packed, const float* d_raw, int64_t B, int S,
-                               const float* stash, float* workspace, void* stream) {
+static int dgrad_one(const cnerf_net* net, const float* packed, const float* d_raw, int64_t B, int S, const float* stash,
+                     float* workspace, const int32_t* live, void* stream) {
   BwdArgs a;
   int rc = cn_make_geom(net, &a.g);
   if (rc) return rc;
-  if (!packed || !d_raw || !stash || !workspace || B < 0 || S <= 0) return CNERF_E_ARG;
+  if (!packed || !d_raw || !stash || !workspace || B < 0 || S <= 0 || (live && S % 32 != 0)) return CNERF_E_ARG;
   if (B == 0) return CNERF_OK;
-  a.lv[0] = BwdLevel{packed, d_raw, stash, workspace, B * S, cn_round_up(B * S, 32)};
+  a.lv[0] = BwdLevel{packed, d_raw, stash, workspace, B * S, cn_round_up(B * S, 32), live ? S : 0};
   a.lv[1] = a.lv[0];
   a.nb0 = (unsigned)cn_div_up(B * S, 32);
+  a.live = live;
   return dispatch(a, 1, cn_stream(stream));
+}
+extern "C" int cnerf_mlp_dgrad(const cnerf_net* net, const float* packed, const float* d_raw, int64_t B, int S,
+                               const float* stash, float* workspace, void* stream) {
+  return dgrad_one(net, packed, d_raw, B, S, stash, workspace, nullptr, stream);
 }
 
 static int wgrad_one(const cnerf_net* net, int64_t B, int S, const float* stash, float* workspace, const cnerf_ptrs* grads,
-                     int accumulate, void* stream, int bf3);
+                     int accumulate, void* stream, int bf3, const int32_t* live = nullptr);
 extern "C" int cnerf_mlp_wgrad(const cnerf_net* net, int64_t B, int S, const float* stash, float* workspace,
                                const cnerf_ptrs* grads, int accumulate, void* stream) {
   return wgrad_one(net, B, S, stash, workspace, grads, accumulate, stream, 0);
@@ -252,15 +261,19 @@ extern "C" int cnerf_mlp_wgrad_bf(const cnerf_net* net, int64_t B, int S, const 
   return wgrad_one(net, B, S, stash, workspace, grads, accumulate, stream, 1);
 }
 static int wgrad_one(const cnerf_net* net, int64_t B, int S, const float* stash, float* workspace, const cnerf_ptrs* grads,
-                     int accumulate, void* stream, int bf3) {
+                     int accumulate, void* stream, int bf3, const int32_t* live) {
   NetGeom g;
   int rc = cn_make_geom(net, &g);
   if (rc) return rc;
-  if (!stash || !workspace || !grads || B < 0 || S <= 0) return CNERF_E_ARG;
+  if (!stash || !workspace || !grads || B < 0 || S <= 0 || (live && S % 32 != 0)) return CNERF_E_ARG;
   if (B == 0) return CNERF_OK;
   const int64_t M = B * S, Mp = cn_round_up(M, 32);
   const int nsplit = cn_wgrad_nsplit(Mp);
   float* partials = workspace + (int64_t)g.g_rows * Mp;
+  if (live) {
+    const NetGeom* gp = &g;
+    return cn_wgrad_launch_n(1, &gp, &stash, &workspace, &Mp, &partials, &nsplit, &grads, accumulate, cn_stream(stream), bf3, live, &S);
+  }
   return cn_wgrad_launch(g, stash, workspace, M, Mp, partials, nsplit, grads, accumulate, cn_stream(stream), bf3);
 }
 
@@ -273,15 +286,34 @@ extern "C" int cnerf_mlp_bwd(const cnerf_net* net, const float* packed, const fl
   return cnerf_mlp_wgrad(net, B, S, stash, workspace, grads, accumulate, stream);
 }
 
+// cnerf_mlp_bwd of a batch padded to a fixed capacity of B rays whose LIVE row count sits in device memory (cnerf_mlp_fwd_live)
+extern "C" int cnerf_mlp_bwd_live(const cnerf_net* net, const float* packed, const float* d_raw, int64_t B, int S,
+                                  const float* stash, float* workspace, const cnerf_ptrs* grads, int accumulate,
+                                  const int32_t* live_rays, void* stream) {
+  if (!grads || !live_rays) return CNERF_E_ARG;
+  int rc = dgrad_one(net, packed, d_raw, B, S, stash, workspace, live_rays, stream);
+  if (rc) return rc;
+  return wgrad_one(net, B, S, stash, workspace, grads, accumulate, stream, 0, live_rays);
+}
+
 // Backward of TWO independent networks in one dgrad grid + one wgrad grid (+ one reduction): the coarse and the fine
 // network of a render_rays training step (R:311-421) — their backward passes share nothing once the forward is done
 // (the fine level's sample depths are detached, R:397).  The dgrad grid is shared when both have the same architecture,
 // otherwise two dgrad launches; the wgrad grid is always shared.  net0 / net1 must be different parameter sets (two
 // reductions into one gradient tensor would race).  Workspaces as for cnerf_mlp_bwd, one per network.
+static int dgrad_pair(const cnerf_net* net0, const float* packed0, const float* d_raw0, int64_t B0, int S0, const float* stash0,
+                      float* workspace0, const cnerf_net* net1, const float* packed1, const float* d_raw1, int64_t B1, int S1,
+                      const float* stash1, float* workspace1, const int32_t* live, void* stream);
 extern "C" int cnerf_mlp_dgrad_pair(const cnerf_net* net0, const float* packed0, const float* d_raw0, int64_t B0, int S0,
                                     const float* stash0, float* workspace0, const cnerf_net* net1, const float* packed1,
                                     const float* d_raw1, int64_t B1, int S1, const float* stash1, float* workspace1,
                                     void* stream) {
+  return dgrad_pair(net0, packed0, d_raw0, B0, S0, stash0, workspace0, net1, packed1, d_raw1, B1, S1, stash1, workspace1, nullptr,
+                    stream);
+}
+static int dgrad_pair(const cnerf_net* net0, const float* packed0, const float* d_raw0, int64_t B0, int S0, const float* stash0,
+                      float* workspace0, const cnerf_net* net1, const float* packed1, const float* d_raw1, int64_t B1, int S1,
+                      const float* stash1, float* workspace1, const int32_t* live, void* stream) {
   BwdArgs a;
   NetGeom g1;
   int rc = cn_make_geom(net0, &a.g);
@@ -294,19 +326,21 @@ extern "C" int cnerf_mlp_dgrad_pair(const cnerf_net* net0, const float* packed0,
   const bool same = net0->D == net1->D && net0->W == net1->W && net0->multires == net1->multires &&
                     net0->multires_views == net1->multires_views && net0->use_viewdirs == net1->use_viewdirs &&
                     net0->output_ch == net1->output_ch && net0->skip == net1->skip;
+  if (live && (S0 % 32 != 0 || S1 % 32 != 0)) return CNERF_E_ARG;
   if (same && M0 > 0 && M1 > 0) {
-    a.lv[0] = BwdLevel{packed0, d_raw0, stash0, workspace0, M0, cn_round_up(M0, 32)};
-    a.lv[1] = BwdLevel{packed1, d_raw1, stash1, workspace1, M1, cn_round_up(M1, 32)};
+    a.lv[0] = BwdLevel{packed0, d_raw0, stash0, workspace0, M0, cn_round_up(M0, 32), live ? S0 : 0};
+    a.lv[1] = BwdLevel{packed1, d_raw1, stash1, workspace1, M1, cn_round_up(M1, 32), live ? S1 : 0};
     a.nb0 = (unsigned)cn_div_up(M0, 32);
+    a.live = live;
     return dispatch(a, 2, cn_stream(stream));
   }
-  if ((rc = cnerf_mlp_dgrad(net0, packed0, d_raw0, B0, S0, stash0, workspace0, stream))) return rc;
-  return cnerf_mlp_dgrad(net1, packed1, d_raw1, B1, S1, stash1, workspace1, stream);
+  if ((rc = dgrad_one(net0, packed0, d_raw0, B0, S0, stash0, workspace0, live, stream))) return rc;
+  return dgrad_one(net1, packed1, d_raw1, B1, S1, stash1, workspace1, live, stream);
 }
 
 static int wgrad_two(const cnerf_net* net0, int64_t B0, int S0, const float* stash0, float* workspace0, const cnerf_ptrs* grads0,
                      const cnerf_net* net1, int64_t B1, int S1, const float* stash1, float* workspace1,
-                     const cnerf_ptrs* grads1, int accumulate, void* stream, int bf3);
+                     const cnerf_ptrs* grads1, int accumulate, void* stream, int bf3, const int32_t* live = nullptr);
 extern "C" int cnerf_mlp_wgrad_pair(const cnerf_net* net0, int64_t B0, int S0, const float* stash0, float* workspace0,
                                     const cnerf_ptrs* grads0, const cnerf_net* net1, int64_t B1, int S1,
                                     const float* stash1, float* workspace1, const cnerf_ptrs* grads1, int accumulate,
@@ -321,11 +355,12 @@ extern "C" int cnerf_mlp_wgrad_bf_pair(const cnerf_net* net0, int64_t B0, int S0
 }
 static int wgrad_two(const cnerf_net* net0, int64_t B0, int S0, const float* stash0, float* workspace0, const cnerf_ptrs* grads0,
                      const cnerf_net* net1, int64_t B1, int S1, const float* stash1, float* workspace1,
-                     const cnerf_ptrs* grads1, int accumulate, void* stream, int bf3) {
-  if (!grads0 || !grads1 || !stash0 || !stash1 || !workspace0 || !workspace1 || B0 < 0 || B1 < 0 || S0 <= 0 || S1 <= 0)
+                     const cnerf_ptrs* grads1, int accumulate, void* stream, int bf3, const int32_t* live) {
+  if (!grads0 || !grads1 || !stash0 || !stash1 || !workspace0 || !workspace1 || B0 < 0 || B1 < 0 || S0 <= 0 || S1 <= 0 ||
+      (live && (S0 % 32 != 0 || S1 % 32 != 0)))
     return CNERF_E_ARG;
-  if (B0 == 0) return wgrad_one(net1, B1, S1, stash1, workspace1, grads1, accumulate, stream, bf3);
-  if (B1 == 0) return wgrad_one(net0, B0, S0, stash0, workspace0, grads0, accumulate, stream, bf3);
+  if (B0 == 0) return wgrad_one(net1, B1, S1, stash1, workspace1, grads1, accumulate, stream, bf3, live);
+  if (B1 == 0) return wgrad_one(net0, B0, S0, stash0, workspace0, grads0, accumulate, stream, bf3, live);
   for (int i = 0; i < CNERF_MAX_TENSORS; ++i)
     if (grads0->p[i] && grads0->p[i] == grads1->p[i]) return CNERF_E_ARG;
   NetGeom g0, g1;
@@ -340,7 +375,8 @@ static int wgrad_two(const cnerf_net* net0, int64_t B0, int S0, const float* sta
   const int ns[2] = {cn_wgrad_nsplit(Mp0), cn_wgrad_nsplit(Mp1)};
   float* parts[2] = {workspace0 + (int64_t)g0.g_rows * Mp0, workspace1 + (int64_t)g1.g_rows * Mp1};
   const cnerf_ptrs* grs[2] = {grads0, grads1};
-  return cn_wgrad_launch_n(2, gs, stashes, Gs, Mps, parts, ns, grs, accumulate, cn_stream(stream), bf3);
+  const int muls[2] = {S0, S1};
+  return cn_wgrad_launch_n(2, gs, stashes, Gs, Mps, parts, ns, grs, accumulate, cn_stream(stream), bf3, live, live ? muls : nullptr);
 }
 
 extern "C" int cnerf_mlp_bwd_pair(const cnerf_net* net0, const float* packed0, const float* d_raw0, int64_t B0, int S0,
@@ -356,4 +392,21 @@ extern "C" int cnerf_mlp_bwd_pair(const cnerf_net* net0, const float* packed0, c
   if (rc) return rc;
   return cnerf_mlp_wgrad_pair(net0, B0, S0, stash0, workspace0, grads0, net1, B1, S1, stash1, workspace1, grads1, accumulate,
                               stream);
+}
+
+// cnerf_mlp_bwd_pair of two levels of ONE ray batch padded to a fixed capacity (B0 == B1 rays) whose LIVE row count sits in device
+// memory: both levels' dgrad tiles and wgrad point ranges stop at live_rays * S of their level
+extern "C" int cnerf_mlp_bwd_pair_live(const cnerf_net* net0, const float* packed0, const float* d_raw0, int64_t B0, int S0,
+                                       const float* stash0, float* workspace0, const cnerf_ptrs* grads0,
+                                       const cnerf_net* net1, const float* packed1, const float* d_raw1, int64_t B1, int S1,
+                                       const float* stash1, float* workspace1, const cnerf_ptrs* grads1, int accumulate,
+                                       const int32_t* live_rays, void* stream) {
+  if (!grads0 || !grads1 || !live_rays || B0 != B1) return CNERF_E_ARG;
+  for (int i = 0; i < CNERF_MAX_TENSORS; ++i)
+    if (grads0->p[i] && grads0->p[i] == grads1->p[i]) return CNERF_E_ARG;
+  int rc = dgrad_pair(net0, packed0, d_raw0, B0, S0, stash0, workspace0, net1, packed1, d_raw1, B1, S1, stash1, workspace1, live_rays,
+                      stream);
+  if (rc) return rc;
+  return wgrad_two(net0, B0, S0, stash0, workspace0, grads0, net1, B1, S1, stash1, workspace1, grads1, accumulate, stream, 0,
+                   live_rays);
 }

@@ -32,11 +32,16 @@ struct FwdArgs {
   int64_t M, Mp;
   int S, rs;
   RayGenDev cam;      // cam.on: the rays are those of a camera, generated here (rays == nullptr)
+  const int* live;    // device count of LIVE rays, or nullptr: tiles whose points all lie at or beyond live * S write zero raw
+                      // outputs and retire (cnerf_mlp_fwd_live: a batch padded to a fixed capacity, row count known on the device only)
 };
 
 #define CN_CONST __attribute__((address_space(4)))
 
-template <int NT, bool VD, bool TRAIN>
+// LIVE: the batch is padded to a fixed capacity and its live row count is read from device memory (cnerf_mlp_fwd_live) — a
+// separate instantiation, so that the code of the default kernels is untouched by the gate (the D=8/W=256 training kernel sits at
+// the register limit: the gate in the same body cost it an eighth spilled dword).
+template <int NT, bool VD, bool TRAIN, bool LIVE = false>
 __global__ __launch_bounds__(64) void mlp_fwd_k(FwdArgs args_by_value) {
   // the argument block is read in place from the kernarg segment (scalar loads next to their use): taken by value, all
   // of it is fetched by the kernel prologue and stays live in SGPRs across the layer loop (31 SGPR spills at NT = 8)
@@ -62,6 +67,19 @@ __global__ __launch_bounds__(64) void mlp_fwd_k(FwdArgs args_by_value) {
   const int nvalid = a.M - p0 < 32 ? (int)(a.M - p0) : 32;
   const int64_t pc = p < a.M ? p : a.M - 1;
   const int64_t ray = pc / a.S;
+  if (LIVE) {
+    // rows [live, B) of the batch are padding (the count was produced on the device, e.g. by cnerf_ss_batch): live * S is a
+    // multiple of 32 whenever S is (64 / 192 here), so a tile is live or dead as a whole.  A dead tile leaves zero raw outputs —
+    // sigma = 0: compositing gives weight 0 to every sample of a padding ray — and no stash (its backward is gated the same way).
+    const int64_t lp = (int64_t)a.live[0] * a.S;
+    if (p0 >= lp) {
+      if (hh == 0 && p < a.M) {
+        const int rc = VD ? 4 : g.out_ch;
+        for (int c = 0; c < rc; ++c) a.raw[p * rc + c] = 0.f;
+      }
+      return;
+    }
+  }
   CN_TINIT(1)
 
   const APanel AP{make_rsrc(a.packed, (unsigned)(g.total * 4)), (m * 8 + 4 * hh) * 4};
@@ -257,9 +275,13 @@ int launch(const FwdArgs& a, hipStream_t st) {
       hipError_t e = hipMemsetAsync(a.stash + (a.Mp - 32) * a.g.s_rows, 0, (size_t)32 * a.g.s_rows * sizeof(float), st);
       if (e != hipSuccess) return (int)e;
     }
-    if (a.g.viewdirs) hipLaunchKernelGGL((mlp_fwd_k<NT, true, true>), dim3(grid), dim3(64), 0, st, a);
+    if (a.live != nullptr) {
+      if (a.g.viewdirs) hipLaunchKernelGGL((mlp_fwd_k<NT, true, true, true>), dim3(grid), dim3(64), 0, st, a);
+      else hipLaunchKernelGGL((mlp_fwd_k<NT, false, true, true>), dim3(grid), dim3(64), 0, st, a);
+    } else if (a.g.viewdirs) hipLaunchKernelGGL((mlp_fwd_k<NT, true, true>), dim3(grid), dim3(64), 0, st, a);
     else hipLaunchKernelGGL((mlp_fwd_k<NT, false, true>), dim3(grid), dim3(64), 0, st, a);
   } else {
+    if (a.live != nullptr) return CNERF_E_UNSUPPORTED;      // (the device-side row count is a training-step feature)
     if (a.g.viewdirs) hipLaunchKernelGGL((mlp_fwd_k<NT, true, false>), dim3(grid), dim3(64), 0, st, a);
     else hipLaunchKernelGGL((mlp_fwd_k<NT, false, false>), dim3(grid), dim3(64), 0, st, a);
   }
@@ -296,6 +318,24 @@ extern "C" int cnerf_mlp_fwd(const cnerf_net* net, const float* packed, const fl
   a.stash = stash;
   a.M = B * S; a.Mp = cn_round_up(a.M, 32); a.S = S; a.rs = ray_stride;
   a.cam = cn_no_raygen();
+  a.live = nullptr;
+  return dispatch(a, stream);
+}
+
+// cnerf_mlp_fwd on a batch padded to a fixed capacity of B rays whose LIVE row count sits in device memory (include/cnerf.h)
+extern "C" int cnerf_mlp_fwd_live(const cnerf_net* net, const float* packed, const float* rays, int ray_stride, const float* z,
+                                  int64_t B, int S, float* raw, float* stash, const int32_t* live_rays, void* stream) {
+  FwdArgs a;
+  int rc = cn_make_geom(net, &a.g);
+  if (rc) return rc;
+  if (!packed || !raw || !rays || !z || !stash || !live_rays || B < 0 || S <= 0 || S % 32 != 0 || ray_stride < 8) return CNERF_E_ARG;
+  if (a.g.viewdirs && ray_stride < 11) return CNERF_E_ARG;
+  if (B == 0) return CNERF_OK;
+  a.packed = packed; a.pts = nullptr; a.rays = rays; a.dirs = nullptr; a.z = z; a.emb = nullptr; a.raw = raw;
+  a.stash = stash;
+  a.M = B * S; a.Mp = cn_round_up(a.M, 32); a.S = S; a.rs = ray_stride;
+  a.cam = cn_no_raygen();
+  a.live = live_rays;
   return dispatch(a, stream);
 }
 
@@ -311,6 +351,7 @@ int cn_mlp_fwd_cam(const cnerf_net* net, const float* packed, const RayGenDev& c
   a.stash = nullptr;
   a.M = B * S; a.Mp = cn_round_up(a.M, 32); a.S = S; a.rs = 0;
   a.cam = cam;
+  a.live = nullptr;
   return dispatch(a, stream);
 }
 
@@ -325,5 +366,6 @@ extern "C" int cnerf_mlp_fwd_embedded(const cnerf_net* net, const float* packed,
   a.raw = raw; a.stash = stash;
   a.M = M; a.Mp = cn_round_up(M, 32); a.S = 1; a.rs = 0;
   a.cam = cn_no_raygen();
+  a.live = nullptr;
   return dispatch(a, stream);
 }

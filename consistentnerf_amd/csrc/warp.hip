@@ -127,13 +127,29 @@ struct SsDev {
   float thr0;
 };
 
+// cnerf_ss_batch: the same launch also assembles the ONE batch the whole `--ss_loss` step renders (run_nerf_view.ss_step_loss):
+// rows [0, N) = the batch's own rays packed as render() packs them, rows [N, N + M) = the reference rays (the `rows` output of the
+// kernel, pointed there by the host), rows [N + M, 2 N) = padding (the reference camera's optical axis: a valid ray whose loss
+// weight is 0), and next to it the per-row target colour / depth prior / loss mask and the LIVE row count N + M — all in device
+// memory: the host never learns M (no read-back; the MLP launches take the count from `live`).
+struct SsComb {
+  float* rows;              // [2N, 8|11]  or nullptr (= plain cnerf_ss_ref_rays)
+  float* target;            // [2N, 3]: target_s | reference colours at the snapped pixels | 0
+  float* prior;             // [2N]:    depth (the batch's prior) | reference depth prior there | 0
+  float* mask;              // [2N]:    sel | 1 | 0
+  int32_t* live;            // [1]:     N + M
+  const float* target_s;    // [N, 3]
+  const float* amin_in;     // the GLOBAL minimum of |z - D_ref| over a batch sharded across ranks (device, 1 float), or nullptr
+};
+
 __global__ __launch_bounds__(1024) void ss_ref_rays_k(SsDev a, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                       const float* __restrict__ depth, int64_t N, const float* __restrict__ image,
                                                       const float* __restrict__ depth_ref, float* __restrict__ rows,
                                                       float* __restrict__ rays_od, float* __restrict__ target,
                                                       float* __restrict__ depth_tgt, float* __restrict__ depth_diff,
                                                       uint8_t* __restrict__ inb, uint8_t* __restrict__ mask,
-                                                      float* __restrict__ sel, int32_t* __restrict__ rank, int32_t* __restrict__ meta) {
+                                                      float* __restrict__ sel, int32_t* __restrict__ rank, int32_t* __restrict__ meta,
+                                                      SsComb cb) {
   __shared__ int wcnt[16];
   __shared__ float wmin[16];
   __shared__ int wnan[16];
@@ -150,6 +166,18 @@ __global__ __launch_bounds__(1024) void ss_ref_rays_k(SsDev a, const float* __re
       p = project(rays_o[3 * i] + dep * rays_d[3 * i], rays_o[3 * i + 1] + dep * rays_d[3 * i + 1],
                   rays_o[3 * i + 2] + dep * rays_d[3 * i + 2], a.w2c, a.cam.fx, a.cam.fy, a.cam.cx, a.cam.cy, a.H, a.W, a.flip);
       in = p.inb;
+      if (cb.rows) {          // the primary ray's own row, colour and prior (the arithmetic of pack_rays_k: raygen.hpp)
+        const int rs = a.cam.vd ? 11 : 8;
+        float o[3], d[3], v[3];
+        cn_finish_ray(rays_o[3 * i], rays_o[3 * i + 1], rays_o[3 * i + 2], rays_d[3 * i], rays_d[3 * i + 1], rays_d[3 * i + 2], a.cam.vd,
+                      a.cam.ndc, a.cam.ax, a.cam.ay, o, d, v);
+        float* out = cb.rows + i * rs;
+        out[0] = o[0]; out[1] = o[1]; out[2] = o[2]; out[3] = d[0]; out[4] = d[1]; out[5] = d[2];
+        out[6] = a.cam.near; out[7] = a.cam.far;
+        if (a.cam.vd) { out[8] = v[0]; out[9] = v[1]; out[10] = v[2]; }
+        cb.target[3 * i] = cb.target_s[3 * i]; cb.target[3 * i + 1] = cb.target_s[3 * i + 1]; cb.target[3 * i + 2] = cb.target_s[3 * i + 2];
+        cb.prior[i] = dep;
+      }
     }
     const unsigned long long bal = __ballot(in);
     if (lane == 0) wcnt[wv] = __popcll(bal);
@@ -214,25 +242,60 @@ __global__ __launch_bounds__(1024) void ss_ref_rays_k(SsDev a, const float* __re
     anynan |= wnan[w];
   }
   const int M = base;
-  // thr = thr0 * 2^k, smallest k >= 0 with min|diff| < thr (VT:921-925 doubles until something passes); a NaN minimum compares
-  // false against every candidate -> k stops at the cap like the cached ladder of round 4 (63 doublings)
+  // thr = thr0 * 2^k, smallest k >= 0 with min|diff| < thr (VT:921-925 doubles until something passes).  A NaN |diff| (a NaN depth
+  // prior) passes no threshold — `NaN < thr` is false, exactly as in the reference's loop — so the minimum is taken over the other
+  // points (`amin` above never picks a NaN up) and the doubling goes on until one of THOSE passes (it used to stop at
+  // k = 0 whenever a NaN was present).  Only when no point has a finite |diff| at all does k reach the cap (the reference loops
+  // forever there): meta[3] reports NaNs, the mask is then empty.
+  const float amin_local = amin;
+  if (cb.amin_in) amin = cb.amin_in[0];     // a batch sharded over ranks: every rank applies the threshold of the WHOLE batch
   float thr = a.thr0;
   int k = 0;
-  if (anynan) {
-    k = 0;
-  } else {
-    while (!(amin < thr) && k < 63) { thr = 2.f * thr; ++k; }
-  }
+  while (!(amin < thr) && k < 63) { thr = 2.f * thr; ++k; }
   if (tid == 0) {
     meta[0] = M; meta[1] = k; meta[2] = __float_as_int(thr); meta[3] = anynan;
+    meta[4] = __float_as_int(amin_local);
+    if (cb.live) cb.live[0] = (int32_t)(N + M);
   }
   if (mask)
     for (int64_t j = tid; j < M; j += 1024) mask[j] = depth_diff[j] < thr ? 1 : 0;
-  if (sel)
-    for (int64_t i = tid; i < N; i += 1024) {
-      const int32_t j = rank[i];
-      sel[i] = (j >= 0 && depth_diff[j] < thr) ? 1.f : 0.f;
+  int nsel = 0;
+  for (int64_t i = tid; i < N; i += 1024) {
+    const int32_t j = rank[i];
+    const float sv = (j >= 0 && depth_diff[j] < thr) ? 1.f : 0.f;
+    nsel += sv != 0.f;
+    if (sel) sel[i] = sv;
+    if (cb.mask) cb.mask[i] = sv;
+  }
+  // meta[5] = how many primary rays `sel` selects (with M and N: the three counts a sharded step all-reduces)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) nsel += __shfl_xor(nsel, o, 64);
+  __syncthreads();                   // (wcnt is free: the chunk loop is over)
+  if (lane == 0) wcnt[wv] = nsel;
+  __syncthreads();
+  if (tid == 0) {
+    int t = 0;
+    for (int w = 0; w < 16; ++w) t += wcnt[w];
+    meta[5] = t;
+  }
+  if (cb.rows) {
+    // second segment: live rows [N, N + M) weigh 1, the padding rows [N + M, 2 N) are a valid ray (the reference camera's optical
+    // axis) with zero target / prior and weight 0 — nothing downstream has to know where the live rows end to stay finite
+    const int rs = a.cam.vd ? 11 : 8;
+    float o[3], d[3], v[3];
+    cn_finish_ray(a.cam.t[0], a.cam.t[1], a.cam.t[2], a.cam.r[2], a.cam.r[5], a.cam.r[8], a.cam.vd, a.cam.ndc, a.cam.ax, a.cam.ay, o, d, v);
+    for (int64_t j = tid; j < N; j += 1024) {
+      cb.mask[N + j] = j < M ? 1.f : 0.f;
+      if (j >= M) {
+        float* out = cb.rows + (N + j) * rs;
+        out[0] = o[0]; out[1] = o[1]; out[2] = o[2]; out[3] = d[0]; out[4] = d[1]; out[5] = d[2];
+        out[6] = a.cam.near; out[7] = a.cam.far;
+        if (a.cam.vd) { out[8] = v[0]; out[9] = v[1]; out[10] = v[2]; }
+        cb.target[3 * (N + j)] = 0.f; cb.target[3 * (N + j) + 1] = 0.f; cb.target[3 * (N + j) + 2] = 0.f;
+        cb.prior[N + j] = 0.f;
+      }
     }
+  }
 }
 
 }  // namespace
@@ -277,7 +340,29 @@ extern "C" int cnerf_ss_ref_rays(const cnerf_ss_warp* c, const float* rays_o, co
   a.w2c = load34(c->w2c);
   a.H = c->ref.H; a.W = c->ref.W; a.flip = c->flip; a.image_ch = c->image_ch; a.thr0 = c->thr0;
   hipLaunchKernelGGL(ss_ref_rays_k, dim3(1), dim3(1024), 0, cn_stream(stream), a, rays_o, rays_d, depth, N, image, depth_ref, rows,
-                     rays_od, target, depth_tgt, depth_diff, inb, mask, sel, rank, meta);
+                     rays_od, target, depth_tgt, depth_diff, inb, mask, sel, rank, meta, SsComb{});
+  CN_CHECK_LAUNCH();
+  return CNERF_OK;
+}
+
+extern "C" int cnerf_ss_batch(const cnerf_ss_warp* c, const float* rays_o, const float* rays_d, const float* depth, const float* target_s,
+                              int64_t N, const float* image, const float* depth_ref, const float* amin_global, float* rows2,
+                              float* target2, float* prior2, float* mask2, int32_t* live, float* rays_od, float* depth_diff, uint8_t* inb,
+                              uint8_t* mask, float* sel, int32_t* rank, int32_t* meta, void* stream) {
+  if (!c || !rays_o || !rays_d || !depth || !target_s || !depth_ref || !image || !rows2 || !target2 || !prior2 || !mask2 || !live ||
+      !depth_diff || !rank || !meta || N <= 0 || N >= (1ll << 30) || c->ref.H < 2 || c->ref.W < 2 || !(c->thr0 > 0.f) || c->image_ch < 3)
+    return CNERF_E_ARG;
+  SsDev a = {};
+  cnerf_raygen rg = c->ref;
+  rg.first = 0;
+  int rc = cn_make_raygen(&rg, &a.cam);
+  if (rc) return rc;
+  a.w2c = load34(c->w2c);
+  a.H = c->ref.H; a.W = c->ref.W; a.flip = c->flip; a.image_ch = c->image_ch; a.thr0 = c->thr0;
+  const int rs = a.cam.vd ? 11 : 8;
+  SsComb cb{rows2, target2, prior2, mask2, live, target_s, amin_global};
+  hipLaunchKernelGGL(ss_ref_rays_k, dim3(1), dim3(1024), 0, cn_stream(stream), a, rays_o, rays_d, depth, N, image, depth_ref,
+                     rows2 + N * rs, rays_od, target2 + 3 * N, prior2 + N, depth_diff, inb, mask, sel, rank, meta, cb);
   CN_CHECK_LAUNCH();
   return CNERF_OK;
 }

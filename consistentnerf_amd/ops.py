@@ -259,7 +259,9 @@ def embed(x: Tensor, L: int) -> Tensor:
 
 def mlp_forward(spec: NetSpec, packed: Tensor, B: int, S: int, *, pts: Optional[Tensor] = None,
                 rays: Optional[Tensor] = None, z: Optional[Tensor] = None, dirs: Optional[Tensor] = None,
-                want_stash: bool = False):
+                want_stash: bool = False, live: Optional[Tensor] = None):
+    """`live` (device int32 [1], training + rays form only): the batch is padded to the capacity B and only its first live[0] rays
+    are real (cnerf_mlp_fwd_live): the launch is sized for B, tiles past the count leave zero raw outputs."""
     lib, net = _lib.load(), spec.c()
     pts, rays, z, dirs = _chk(pts, "pts"), _chk(rays, "rays"), _chk(z, "z"), _chk(dirs, "dirs")
     dev = packed.device
@@ -268,6 +270,14 @@ def mlp_forward(spec: NetSpec, packed: Tensor, B: int, S: int, *, pts: Optional[
     if want_stash:
         stash = torch.empty(lib.cnerf_mlp_stash_floats(C.byref(net), B * S), device=dev, dtype=torch.float32)
     rs = rays.shape[1] if rays is not None else 0
+    if live is not None:
+        if not want_stash or rays is None or pts is not None or dirs is not None or live.dtype != torch.int32 or not live.is_cuda:
+            raise CnerfError("mlp_forward(live=...) is the training forward on ray rows (no explicit points / directions); "
+                             "live must be a device int32 tensor")
+        with _timed("mlp_fwd_train", B * S):
+            _lib.check(lib.cnerf_mlp_fwd_live(C.byref(net), _p(packed), _p(rays), rs, _p(z), B, S, _p(raw), _p(stash), _p(live),
+                                              _stream()), "cnerf_mlp_fwd_live")
+        return raw, stash
     with _timed("mlp_fwd_train" if want_stash else "mlp_fwd", B * S):
         _lib.check(lib.cnerf_mlp_fwd(C.byref(net), _p(packed), _p(pts), _p(rays), rs, _p(dirs), _p(z), B, S,
                                      _p(raw), _p(stash), _stream()), "cnerf_mlp_fwd")
@@ -340,8 +350,10 @@ def mlp_forward_embedded(spec: NetSpec, packed: Tensor, x: Tensor, want_stash: b
 
 
 def mlp_backward(spec: NetSpec, packed: Tensor, d_raw: Tensor, B: int, S: int, stash: Tensor,
-                 grads: Optional[List[Tensor]] = None, accumulate: bool = False, packed_bf: Optional[Tensor] = None) -> List[Tensor]:
-    """packed_bf (the three-plane buffer of pack_weights_bf): the dgrad runs in the opt-in bf16x3 arithmetic."""
+                 grads: Optional[List[Tensor]] = None, accumulate: bool = False, packed_bf: Optional[Tensor] = None,
+                 live: Optional[Tensor] = None) -> List[Tensor]:
+    """packed_bf (the three-plane buffer of pack_weights_bf): the dgrad runs in the opt-in bf16x3 arithmetic.
+    live: the forward ran through mlp_forward(live=...) — the backward stops at the same device-side row count (exact fp32)."""
     lib, net = _lib.load(), spec.c()
     d_raw = _chk(d_raw, "d_raw")
     dev = packed.device
@@ -350,6 +362,13 @@ def mlp_backward(spec: NetSpec, packed: Tensor, d_raw: Tensor, B: int, S: int, s
         accumulate = False
     ws = torch.empty(lib.cnerf_mlp_bwd_ws_floats(C.byref(net), B * S), device=dev, dtype=torch.float32)
     ptrs = _ptrs(grads)
+    if live is not None:
+        if packed_bf is not None:
+            raise CnerfError("mlp_backward(live=...) is an exact-fp32 path")
+        with _timed("mlp_bwd_live", B * S):
+            _lib.check(lib.cnerf_mlp_bwd_live(C.byref(net), _p(packed), _p(d_raw), B, S, _p(stash), _p(ws), C.byref(ptrs),
+                                              int(accumulate), _p(live), _stream()), "cnerf_mlp_bwd_live")
+        return grads
     if packed_bf is not None and DGRAD_BF3:
         with _timed("mlp_dgrad_bf3", B * S):
             _lib.check(lib.cnerf_mlp_dgrad_bf(C.byref(net), _p(packed_bf), _p(d_raw), B, S, _p(stash), _p(ws), _stream()),
@@ -367,10 +386,12 @@ def mlp_backward(spec: NetSpec, packed: Tensor, d_raw: Tensor, B: int, S: int, s
 
 def mlp_backward_pair(spec0: NetSpec, packed0: Tensor, d_raw0: Tensor, B0: int, S0: int, stash0: Tensor, grads0: List[Tensor],
                       spec1: NetSpec, packed1: Tensor, d_raw1: Tensor, B1: int, S1: int, stash1: Tensor, grads1: List[Tensor],
-                      accumulate: bool = False, packed_bf0: Optional[Tensor] = None, packed_bf1: Optional[Tensor] = None):
+                      accumulate: bool = False, packed_bf0: Optional[Tensor] = None, packed_bf1: Optional[Tensor] = None,
+                      live: Optional[Tensor] = None):
     """cnerf_mlp_bwd_pair: the backward of two independent networks (coarse / fine) as one dgrad grid, one wgrad grid and
     one reduction; gradients are written (or accumulated) into grads0 / grads1.  packed_bf0 AND packed_bf1: the dgrad grid runs
-    in the opt-in bf16x3 arithmetic."""
+    in the opt-in bf16x3 arithmetic.  live: both levels belong to one ray batch whose live row count sits on the device
+    (mlp_forward(live=...)): cnerf_mlp_bwd_pair_live (exact fp32)."""
     lib = _lib.load()
     n0, n1 = spec0.c(), spec1.c()
     d_raw0, d_raw1 = _chk(d_raw0, "d_raw0"), _chk(d_raw1, "d_raw1")
@@ -378,6 +399,14 @@ def mlp_backward_pair(spec0: NetSpec, packed0: Tensor, d_raw0: Tensor, B0: int, 
     ws0 = torch.empty(lib.cnerf_mlp_bwd_ws_floats(C.byref(n0), B0 * S0), device=dev, dtype=torch.float32)
     ws1 = torch.empty(lib.cnerf_mlp_bwd_ws_floats(C.byref(n1), B1 * S1), device=dev, dtype=torch.float32)
     p0, p1 = _ptrs(grads0), _ptrs(grads1)
+    if live is not None:
+        if packed_bf0 is not None or packed_bf1 is not None:
+            raise CnerfError("mlp_backward_pair(live=...) is an exact-fp32 path")
+        with _timed("mlp_bwd_live", B0 * S0 + B1 * S1):
+            _lib.check(lib.cnerf_mlp_bwd_pair_live(C.byref(n0), _p(packed0), _p(d_raw0), B0, S0, _p(stash0), _p(ws0), C.byref(p0),
+                                                   C.byref(n1), _p(packed1), _p(d_raw1), B1, S1, _p(stash1), _p(ws1), C.byref(p1),
+                                                   int(accumulate), _p(live), _stream()), "cnerf_mlp_bwd_pair_live")
+        return
     if packed_bf0 is not None and packed_bf1 is not None and DGRAD_BF3:
         with _timed("mlp_dgrad_bf3", B0 * S0 + B1 * S1):
             _lib.check(lib.cnerf_mlp_dgrad_bf_pair(C.byref(n0), _p(packed_bf0), _p(d_raw0), B0, S0, _p(stash0), _p(ws0),
@@ -598,10 +627,12 @@ class ClossSpec:
     n: int = 256
     counts: Optional[Tensor] = None
     ss_coins: Optional[tuple] = None      # (rgb, depth, rgb0, depth0) draws of VT:941-969: the in-loop consistency step's primary terms
+    seg_row: int = 0                      # > 0 (with ss_coins): the batch is [primary rays | warped rays + padding] cut here (ss_batch)
+    counts3: Optional[Tensor] = None      # (with seg_row) GLOBAL (selected, primary, warped) ray counts of a batch sharded over ranks
 
     def c(self) -> Closs:
         return Closs(self.target.data_ptr(), None if self.mask is None else self.mask.data_ptr(),
-                     None if self.prior is None else self.prior.data_ptr(), float(self.far))
+                     None if self.prior is None else self.prior.data_ptr(), float(self.far), int(self.seg_row))
 
     def checked(self, B: int) -> "ClossSpec":
         t = _chk(self.target.reshape(-1, 3), "target")
@@ -619,8 +650,11 @@ class ClossSpec:
         coins = None if self.ss_coins is None else tuple(int(bool(c)) for c in self.ss_coins)
         if coins is not None and (len(coins) != 4 or P > 0 or self.counts is not None or m is None):
             raise CnerfError("closs: ss_coins takes 4 draws, a selection mask, no patch term and no global counts")
+        seg = int(self.seg_row)
+        if seg and (coins is None or seg % 8 != 0 or not 0 < seg < B):
+            raise CnerfError(f"closs: seg_row {seg} needs ss_coins, a multiple of 8 and 0 < seg_row < B = {B}")
         return ClossSpec(t, m, pr, float(self.far), float(self.coef), float(self.rgb_w), float(self.depth_w), float(self.patch_w),
-                         mono, P, int(self.n), _chk(self.counts, "counts"), coins)
+                         mono, P, int(self.n), _chk(self.counts, "counts"), coins, seg, _chk(self.counts3, "counts3") if seg else None)
 
 
 def composite_forward_closs(raw: Tensor, z: Tensor, rays: Tensor, noise: Optional[Tensor], white_bkgd: bool, L: ClossSpec):
@@ -642,16 +676,21 @@ def composite_forward_closs(raw: Tensor, z: Tensor, rays: Tensor, noise: Optiona
 
 def closs_finish(L: ClossSpec, B: int, ws_last: Tensor, ws_coarse: Optional[Tensor], depth_last: Optional[Tensor],
                  depth_coarse: Optional[Tensor], want_grad: bool = True):
-    """cnerf_closs_finish -> (terms[8], stats[8], patch_d[levels, P * n] | None)."""
+    """cnerf_closs_finish -> (terms[8], stats[8], patch_d[levels, P * n] | None); with L.seg_row (the one-render in-loop consistency
+    step, cnerf_closs_finish_ss2): terms[12], stats[16] = per level [2 segments][4]."""
     dev = ws_last.device
-    terms, stats = torch.empty(8, device=dev), torch.empty(8, device=dev)
+    terms, stats = torch.empty(12 if L.seg_row else 8, device=dev), torch.empty(16 if L.seg_row else 8, device=dev)
     levels = 2 if ws_coarse is not None else 1
     patch_d = torch.empty(levels, L.P * L.n, device=dev) if (L.P > 0 and want_grad) else None
     a = lambda x: None if x is None else x.data_ptr()  # noqa: E731
     t = ClossTail(a(ws_last), a(ws_coarse), int(B), a(L.counts), L.coef, L.far, L.rgb_w, L.depth_w, L.patch_w,
                   int(L.prior is not None), a(depth_last) if L.P > 0 else None,
                   a(depth_coarse) if (L.P > 0 and levels == 2) else None, a(L.mono) if L.P > 0 else None, L.P, L.n)
-    if L.ss_coins is not None:
+    if L.ss_coins is not None and L.seg_row:
+        coins = (C.c_int32 * 4)(*L.ss_coins)
+        _lib.check(_lib.load().cnerf_closs_finish_ss2(C.byref(t), coins, int(L.seg_row), _p(L.counts3), _p(terms), _p(stats), _stream()),
+                   "cnerf_closs_finish_ss2")
+    elif L.ss_coins is not None:
         coins = (C.c_int32 * 4)(*L.ss_coins)
         _lib.check(_lib.load().cnerf_closs_finish_ss(C.byref(t), coins, _p(terms), _p(stats), _stream()), "cnerf_closs_finish_ss")
     else:
@@ -777,10 +816,10 @@ _PINNED_META = {}
 
 
 def _pinned_meta(dev):
-    """A small ring of pinned int32[4] buffers per device (pinned allocations cost ~100 us each: never per step)."""
+    """A small ring of pinned int32[8] buffers per device (pinned allocations cost ~100 us each: never per step)."""
     ring = _PINNED_META.get(dev.index)
     if ring is None:
-        ring = _PINNED_META[dev.index] = [[torch.empty(4, dtype=torch.int32).pin_memory() for _ in range(8)], 0]
+        ring = _PINNED_META[dev.index] = [[torch.empty(8, dtype=torch.int32).pin_memory() for _ in range(8)], 0]
     ring[1] = (ring[1] + 1) % len(ring[0])
     return ring[0][ring[1]]
 
@@ -788,7 +827,7 @@ def _pinned_meta(dev):
 def ss_ref_rays(rays_o: Tensor, rays_d: Tensor, depth: Tensor, w2c_ref, c2w_ref, K, H: int, W: int, image: Tensor, depth_ref: Tensor,
                 thr0: float, near: float, far: float, use_viewdirs: bool, ndc: bool, ndc_coef=(0.0, 0.0), flip: bool = False,
                 want_rows: bool = True):
-    """cnerf_ss_ref_rays (VT:905-925): one launch + ONE 16-byte read-back (the ray count M of the second render; the reference
+    """cnerf_ss_ref_rays (VT:905-925): one launch + ONE 32-byte read-back (the ray count M of the second render; the reference
     synchronises at every boolean index and every threshold doubling) -> dict(M, k, thr (python float), rows [M, 8|11] | None,
     rays_od [2, M, 3] (views of a [2, N, 3] buffer), target [M, 3], depth_tgt [M], depth_diff [M], inb [N] uint8, mask [M] uint8,
     sel [N] float, rank [N] int32).  image [H, W, >=3] and depth_ref [H, W] live on the device; w2c_ref / c2w_ref are host 3x4|4x4."""
@@ -812,7 +851,7 @@ def ss_ref_rays(rays_o: Tensor, rays_d: Tensor, depth: Tensor, w2c_ref, c2w_ref,
     target, dtgt, diff = torch.empty(N, 3, device=dev), torch.empty(N, device=dev), torch.empty(N, device=dev)
     inb, mask = torch.empty(N, device=dev, dtype=torch.uint8), torch.empty(N, device=dev, dtype=torch.uint8)
     sel, rank = torch.empty(N, device=dev), torch.empty(N, device=dev, dtype=torch.int32)
-    meta = torch.empty(4, device=dev, dtype=torch.int32)
+    meta = torch.empty(8, device=dev, dtype=torch.int32)
     _lib.check(_lib.load().cnerf_ss_ref_rays(C.byref(cfg), _p(rays_o), _p(rays_d), _p(depth), N, _p(image), _p(depth_ref), _p(rows),
                                              _p(od), _p(target), _p(dtgt), _p(diff), _p(inb), _p(mask), _p(sel), _p(rank), _p(meta),
                                              _stream()), "cnerf_ss_ref_rays")
@@ -825,6 +864,48 @@ def ss_ref_rays(rays_o: Tensor, rays_d: Tensor, depth: Tensor, w2c_ref, c2w_ref,
     thr = float(np.int32(int(host[2])).view(np.float32))
     return dict(M=M, k=k, thr=thr, rows=None if rows is None else rows[:M], rays_od=od[:, :M], target=target[:M], depth_tgt=dtgt[:M],
                 depth_diff=diff[:M], inb=inb, mask=mask[:M], sel=sel, rank=rank)
+
+
+def _ss_cfg(w2c_ref, c2w_ref, K, H, W, image, thr0, near, far, use_viewdirs, ndc, ndc_coef, flip) -> "SsWarp":
+    cfg = SsWarp()
+    r = cfg.ref
+    r.H, r.W, r.fx, r.fy, r.cx, r.cy = int(H), int(W), float(K[0][0]), float(K[1][1]), float(K[0][2]), float(K[1][2])
+    r.c2w = _f4(c2w_ref.detach().cpu().numpy() if isinstance(c2w_ref, torch.Tensor) else c2w_ref)
+    r.near, r.far, r.use_viewdirs, r.ndc = float(near), float(far), int(use_viewdirs), int(ndc)
+    r.ndc_ax, r.ndc_ay, r.first = float(ndc_coef[0]), float(ndc_coef[1]), 0
+    cfg.w2c = _f4(w2c_ref.detach().cpu().numpy() if isinstance(w2c_ref, torch.Tensor) else w2c_ref)
+    cfg.flip, cfg.image_ch, cfg.thr0 = int(flip), int(image.shape[2]), float(thr0)
+    return cfg
+
+
+def ss_batch(rays_o: Tensor, rays_d: Tensor, depth: Tensor, target_s: Tensor, w2c_ref, c2w_ref, K, H: int, W: int, image: Tensor,
+             depth_ref: Tensor, thr0: float, near: float, far: float, use_viewdirs: bool, ndc: bool, ndc_coef=(0.0, 0.0),
+             flip: bool = False, amin_global: Optional[Tensor] = None):
+    """cnerf_ss_batch (VT:899-925 for the one-render step): ONE launch, NO read-back -> dict of DEVICE tensors:
+    rows [2N, 8|11], target [2N, 3], prior [2N], mask [2N] (the combined batch: N primary rays | M warped rays | N - M padding),
+    live int32 [1] = N + M, meta int32 [8] (M, k, bits of thr, NaN flag, bits of the local min |diff|, number of selected primary rays),
+    rays_od [2, N, 3], depth_diff [N], inb [N] uint8, occ [N] uint8 (the occlusion mask over the first M), sel [N], rank [N] int32 —
+    the per-M outputs keep their capacity N (the host does not know M; `ss_host_view` slices them after a synchronisation)."""
+    rays_o, rays_d, depth = _chk(rays_o.reshape(-1, 3), "rays_o"), _chk(rays_d.reshape(-1, 3), "rays_d"), _chk(depth.reshape(-1), "depth")
+    target_s = _chk(target_s.reshape(-1, 3), "target_s")
+    image, depth_ref, amin_global = _chk(image, "image"), _chk(depth_ref, "depth_ref"), _chk(amin_global, "amin_global")
+    N, dev = rays_o.shape[0], rays_o.device
+    if image.dim() != 3 or image.shape[0] != H or image.shape[1] != W or image.shape[2] < 3 or depth_ref.numel() != H * W:
+        raise CnerfError(f"ss_batch: image must be [{H}, {W}, >=3] and depth_ref [{H}, {W}]")
+    if rays_d.shape[0] != N or depth.shape[0] != N or target_s.shape[0] != N or N == 0:
+        raise CnerfError("ss_batch: rays_o / rays_d / depth / target_s must describe the same (non-empty) batch")
+    cfg = _ss_cfg(w2c_ref, c2w_ref, K, H, W, image, thr0, near, far, use_viewdirs, ndc, ndc_coef, flip)
+    rows = torch.empty(2 * N, 11 if use_viewdirs else 8, device=dev)
+    target, prior, mask2 = torch.empty(2 * N, 3, device=dev), torch.empty(2 * N, device=dev), torch.empty(2 * N, device=dev)
+    live, meta = torch.empty(1, device=dev, dtype=torch.int32), torch.empty(8, device=dev, dtype=torch.int32)
+    od, diff = torch.empty(2, N, 3, device=dev), torch.empty(N, device=dev)
+    inb, occ = torch.empty(N, device=dev, dtype=torch.uint8), torch.empty(N, device=dev, dtype=torch.uint8)
+    sel, rank = torch.empty(N, device=dev), torch.empty(N, device=dev, dtype=torch.int32)
+    _lib.check(_lib.load().cnerf_ss_batch(C.byref(cfg), _p(rays_o), _p(rays_d), _p(depth), _p(target_s), N, _p(image), _p(depth_ref),
+                                          _p(amin_global), _p(rows), _p(target), _p(prior), _p(mask2), _p(live), _p(od), _p(diff),
+                                          _p(inb), _p(occ), _p(sel), _p(rank), _p(meta), _stream()), "cnerf_ss_batch")
+    return dict(N=N, rows=rows, target=target, prior=prior, mask=mask2, live=live, meta=meta, rays_od=od, depth_diff=diff, inb=inb,
+                occ=occ, sel=sel, rank=rank)
 
 
 def hard_mask_pair(H, W, K, c2w_tgt, w2c_ref, depth_tgt: Tensor, depth_ref: Tensor, thr0: float, chunk: int,

@@ -30,8 +30,9 @@ class RayPoints:
     """Lazy stand-in for the [N_rays, N_samples, 3] point tensor of R:384: the fused kernel evaluates
     o + d*z itself, so the 9.4 MB/step point cloud is never written.  `.materialize()` gives the tensor."""
 
-    def __init__(self, rays, z_vals):
+    def __init__(self, rays, z_vals, live=None):
         self.rays, self.z_vals = rays, z_vals
+        self.live = live          # device int32 [1]: only the first live[0] rays are real (a batch padded to a fixed capacity)
         self.shape = torch.Size([z_vals.shape[0], z_vals.shape[1], 3])
         self.device = z_vals.device
 
@@ -281,7 +282,7 @@ class _MlpFn(torch.autograd.Function):
     """Fused gamma(x), gamma(d) + MLP (replaces R:37-52 + H:44-45 + H:107-130 and their autograd)."""
 
     @staticmethod
-    def forward(ctx, model, B, S, pts, rays, z, dirs, emb, *params):
+    def forward(ctx, model, B, S, pts, rays, z, dirs, emb, live, *params):
         spec = model.spec()
         packed, gen = _packed_gen(model)
         if any(ctx.needs_input_grad[3:8]):
@@ -289,7 +290,7 @@ class _MlpFn(torch.autograd.Function):
             # sample positions (z is detached at R:397, rays come from the data), and the dgrad kernel stops at layer 0
             raise ops.CnerfError("gradients w.r.t. sample positions / rays / view directions / pre-embedded inputs are "
                                  "not implemented (only w.r.t. the network parameters)")
-        train = any(ctx.needs_input_grad[8:])
+        train = any(ctx.needs_input_grad[9:])
         if emb is not None:      # NeRF.forward(x) on pre-embedded inputs
             raw, stash = ops.mlp_forward_embedded(spec, packed, emb, want_stash=train)
         elif train and training_precision(model) == "bf16x3":
@@ -298,7 +299,12 @@ class _MlpFn(torch.autograd.Function):
             ctx.packed_bf, ctx.packed_bf_gen = _packed_bf_gen(model, 3)
             raw, stash = ops.mlp_forward_bf_train(spec, ctx.packed_bf, B, S, pts=pts, rays=rays, z=z, dirs=dirs)
         else:
-            raw, stash = ops.mlp_forward(spec, packed, B, S, pts=pts, rays=rays, z=z, dirs=dirs, want_stash=train)
+            # `live` (device int32 [1]; RayPoints.live): the batch is padded to its capacity B and only the first live[0] rays are
+            # real — the training kernels stop there (run_nerf_view.ss_step_loss: the one-render in-loop consistency step).  Every
+            # other route simply processes the padding rays too (they are valid rays whose loss weight is 0: same result, more work).
+            use_live = live if (train and pts is None and dirs is None and S % 32 == 0) else None
+            raw, stash = ops.mlp_forward(spec, packed, B, S, pts=pts, rays=rays, z=z, dirs=dirs, want_stash=train, live=use_live)
+            ctx.live = use_live
         if train:
             ctx.spec, ctx.B, ctx.S, ctx.stash, ctx.packed, ctx.packed_gen = spec, B, S, stash, packed, gen
             ctx.params, ctx.model = params, model
@@ -320,39 +326,41 @@ class _MlpFn(torch.autograd.Function):
         # step) and autograd gets no per-tensor gradients back.  Anything else — plain nn.Parameters, and
         # torch.autograd.grad() on FusedAdam-owned ones, where the engine captures gradients instead of accumulating them
         # — takes the tensor route and leaves the flat buffer untouched.
-        direct = _direct_ok(ctx.needs_input_grad[8:], params) and _engine_accumulates(params[0])
+        direct = _direct_ok(ctx.needs_input_grad[9:], params) and _engine_accumulates(params[0])
         pair = getattr(ctx, "pair", None)
-        nret = (None,) * (8 + len(params))
+        nret = (None,) * (9 + len(params))
+        live = getattr(ctx, "live", None)
         if direct and pair is not None and pair.fine() is ctx and pair.parked is None:
             c = pair.coarse()
             # park only when the coarse node is certain to run in this very pass, on the direct route as well
-            if (c is not None and c.stash is not None and _direct_ok(c.needs_input_grad[8:], c.params)
+            if (c is not None and c.stash is not None and _direct_ok(c.needs_input_grad[9:], c.params)
                     and _ENGINE_QUERY(c)):
                 pair.parked = (ctx.spec, ctx.packed, g_raw.contiguous(), ctx.B, ctx.S, ctx.stash, [p.grad for p in params],
-                               ctx.model, getattr(ctx, "packed_bf", None), params)
+                               ctx.model, getattr(ctx, "packed_bf", None), params, live)
                 ctx.stash = ctx.packed = ctx.params = ctx.model = None
                 return nret
         parked = None
         if pair is not None and pair.coarse() is ctx and pair.parked is not None:
             parked, pair.parked = pair.parked, None
-        if parked is not None and direct:
-            fs, fp, fg, fB, fS, fst, fgr, fmodel, fbf, fparams = parked
+        if parked is not None and direct and parked[10] is live and (live is None or parked[3] == ctx.B):
+            fs, fp, fg, fB, fS, fst, fgr, fmodel, fbf, fparams, _flive = parked
             ops.mlp_backward_pair(fs, fp, fg, fB, fS, fst, fgr, ctx.spec, ctx.packed, g_raw.contiguous(), ctx.B, ctx.S,
                                   ctx.stash, [p.grad for p in params], accumulate=not _take_dropped(fparams, params), packed_bf0=fbf,
-                                  packed_bf1=getattr(ctx, "packed_bf", None))
+                                  packed_bf1=getattr(ctx, "packed_bf", None), live=live)
             _report_ready_pair(fmodel, ctx.model)
             ctx.stash = ctx.packed = ctx.params = ctx.model = None
             return nret
         if parked is not None:        # (cannot happen — the fine node checked this node's route — but never drop a gradient)
-            fs, fp, fg, fB, fS, fst, fgr, fmodel, fbf, fparams = parked
-            ops.mlp_backward(fs, fp, fg, fB, fS, fst, grads=fgr, accumulate=not _take_dropped(fparams), packed_bf=fbf)
+            fs, fp, fg, fB, fS, fst, fgr, fmodel, fbf, fparams, flive = parked
+            ops.mlp_backward(fs, fp, fg, fB, fS, fst, grads=fgr, accumulate=not _take_dropped(fparams), packed_bf=fbf, live=flive)
             _report_ready(fmodel, True)
         out = [p.grad for p in params] if direct else None
         grads = ops.mlp_backward(ctx.spec, ctx.packed, g_raw.contiguous(), ctx.B, ctx.S, ctx.stash, grads=out,
-                                 accumulate=direct and not _take_dropped(params), packed_bf=getattr(ctx, "packed_bf", None))
+                                 accumulate=direct and not _take_dropped(params), packed_bf=getattr(ctx, "packed_bf", None),
+                                 live=live)
         _report_ready(ctx.model, direct)
         ctx.stash = ctx.packed = ctx.params = ctx.model = None
-        return nret if direct else (None,) * 8 + tuple(grads)
+        return nret if direct else (None,) * 9 + tuple(grads)
 
 
 class _CompositeFn(torch.autograd.Function):
@@ -433,11 +441,12 @@ class _RenderClossFn(torch.autograd.Function):
         d_raw = d_raw_c = None
         if g_loss is not None:
             L = ctx.L
+            w = 8 if L.seg_row else 4       # (two segments: per level [2][4] seed weights, cnerf_closs_finish_ss2)
             if ctx.needs_input_grad[0]:
-                d_raw = ops.composite_backward_closs(raw, z, rays, ctx.noise, ctx.white, L, rgb, depth, stats[0:4], g_loss,
+                d_raw = ops.composite_backward_closs(raw, z, rays, ctx.noise, ctx.white, L, rgb, depth, stats[0:w], g_loss,
                                                      None if patch_d is None else patch_d[0])
             if raw_c is not None and ctx.needs_input_grad[1]:
-                d_raw_c = ops.composite_backward_closs(raw_c, z_c, rays, ctx.noise_c, ctx.white, L, rgb_c, depth_c, stats[4:8],
+                d_raw_c = ops.composite_backward_closs(raw_c, z_c, rays, ctx.noise_c, ctx.white, L, rgb_c, depth_c, stats[w:2 * w],
                                                        g_loss, None if patch_d is None else patch_d[1])
         return (d_raw, d_raw_c) + (None,) * 10
 
@@ -505,9 +514,9 @@ def run_network(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk=1024 * 64
         # inference pass would run the training kernel and write a 10 KB-per-point stash nobody reads
         params = [p.detach() for p in params]
     if isinstance(inputs, RayPoints):
-        return _MlpFn.apply(fn, B, S, None, inputs.rays, inputs.z_vals, dirs, None, *params)
+        return _MlpFn.apply(fn, B, S, None, inputs.rays, inputs.z_vals, dirs, None, getattr(inputs, "live", None), *params)
     pts = inputs.reshape(-1, 3).contiguous()
-    return _MlpFn.apply(fn, B, S, pts, None, None, dirs, None, *params)
+    return _MlpFn.apply(fn, B, S, pts, None, None, dirs, None, None, *params)
 
 
 def _is_viewdir_columns(viewdirs, rays):
@@ -574,6 +583,8 @@ def batchify_rays(rays_flat, chunk=1024 * 32, **kwargs):
     """R:55-67."""
     all_ret = {}
     gr = kwargs.pop("_global_rows", None)
+    if kwargs.get("_live") is not None and rays_flat.shape[0] > chunk:
+        raise ops.CnerfError(f"_live needs the padded batch ({rays_flat.shape[0]} rows) to fit one chunk ({chunk})")
     if gr is not None and rays_flat.shape[0] > chunk:
         # every chunk would draw the whole batch's stream afresh, while the unsharded call draws one stream PER CHUNK: the
         # "N-rank step sees the 1-rank step's random numbers row for row" guarantee holds for shards that fit one chunk
@@ -877,12 +888,14 @@ def _create_nerf(args, model_cls, view_variant):
 
 def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False, lindisp=False, perturb=0.,
                 N_importance=0, network_fine=None, white_bkgd=False, raw_noise_std=0., verbose=False, pytest=False,
-                _with_depth=False, _debug=False, _global_rows=None, _target=None):
+                _with_depth=False, _debug=False, _global_rows=None, _target=None, _live=None):
     """R:311-421 (V:441-551 when _with_depth).  Returns the same dict (+ the sample depths when _debug).
     `_global_rows = (offset, total)`: `ray_batch` is rows [offset, offset + N_rays) of a global batch of `total` rays sharded over
     ranks — the jitter / resampling / noise streams are drawn for the whole batch and sliced (_rows_of_global).
     `_target` [N_rays, 3] (render_loss): the compositing launches also produce ret['loss'] = img2mse(rgb_map, _target)
-    (+ img2mse(rgb0, _target) with two levels) through _RenderLossFn; the maps are then detached values."""
+    (+ img2mse(rgb0, _target) with two levels) through _RenderLossFn; the maps are then detached values.
+    `_live` (device int32 [1]): `ray_batch` is padded to a fixed capacity, only its first _live[0] rows are real rays (the rest are
+    valid dummy rays whose loss weight is 0): the MLP training kernels stop at the count, which never visits the host."""
     rays = ray_batch if ray_batch.is_contiguous() else ray_batch.contiguous()
     N_rays, dev = rays.shape[0], rays.device
     if N_rays == 0:   # nothing to launch (the reference's batchify_rays raises on an empty batch; here: empty maps)
@@ -913,7 +926,7 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
     z_vals = ops.coarse_z(rays, N_samples, t_rand, lindisp, rng=rng)
     if N_importance > 0:
         _prepack_pair(network_fn, network_fine)
-    raw = network_query_fn(RayPoints(rays, z_vals), viewdirs, network_fn)
+    raw = network_query_fn(RayPoints(rays, z_vals, _live), viewdirs, network_fn)
     noise = _density_noise((N_rays, N_samples), raw_noise_std, pytest, dev, _global_rows)
     loss = loss_c = terms = None
     if _target is None:
@@ -948,17 +961,19 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
         z_vals, z_std = ops.resample(z_vals, weights, u, rng=rng, Nf=N_importance)   # R:395-399 + R:415, no gradient (R:397)
         run_fn = network_fn if network_fine is None else network_fine
         raw_coarse = raw
-        raw = network_query_fn(RayPoints(rays, z_vals), viewdirs, run_fn)
+        raw = network_query_fn(RayPoints(rays, z_vals, _live), viewdirs, run_fn)
         _link_levels(raw_coarse, raw)
         noise = _density_noise((N_rays, N_samples + N_importance), raw_noise_std, pytest, dev, _global_rows)
         if _target is None:
             rgb_map, disp_map, acc_map, weights, depth_map = _CompositeFn.apply(raw, z_vals, rays, noise, bool(white_bkgd))
         elif isinstance(_target, ops.ClossSpec):
             rc = raw_coarse
-            if _target.ss_coins is not None and not (_target.ss_coins[2] or (_target.prior is not None and _target.ss_coins[3])):
+            if (_target.ss_coins is not None and not _target.seg_row
+                    and not (_target.ss_coins[2] or (_target.prior is not None and _target.ss_coins[3]))):
                 # VT:959 / VT:966 with both coarse coins 0: no term of this render depends on the coarse network (its colour term
                 # falls back to the FINE rgb, its depth term is absent) — as in the reference's graph, the coarse level then has no
-                # backward at all (left attached, its dgrad + wgrad would run on zero seeds: 16 % of the step for nothing)
+                # backward at all (left attached, its dgrad + wgrad would run on zero seeds: 16 % of the step for nothing).  (Not in the
+                # one-render form of the step, seg_row > 0: the second render's coarse terms always reach the coarse network.)
                 rc = raw_coarse.detach()
             loss, terms, rgb_map, disp_map, acc_map, weights, depth_map = _RenderClossFn.apply(
                 raw, rc, z_vals, z_coarse, rays, noise, noise_coarse, bool(white_bkgd), _target, rgb_map_0, depth_map_0, ws_c)

@@ -267,10 +267,7 @@ def _ss_rays(rays_o, rays_d, depth_cas_s, pose_ref, K, image_ref, depth_ref, H, 
     """VT:905-925 as ONE launch (ops.ss_ref_rays) + one 16-byte read-back -> the dictionary ss_consistency returns, minus the
     second render."""
     dev = rays_o.device
-    c2w_ref = torch.eye(4)
-    c2w_ref[:3, :4] = torch.as_tensor(np.asarray(pose_ref.cpu() if isinstance(pose_ref, torch.Tensor) else pose_ref),
-                                      dtype=torch.float32)[:3, :4]
-    w2c_ref = torch.inverse(c2w_ref)                       # 4x4 on the host, as VT:910
+    c2w_ref, w2c_ref = _ss_pose(pose_ref)
     img = torch.as_tensor(image_ref, dtype=torch.float32).to(dev)
     dep = torch.as_tensor(depth_ref, dtype=torch.float32).to(dev)
     # the warp, the compaction of the in-bounds points (`x[mask]` in the reference: a host sync per boolean index), the reference
@@ -380,8 +377,116 @@ def _ss_coins_lines(coins4, with_depth):
     return c if with_depth else [c[0], c[2]]
 
 
+_SS_TERM_NAMES = ("loss", "img_loss", "depth_loss", None, "img_loss0", "depth_loss0", None, "M", "img_loss_ref", "depth_loss_ref",
+                  "img_loss0_ref", "depth_loss0_ref")
+
+
+def _ss_pose(pose_ref):
+    c2w_ref = torch.eye(4)
+    c2w_ref[:3, :4] = torch.as_tensor(np.asarray(pose_ref.cpu() if isinstance(pose_ref, torch.Tensor) else pose_ref),
+                                      dtype=torch.float32)[:3, :4]
+    return c2w_ref, torch.inverse(c2w_ref)                 # 4x4 on the host, as VT:910
+
+
+def _ss_one_render_ok(batch_rays, target_s, depth_cas_s, render_kwargs, chunk):
+    """The one-render form of the step needs: a single chunk for the 2N-row batch, N a multiple of the 8 rays of a compositing
+    workgroup (the loss partials of a workgroup belong to one segment), scalar bounds, device fp32 inputs, the stock query."""
+    rays_o = batch_rays[0]
+    n = rays_o.reshape(-1, 3).shape[0]
+    t = target_s if torch.is_tensor(target_s) else None
+    near, far = render_kwargs.get('near', 0.), render_kwargs.get('far', 1.)
+    return (n > 0 and n % 8 == 0 and 2 * n <= chunk and rays_o.is_cuda and t is not None and t.is_cuda and t.dtype == torch.float32
+            and t.reshape(-1, 3).shape[0] == n and torch.is_tensor(depth_cas_s) and depth_cas_s.is_cuda
+            and not torch.is_tensor(near) and not torch.is_tensor(far) and render_kwargs.get('c2w') is None
+            and isinstance(render_kwargs.get('network_fn'), NeRF))
+
+
+def ss_global_stats(meta, n_local, group=None):
+    """The two exchanges a SHARDED `--ss_loss` step needs (VT:917-921 and VT:941-966 are batch-global): from the `meta` of
+    this rank's ops.ss_batch call -> (amin_global [1] float: all-reduce MIN of the ranks' minimum |z - D_ref|, the input of the
+    threshold-doubling rule), and a function counts3(meta2) -> [3] float: all-reduce SUM of (selected primary rays, primary rays,
+    warped rays) once the global threshold has been applied (the `meta` of the second ops.ss_batch call)."""
+    import torch.distributed as dist
+    amin = meta[4:5].view(torch.float32).clone()
+    on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    if on:
+        dist.all_reduce(amin, op=dist.ReduceOp.MIN, group=group)
+
+    def counts3(meta2):
+        c = torch.stack([meta2[5].to(torch.float32), torch.tensor(float(n_local), device=meta2.device), meta2[0].to(torch.float32)])
+        if on:
+            dist.all_reduce(c, op=dist.ReduceOp.SUM, group=group)
+        return c
+    return amin, counts3
+
+
+def ss_host_view(info):
+    """`ss_step_loss`'s one-render `info` in the reference's shapes (a HOST SYNCHRONISATION: reads M and the threshold back): the
+    dictionary of the two-render route — mask [M, 1], batch_rays_ref [2, M, 3], rgb_target_ref [1, 3, M], rays_depth_ref [1, 1, M],
+    rgb_ref [M, 3], depth_pred_ref [M], threshold (0-d tensor) ... — for logging, tests and callers written against VT:905-938."""
+    if "meta" not in info:
+        return info
+    meta = info["meta"].cpu()
+    M, N = int(meta[0]), info["N"]
+    out = dict(info)
+    out.update(M=M, threshold=torch.tensor(float(np.int32(int(meta[2])).view(np.float32)), dtype=torch.float32),
+               mask=info["occ"][:M].view(torch.bool)[:, None], batch_rays_ref=info["rays_od"][:, :M],
+               rgb_target_ref=info["_target2"][N:N + M].t()[None], rays_depth_ref=info["_prior2"][N:N + M][None, None],
+               rgb_ref=info["rgb_ref"][:M], depth_pred_ref=info["depth_pred_ref"][:M],
+               extras_ref={k: v[:M] for k, v in info["extras_ref"].items()})
+    return out
+
+
+def _ss_step_one_render(H, W, K, batch_rays, target_s, depth_cas_s, pose_ref, image_ref, depth_ref, render_kwargs, chunk,
+                        occlusion_threshold, with_depth_loss, coins, global_stats, group):
+    """VT:899-969 as ONE render of 2N rows (ops.ss_batch + the two-segment loss tail): no host synchronisation anywhere — the second
+    render's ray count M exists only in device memory (the MLP launches are sized for the capacity and stop at the device-side
+    count), so the step can be recorded as a hipGraph; 15 launches, all own kernels."""
+    rays_o, rays_d = batch_rays[0], batch_rays[1]
+    dev = rays_o.device
+    c2w_ref, w2c_ref = _ss_pose(pose_ref)
+    img = torch.as_tensor(image_ref, dtype=torch.float32).to(dev)
+    dep = torch.as_tensor(depth_ref, dtype=torch.float32).to(dev)
+    near, far = float(render_kwargs.get('near', 0.)), float(render_kwargs.get('far', 1.))
+    vd, ndc = bool(render_kwargs.get('use_viewdirs', False)), bool(render_kwargs.get('ndc', True))
+    coef = ndc_coefficients(H, W, K[0][0]) if ndc else (0., 0.)
+    args = (rays_o, rays_d, depth_cas_s, target_s, w2c_ref.numpy(), c2w_ref.numpy(), K, H, W, img, dep, float(occlusion_threshold),
+            near, far, vd, ndc, coef)
+    counts3 = None
+    if global_stats is not None:          # the caller ran the exchanges (tests: the shards of one batch on one GPU)
+        amin_g, counts3 = global_stats
+        b = ops.ss_batch(*args, flip=False, amin_global=amin_g)
+    elif group is not None:
+        b0 = ops.ss_batch(*args, flip=False)
+        amin_g, counts_fn = ss_global_stats(b0["meta"], b0["N"], group)
+        b = ops.ss_batch(*args, flip=False, amin_global=amin_g)
+        counts3 = counts_fn(b["meta"])
+    else:
+        b = ops.ss_batch(*args, flip=False)
+    N = b["N"]
+    spec = ops.ClossSpec(b["target"], b["mask"], b["prior"] if with_depth_loss else None, 1.0, 0.0, 1.0, 1.0, 0.0, None, 0, 256, None,
+                         tuple(coins), N, counts3)
+    kw = {k: v for k, v in render_kwargs.items() if k not in ('near', 'far', 'ndc', 'use_viewdirs', 'c2w_staticcam', 'c2w')}
+    ret = batchify_rays(b["rows"], chunk, _with_depth=True, _target=spec, _live=b["live"], **dict(kw, retraw=True))
+    loss, t = ret.pop('loss'), ret.pop('loss_terms')
+    terms = {k: t[i] for i, k in enumerate(_SS_TERM_NAMES) if k is not None}
+    cut = lambda x: (x[:N], x[N:])  # noqa: E731
+    rgb, rgb_ref = cut(ret['rgb_map'])
+    disp, _ = cut(ret['disp_map'])
+    acc, _ = cut(ret['acc_map'])
+    depth, depth_ref_pred = cut(ret['depth_map'])
+    extras = {k: v[:N] for k, v in ret.items() if k not in ('rgb_map', 'disp_map', 'acc_map', 'depth_map')}
+    extras_ref = {k: v[N:] for k, v in ret.items() if k not in ('rgb_map', 'disp_map', 'acc_map', 'depth_map')}
+    info = dict(N=N, loss=loss, terms=terms, live=b["live"], meta=b["meta"], mask_bound=b["inb"].view(torch.bool)[None], occ=b["occ"],
+                sel=b["sel"], rank=b["rank"], rays_od=b["rays_od"], depth_diff=b["depth_diff"], rows=b["rows"], _target2=b["target"],
+                _prior2=b["prior"], _mask2=b["mask"], rgb=rgb, disp=disp, acc=acc, depth_pred=depth, extras=extras, rgb_ref=rgb_ref,
+                depth_pred_ref=depth_ref_pred, extras_ref=extras_ref, img_loss=terms["img_loss"], img_loss0=terms["img_loss0"],
+                coins=tuple(coins), route="one_render")
+    return loss, info
+
+
 def ss_step_loss(H, W, K, batch_rays, target_s, depth_cas_s, pose_ref, image_ref, depth_ref, render_kwargs, chunk=1024 * 32,
-                 occlusion_threshold=0.1, with_depth_loss=False, coins=None):
+                 occlusion_threshold=0.1, with_depth_loss=False, coins=None, route=None, global_stats=None, group=None):
     """The whole loss of one `--ss_loss` step of run_nerf_view_test.train() (VT:899-969) as ONE call, at the standard of
     render_loss: the warp / compaction / reference-ray launch FIRST (it depends on the batch only), then the primary render with its
     terms — each behind its `random.randint(0, 1)` coin, restricted to the rays `[mask_bound][mask]` — folded into its compositing
@@ -390,21 +495,40 @@ def ss_step_loss(H, W, K, batch_rays, target_s, depth_cas_s, pose_ref, image_ref
     order (two draws without the depth loss).  -> (loss, info): info carries ss_consistency's dictionary (`mask_bound`, `mask`,
     `sel`, `threshold`, `batch_rays_ref`, the second render's maps) plus the primary render's `rgb`, `disp`, `acc`, `depth_pred`,
     `extras`, `img_loss`, `img_loss0` and the two partial losses `loss_primary`, `loss_ref`.
-    Values: the reference's lines up to summation order (the loss adds the second render's terms first there; here last)."""
+    Values: the reference's lines up to summation order (the loss adds the second render's terms first there; here last).
+
+    route (round 6): "one_render" — the primary rays and the warped rays are rendered as ONE batch of 2N rows (ops.ss_batch builds
+    it in the warp launch; rows past N + M are padding) with a two-segment loss tail (cnerf_closs_finish_ss2), the loss accumulated
+    in the reference's own order: half the MFMA launches, 15 launches in all, and NO host synchronisation — M lives on the device
+    only, so `info` holds capacity-N tensors (`ss_host_view(info)` gives the reference's shapes at the cost of a sync) and the step
+    can be recorded as a hipGraph; "two_renders" — round 5's form described above (one 16-byte read-back).  None: one_render when
+    the batch qualifies (_ss_one_render_ok), else two_renders.
+    Sharded batches: `group` = the process group whose ranks each hold a slice of the batch (two small all-reduces: MIN
+    of the minimum |z - D_ref| for the threshold rule, SUM of the three ray counts the means divide by), or `global_stats` =
+    (amin_global, counts3) when the caller ran them; the per-rank losses then ADD UP to the unsharded loss (GradReducer(mean=False))."""
     import random
     rays_o, rays_d = batch_rays[0], batch_rays[1]
-    info = _ss_rays(rays_o, rays_d, depth_cas_s, pose_ref, K, image_ref, depth_ref, H, W, render_kwargs, occlusion_threshold)
     if coins is None:
         c_rgb = random.randint(0, 1)
         c_dep = random.randint(0, 1) if with_depth_loss else 0
         c_rgb0 = random.randint(0, 1) if render_kwargs.get('N_importance', 0) > 0 else 0
         c_dep0 = random.randint(0, 1) if (with_depth_loss and render_kwargs.get('N_importance', 0) > 0) else 0
         coins = (c_rgb, c_dep, c_rgb0, c_dep0)
+    ok = _ss_one_render_ok(batch_rays, target_s, depth_cas_s, render_kwargs, chunk)
+    if route == "one_render" and not ok:
+        raise ops.CnerfError("ss_step_loss(route='one_render'): the batch does not qualify (N % 8, 2 N <= chunk, scalar bounds, "
+                             "device fp32 inputs)")
+    if (global_stats is not None or group is not None) and not (ok and route != "two_renders"):
+        raise ops.CnerfError("ss_step_loss: sharded batches take the one-render route")
+    if ok and route != "two_renders":
+        return _ss_step_one_render(H, W, K, batch_rays, target_s, depth_cas_s, pose_ref, image_ref, depth_ref, render_kwargs, chunk,
+                                   occlusion_threshold, with_depth_loss, coins, global_stats, group)
+    info = _ss_rays(rays_o, rays_d, depth_cas_s, pose_ref, K, image_ref, depth_ref, H, W, render_kwargs, occlusion_threshold)
     lp, terms, rgb, disp, acc, depth, extras = render_loss(
         H, W, K, target_s, mask=info["sel"], depth_prior=depth_cas_s.reshape(-1) if with_depth_loss else None, chunk=chunk,
         rays=batch_rays, depth_far=1.0, mono=None, _ss_coins=tuple(coins), **dict(render_kwargs, retraw=True))
     ls = _ss_second_render(info, H, W, K, render_kwargs, chunk, with_depth_loss)
     loss = ls + lp
     info.update(loss=loss, loss_primary=lp, loss_ref=ls, rgb=rgb, disp=disp, acc=acc, depth_pred=depth, extras=extras,
-                img_loss=terms.get("img_loss"), img_loss0=terms.get("img_loss0"), coins=tuple(coins))
+                img_loss=terms.get("img_loss"), img_loss0=terms.get("img_loss0"), coins=tuple(coins), route="two_renders")
     return loss, info

@@ -21,7 +21,11 @@
 extern "C" {
 #endif
 
-#define CNERF_ABI_VERSION 5   /* 5: + cnerf_ss_ref_rays (the in-loop consistency block's warp / compaction / reference rays / occlusion mask as one
+#define CNERF_ABI_VERSION 6   /* 6: + the in-loop consistency step as ONE render whose row count lives on the device: cnerf_ss_batch (the combined
+                                * batch + its live-row count), cnerf_mlp_fwd_live / cnerf_mlp_bwd_live / cnerf_mlp_bwd_pair_live (launches of a fixed
+                                * capacity that stop at a device-side count), cnerf_closs_finish_ss2 (the two-segment loss tail); cnerf_closs gains
+                                * a trailing `seg_row` (0 = the v5 behaviour), cnerf_ss_ref_rays' meta grows to 8 ints; otherwise v5 unchanged.
+                                * 5: + cnerf_ss_ref_rays (the in-loop consistency block's warp / compaction / reference rays / occlusion mask as one
                                 * launch), cnerf_closs_finish_ss (its primary terms folded into compositing); every v4 entry point unchanged.   4: + cnerf_sample_pixels (one-launch training batch of an image), the ConsistentNeRF losses folded into
                                 * compositing (cnerf_closs, *_closs, cnerf_closs_finish); cnerf_masked_loss uses its workspace for
                                 * batches > 16384 rays; every v3 entry point unchanged.   3: + in-kernel uniform streams (cnerf_rng, *_rng) and compositing with img2mse folded in (*_mse);
@@ -115,6 +119,13 @@ int cnerf_mlp_fwd(const cnerf_net* net, const float* packed, const float* pts, c
  * the stash (and therefore cnerf_mlp_bwd with B=M, S=1) works unchanged. */
 int cnerf_mlp_fwd_embedded(const cnerf_net* net, const float* packed, const float* x_embedded, int64_t M,
                            float* raw, float* stash, void* stream);
+/* cnerf_mlp_fwd (rays form) over a batch padded to a fixed CAPACITY of B rays whose live row count sits in device memory
+ * (live_rays[0] <= B, e.g. cnerf_ss_batch's `live`): the launch is sized for B — the host never reads the count, the step stays
+ * free of host synchronisation and capturable as a hipGraph — and the 32-point tiles at or beyond live_rays[0] * S retire at once,
+ * leaving ZERO raw outputs (sigma = 0: compositing gives such a ray weight 0) and no stash.  Training form only (stash required);
+ * S must be a multiple of 32. */
+int cnerf_mlp_fwd_live(const cnerf_net* net, const float* packed, const float* rays, int ray_stride, const float* z, int64_t B, int S,
+                       float* raw, float* stash, const int32_t* live_rays, void* stream);
 /* ---- OPT-IN reduced-precision inference forward (never the default path, never used for training) -------------------
  * The same fused encoding + MLP as cnerf_mlp_fwd (run_nerf.py:37-52, run_nerf_helpers.py:107-130), its GEMMs on the bf16
  * matrix cores with every operand split into `planes` bf16 terms and fp32 accumulation:
@@ -166,6 +177,15 @@ int cnerf_mlp_bwd_pair(const cnerf_net* net0, const float* packed0, const float*
                        const float* stash0, float* workspace0, const cnerf_ptrs* grads0,
                        const cnerf_net* net1, const float* packed1, const float* d_raw1, int64_t B1, int S1,
                        const float* stash1, float* workspace1, const cnerf_ptrs* grads1, int accumulate, void* stream);
+/* cnerf_mlp_bwd / cnerf_mlp_bwd_pair of a forward that ran through cnerf_mlp_fwd_live: activation-gradient tiles and weight-gradient
+ * point ranges stop at live_rays[0] * S of their level (both levels of the pair belong to ONE ray batch: B0 == B1).  Exact fp32. */
+int cnerf_mlp_bwd_live(const cnerf_net* net, const float* packed, const float* d_raw, int64_t B, int S, const float* stash,
+                       float* workspace, const cnerf_ptrs* grads, int accumulate, const int32_t* live_rays, void* stream);
+int cnerf_mlp_bwd_pair_live(const cnerf_net* net0, const float* packed0, const float* d_raw0, int64_t B0, int S0,
+                            const float* stash0, float* workspace0, const cnerf_ptrs* grads0,
+                            const cnerf_net* net1, const float* packed1, const float* d_raw1, int64_t B1, int S1,
+                            const float* stash1, float* workspace1, const cnerf_ptrs* grads1, int accumulate,
+                            const int32_t* live_rays, void* stream);
 /* Its two halves (cf. cnerf_mlp_dgrad / cnerf_mlp_wgrad). */
 int cnerf_mlp_dgrad_pair(const cnerf_net* net0, const float* packed0, const float* d_raw0, int64_t B0, int S0,
                          const float* stash0, float* workspace0, const cnerf_net* net1, const float* packed1,
@@ -237,6 +257,8 @@ typedef struct cnerf_closs {
   const float* mask;     /* [B] floats 0 / 1, or NULL */
   const float* prior;    /* [B] depth prior, or NULL (no depth term) */
   float far;             /* depth terms compare depth / far (V:1737) */
+  int64_t seg_row;       /* 0, or (cnerf_closs_finish_ss2) the first ray of the batch's SECOND segment: cnerf_composite_bwd_closs then
+                          * takes `stats` as [2][4] and seeds rays >= seg_row with the second set */
 } cnerf_closs;
 typedef struct cnerf_closs_sum {
   const float* ws_last;      /* workspace of the last (fine) level's forward */
@@ -263,6 +285,18 @@ int cnerf_closs_finish(const cnerf_closs_sum* t, float* terms, float* stats, flo
  * terms; loss = img_loss + depth + img_loss0 + depth0 in that order.  terms / stats as cnerf_closs_finish (no patch term, no
  * global counts: P must be 0, counts NULL). */
 int cnerf_closs_finish_ss(const cnerf_closs_sum* t, const int32_t* coins4, float* terms, float* stats, void* stream);
+/* The WHOLE `--ss_loss` step (run_nerf_view_test.py:899-969) rendered as ONE batch of t->B rays = [the N primary rays | the M <= N
+ * warped rays of the second render + N - M padding rays] (cnerf_ss_batch), cut at seg_row = N (a multiple of the 8 rays of a
+ * compositing workgroup): mask / target / prior of the compositing launches = cnerf_ss_batch's mask2 / target2 / prior2, far = 1.
+ *   second segment  (:930-938)  img2mse(rgb_ref, rgb_target_ref) [+ img2mse(depth_pred_ref, rays_depth_ref)] of the fine, then of the
+ *                               coarse level: means over the M live rows (mask 1; the padding rows carry mask 0 and weight 0)
+ *   first segment   (:941-969)  the four coin-gated terms of cnerf_closs_finish_ss
+ * accumulated in the reference's order (second render's terms first).  M is the device-side count of mask-1 rows of the second
+ * segment — the host never needs it; counts3 (nullable, device) = the GLOBAL (selected primary rays, primary rays, warped rays) of a
+ * batch sharded over ranks.  terms12 = the 8 of cnerf_closs_finish_ss (terms12[7] = M as a float) + img_ref, depth_ref, img0_ref,
+ * depth0_ref;  stats16 = per level [2 segments][4]: (w1, w0, wd, -) — level l passes stats16 + 8 l to cnerf_composite_bwd_closs. */
+int cnerf_closs_finish_ss2(const cnerf_closs_sum* t, const int32_t* coins4, int64_t seg_row, const float* counts3, float* terms12,
+                           float* stats16, void* stream);
 int cnerf_composite_bwd_closs(const float* raw, int raw_ch, const float* z, const float* rays, int ray_stride, const float* noise,
                               int64_t B, int S, int white_bkgd, const cnerf_closs* L, const float* rgb, const float* depth,
                               const float* stats, const float* g_loss, float rgb_w, float depth_w, float patch_w,
@@ -422,7 +456,10 @@ int cnerf_hard_mask_pair(int H, int W, float fx, float fy, float cx, float cy, c
  *                    mask.sum() > 0, a host synchronisation per doubling in the reference; k <= 63)
  *   inb[N]           mask_bound;   rank[N] = row of ray i among the M (or -1);   sel[N] = 1.0 where inb AND mask[rank] — the rays
  *                    `x[mask_bound.squeeze()][mask.squeeze()]` selects in the primary render's terms (:941-969) — else 0.0
- *   meta[4]          M, k, the bits of thr (float), 1 if some depth_diff is NaN (then k = 0, as torch.min propagates NaN)
+ *   meta[8]          M, k, the bits of thr (float), 1 if some depth_diff is NaN (a NaN passes no threshold, as in the reference's
+ *                    loop: the doubling runs on the minimum of the others; k = 63 and an empty mask only if NO |diff| is finite),
+ *                    the bits of the minimum |diff| of THIS call's points (float; +inf without in-bounds points), the number of
+ *                    primary rays `sel` selects, 2 unused
  * depth_diff, rank and meta are required (workspaces of the second sweep); rows, rays_od, target, depth_tgt, inb, mask, sel may be
  * NULL.  One workgroup, deterministic.  M = 0 is reported, not an error (the reference loops forever there). */
 typedef struct cnerf_ss_warp {
@@ -435,6 +472,20 @@ typedef struct cnerf_ss_warp {
 int cnerf_ss_ref_rays(const cnerf_ss_warp* cfg, const float* rays_o, const float* rays_d, const float* depth, int64_t N,
                       const float* image, const float* depth_ref, float* rows, float* rays_od, float* target, float* depth_tgt,
                       float* depth_diff, uint8_t* inb, uint8_t* mask, float* sel, int32_t* rank, int32_t* meta, void* stream);
+/* The same launch assembling the ONE batch the whole `--ss_loss` step renders (run_nerf_view.ss_step_loss; :899-969), capacity 2 N rows:
+ *   rows2[2N][8|11]  [0, N) the batch's own rays packed as render() packs them (run_nerf.py:100-125), [N, N + M) the reference rays
+ *                    (cnerf_ss_ref_rays' rows), [N + M, 2N) padding: the reference camera's optical axis, a valid ray
+ *   target2[2N][3]   target_s | the reference view's colours at the snapped pixels | 0
+ *   prior2[2N]       depth (the batch's prior, :894) | the reference view's depth prior there | 0
+ *   mask2[2N]        sel | 1 | 0      — the loss mask of the compositing launches (cnerf_closs, cnerf_closs_finish_ss2)
+ *   live[1]          N + M            — for cnerf_mlp_fwd_live / cnerf_mlp_bwd_pair_live: nothing on the host waits for M
+ * amin_global (nullable, device float): the minimum of |z - D_ref| over ALL ranks' in-bounds points of a batch sharded across ranks
+ * (all-reduce MIN of meta[4] of a first call): the doubling rule then yields the global batch's threshold on every rank.
+ * rays_od, inb, mask, sel may be NULL; depth_diff, rank, meta[8] as for cnerf_ss_ref_rays. */
+int cnerf_ss_batch(const cnerf_ss_warp* cfg, const float* rays_o, const float* rays_d, const float* depth, const float* target_s,
+                   int64_t N, const float* image, const float* depth_ref, const float* amin_global, float* rows2, float* target2,
+                   float* prior2, float* mask2, int32_t* live, float* rays_od, float* depth_diff, uint8_t* inb, uint8_t* mask,
+                   float* sel, int32_t* rank, int32_t* meta, void* stream);
 
 /* img2mse (run_nerf_helpers.py:9): loss[0] = mean((x - y)^2) over n elements; d_x (nullable) = 2 (x - y) / n, the
  * gradient of the loss w.r.t. x.  One launch, fixed summation order. */

@@ -15,7 +15,7 @@ import sys
 SHORT = (("mlp_fwd_bfs_k<8, 3, true>", "fwd_train_bf3"), ("mlp_fwd_bfs_k<8, 1", "mlp_fwd_bf1"), ("mlp_fwd_bfs_k<8, 2", "mlp_fwd_bf2"),
          ("mlp_fwd_bfs_k<8, 3", "mlp_fwd_bf3"), ("mlp_dgrad_bfs_k", "dgrad_bf3"), ("wgrad_mixed_k", "wgrad_bf3"),
          ("mlp_fwd_bf_k<8, 1>", "mlp_fwd_bf1"), ("mlp_fwd_bf_k<8, 2>", "mlp_fwd_bf2"), ("mlp_fwd_bf_k<8, 3>", "mlp_fwd_bf3"),
-         ("mlp_fwd_k<8, true, true>", "mlp_fwd_train"), ("mlp_fwd_k<8, true, false>", "mlp_fwd_inf"), ("mlp_fwd_k", "mlp_fwd"),
+         ("mlp_fwd_k<8, true, true", "mlp_fwd_train"), ("mlp_fwd_k<8, true, false", "mlp_fwd_inf"), ("mlp_fwd_k", "mlp_fwd"),
          ("mlp_dgrad_k", "mlp_dgrad"), ("wgrad_reduce_k", "wgrad_reduce"), ("wgrad_k", "wgrad"))
 
 

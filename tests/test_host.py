@@ -30,7 +30,7 @@ def test_header_symbols_all_exported(lib):
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r" T (cnerf_[a-z0-9_]+)", out))
     assert declared <= exported, declared - exported
-    assert lib.cnerf_abi_version() == 5
+    assert lib.cnerf_abi_version() == 6
     assert lib.cnerf_strerror(-2).decode().startswith("configuration")
 
 
