@@ -617,7 +617,12 @@ def c3_scene(dev):
     t_masks = time.perf_counter() - t0
     mono = 1.0 / np.maximum(depths, 1e-3)
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(dev)  # noqa: E731
+    # the in-loop consistency leg compares UN-normalised depths (VT:933, VT:950: no / far): the analytic scene's background depth of
+    # ~1417 (rays that miss the geometry) would make its loss a sum of (1417 - d)^2 outliers (~1e4: round 5's `final_loss`), so that
+    # leg reads priors bounded by the far plane
+    dep_ss = np.minimum(depths, far)
     return dict(H=H, W=W, K=K, near=near, far=far, poses=poses, kw=kw_train, opt=optimizer, images=images, depths=depths, masks=masks,
+                dep_ss_t=[t(dep_ss[i]) for i in range(3)],
                 img_t=[t(images[i]) for i in range(3)], dep_t=[t(depths[i]) for i in range(3)],
                 msk_t=[t(masks[i]) for i in range(3)], mono_t=[t(mono[i]) for i in range(3)], t_masks=t_masks)
 
@@ -661,9 +666,10 @@ def c3_ss_step_fn(sc, route="ss_step_loss"):
     4096 random rays of view v; their depth-prior points warped into a random other training view (a12, VT variant), occlusion test,
     a SECOND full render on the warped rays + its four loss terms; the primary render's terms restricted by the masks per coin;
     backward through both renders; Adam.  ~2x the MLP work of a plain step.
-    route "ss_step_loss": the one-call surface (run_nerf_view.ss_step_loss: one warp / compaction launch, every loss term of both
-    renders in their compositing launches); route "reference_lines": render, ss_consistency, ss_primary_losses as separate calls in
-    the reference's order."""
+    route "ss_step_loss": the one-call surface, ONE render (round 6: run_nerf_view.ss_step_loss -> the warp launch assembles the
+    combined 2 x 4096-row batch and its device-side live-row count, the MLP launches stop at the count, two-segment loss tail; no host
+    synchronisation); "two_renders": round 5's one-call form (two renders, one read-back); "reference_lines": render, ss_consistency,
+    ss_primary_losses as separate calls in the reference's order."""
     from consistentnerf_amd import raybank as RB, run_nerf as R, run_nerf_view as V
     H, W, K, kw, opt = sc["H"], sc["W"], sc["K"], sc["kw"], sc["opt"]
     rs = np.random.RandomState(3)
@@ -671,16 +677,17 @@ def c3_ss_step_fn(sc, route="ss_step_loss"):
     def step(i):
         v, r = i % 3, (i + 1 + int(rs.randint(0, 2))) % 3
         rays, target, sel, (d_prior,) = RB.sample_patch_rays(sc["img_t"][v], sc["poses"][v], H, W, K, 4096, None,
-                                                             extras=(sc["dep_t"][v],), render_kwargs=kw)
+                                                             extras=(sc["dep_ss_t"][v],), render_kwargs=kw)
         coins = [int(c) for c in rs.randint(0, 2, 4)]
-        if route == "ss_step_loss":
-            loss, ss = V.ss_step_loss(H, W, K, rays, target, d_prior, sc["poses"][r], sc["img_t"][r], sc["dep_t"][r], kw, chunk=32768,
-                                      occlusion_threshold=0.1, with_depth_loss=True, coins=coins)
+        if route in ("ss_step_loss", "two_renders"):
+            loss, ss = V.ss_step_loss(H, W, K, rays, target, d_prior, sc["poses"][r], sc["img_t"][r], sc["dep_ss_t"][r], kw, chunk=32768,
+                                      occlusion_threshold=0.1, with_depth_loss=True, coins=coins,
+                                      route=None if route == "ss_step_loss" else "two_renders")
             opt.zero_grad()
             R.backward(loss)
         else:
             rgb, disp, acc, depth, extras = V.render(H, W, K, chunk=32768, rays=rays, retraw=True, **kw)
-            ss = V.ss_consistency(rays[0], rays[1], d_prior, sc["poses"][r], K, sc["img_t"][r], sc["dep_t"][r], H, W, kw, chunk=32768,
+            ss = V.ss_consistency(rays[0], rays[1], d_prior, sc["poses"][r], K, sc["img_t"][r], sc["dep_ss_t"][r], H, W, kw, chunk=32768,
                                   occlusion_threshold=0.1, with_depth_loss=True)
             opt.zero_grad()
             lp, _, _ = V.ss_primary_losses(rgb, depth, extras, target, d_prior, ss["mask_bound"], ss["mask"], with_depth_loss=True,
@@ -688,9 +695,15 @@ def c3_ss_step_fn(sc, route="ss_step_loss"):
             loss = ss["loss"] + lp
             loss.backward()
         opt.step()
-        step.rays_second = int(ss["batch_rays_ref"].shape[1])
+        if "live" in ss:          # one render: the row count stays on the device — kept as tensors, read once after the timed region
+            step.lives.append(ss["live"])
+            step.terms = ss["terms"]
+        else:
+            step.lives.append(4096 + int(ss["batch_rays_ref"].shape[1]))
+        # VT:959 / VT:966 with both coarse coins 0: the primary rays' coarse level has no backward (as in the reference's graph)
+        step.skips.append(4096 if not (coins[2] or coins[3]) else 0)
         return loss
-    step.rays_second = 0
+    step.lives, step.skips, step.terms = [], [], None
     return step
 
 
@@ -787,12 +800,19 @@ def c3_ss_leg(dev, steps=10):
     """a15 timed (VERDICT r04 missing 4): the in-loop consistency step, c3_ss_step_fn."""
     sc = c3_scene(dev)
     dt_lines, _, _ = _time_steps(c3_ss_step_fn(sc, "reference_lines"), steps)
+    dt_two, _, _ = _time_steps(c3_ss_step_fn(sc, "two_renders"), steps)
     step = c3_ss_step_fn(sc)
     dt, loss, prof = _time_steps(step, steps)
     table = per_kernel_table(prof, dt * steps * 1e3)
-    # MFMA work actually launched per step: both renders' ray-samples (the second render's ray count varies: in-bounds warped rays)
-    pts = sum(r["points"] * r["launches"] for r in table if r["kernel"] == "mlp_wgrad") / steps
-    tf = pts * 2 * (MAC_FWD + MAC_DGRAD + MAC_WGRAD) / dt / 1e12
+    # MFMA work of a step = the ray-samples of its LIVE rows (4096 primary + M warped; the launches are sized for 8192 rows and stop
+    # at the device-side count): 256 ray-samples per live row through forward, dgrad and wgrad
+    lives, skips = [int(x) for x in step.lives[-steps:]], step.skips[-steps:]
+    pts = 256.0 * sum(lives) / steps                       # forward: every live row, both levels
+    pts_bwd = pts - 64.0 * sum(skips) / steps              # backward: minus the primary rays' coarse level on the steps that skip it
+    for r in table:      # (the HIP-event records carry the launch CAPACITY: rescale every MFMA row to the points it really covered)
+        r["points_capacity"] = r["points"]
+        r["points"] = r["points"] * (sum(lives) / steps) / 8192.0 if r["kernel"] == "mlp_fwd_train" else pts_bwd
+    tf = (pts * 2 * MAC_FWD + pts_bwd * 2 * (MAC_DGRAD + MAC_WGRAD)) / dt / 1e12
     # (the second render's ray count differs from step to step: one row per kernel here, sizes pooled — the launch-size-resolved
     #  table would be ~40 rows of this line)
     pooled = {}
@@ -804,17 +824,24 @@ def c3_ss_leg(dev, steps=10):
               "points_per_step": a["points"] / steps,
               "frac": round(fl[a["kernel"]] * a["points"] / (a["ms"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if a["kernel"] in fl else None,
               "share_of_step": round(a["ms"] / (dt * steps * 1e3), 4)} for a in pooled.values()]
-    out = {"ms_per_step": dt * 1e3, "ms_per_step_reference_lines": dt_lines * 1e3, "steps": steps, "rays_primary": 4096,
-           "rays_second_render_last_step": step.rays_second,
-           "ray_samples_per_step_avg": pts, "ray_samples_per_s": pts / dt, "final_loss": float(loss.item()),
+    out = {"ms_per_step": dt * 1e3, "ms_per_step_two_renders": dt_two * 1e3, "ms_per_step_reference_lines": dt_lines * 1e3, "steps": steps,
+           "rays_primary": 4096, "rays_second_render_last_step": lives[-1] - 4096, "live_rows_avg": sum(lives) / steps,
+           "ray_samples_per_step_avg": pts, "ray_samples_backward_per_step_avg": pts_bwd, "ray_samples_per_s": pts / dt,
+           "final_loss": float(loss.item()),
+           "final_terms": None if step.terms is None else {k: float(v) for k, v in step.terms.items()},
            "finite": bool(np.isfinite(loss.item())),
-           "step": "VT:895-972 with --ss_loss --with_depth_loss through run_nerf_view.ss_step_loss: ONE warp / compaction / reference-ray "
-                   "launch + a 16-byte read-back, primary render (4096 rays) with its four terms under the masks per coin folded into its "
-                   "compositing launches, second render on the warped rays with its 4 consistency terms folded the same way; backward "
-                   "through both renders; Adam",
+           "loss_note": "un-normalised depth MSEs (VT:933, VT:950) against priors bounded by the far plane; VT's warp has no "
+                        "OpenGL->OpenCV flip (VT:451-501), so on this OpenGL-convention rig the warped rays look away from the scene "
+                        "and the occlusion threshold doubles to 6.4: the values are what the reference's lines compute here",
+           "step": "VT:895-972 with --ss_loss --with_depth_loss through run_nerf_view.ss_step_loss as ONE render: the warp launch "
+                   "assembles the 8192-row batch [4096 primary | M warped | padding] + its device-side live-row count, both levels' "
+                   "MLP launches stop at the count, every loss term of both segments in the compositing launches + one two-segment "
+                   "tail; merged backward; Adam.  No host synchronisation.",
            "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
-                        "basis": "whole step / the ray-samples its wgrad launches covered, 3489024 FLOP per ray-sample", "kernels": table},
+                        "basis": "whole step / (live ray-samples x forward FLOPs + the ray-samples the backward covered x (dgrad + wgrad) "
+                                 "FLOPs): the coarse level of the primary rays has no backward when neither coarse coin selects it",
+                        "kernels": table},
            "launches_per_step": c3_dispatch_pass("c3_ss")}
     del sc
     torch.cuda.empty_cache()

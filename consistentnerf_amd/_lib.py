@@ -127,9 +127,11 @@ SIGNATURES = {
     "cnerf_mlp_bwd_ws_floats": (_i64, [_NetP, _i64]),
     "cnerf_mlp_bwd": (_i, [_NetP, _vp, _vp, _i64, _i, _vp, _vp, _PtrsP, _i, _vp]),
     "cnerf_mlp_bwd_pair": (_i, [_NetP, _vp, _vp, _i64, _i, _vp, _vp, _PtrsP, _NetP, _vp, _vp, _i64, _i, _vp, _vp, _PtrsP, _i, _vp]),
+    "cnerf_mlp_dgrad_pair_live": (_i, [_NetP, _vp, _vp, _i64, _i, _vp, _vp, _NetP, _vp, _vp, _i64, _i, _vp, _vp, _vp, _i64, _i64, _vp]),
+    "cnerf_mlp_wgrad_pair_live": (_i, [_NetP, _i64, _i, _vp, _vp, _PtrsP, _NetP, _i64, _i, _vp, _vp, _PtrsP, _i, _vp, _i64, _i64, _vp]),
     "cnerf_mlp_bwd_live": (_i, [_NetP, _vp, _vp, _i64, _i, _vp, _vp, _PtrsP, _i, _vp, _vp]),
     "cnerf_mlp_bwd_pair_live": (_i, [_NetP, _vp, _vp, _i64, _i, _vp, _vp, _PtrsP, _NetP, _vp, _vp, _i64, _i, _vp, _vp, _PtrsP, _i, _vp,
-                                     _vp]),
+                                     _i64, _i64, _vp]),
     "cnerf_mlp_dgrad_pair": (_i, [_NetP, _vp, _vp, _i64, _i, _vp, _vp, _NetP, _vp, _vp, _i64, _i, _vp, _vp, _vp]),
     "cnerf_mlp_wgrad_pair": (_i, [_NetP, _i64, _i, _vp, _vp, _PtrsP, _NetP, _i64, _i, _vp, _vp, _PtrsP, _i, _vp]),
     "cnerf_mlp_dgrad": (_i, [_NetP, _vp, _vp, _i64, _i, _vp, _vp, _vp]),

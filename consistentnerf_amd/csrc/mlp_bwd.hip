@@ -14,7 +14,8 @@ int cn_wgrad_launch(const NetGeom& g, const float* stash, const float* G, int64_
                     int nsplit, const cnerf_ptrs* grads, int accumulate, hipStream_t st, int bf3 = 0);
 int cn_wgrad_launch_n(int n, const NetGeom* const* g, const float* const* stash, const float* const* G, const int64_t* Mp,
                       float* const* partials, const int* nsplit, const cnerf_ptrs* const* grads, int accumulate,
-                      hipStream_t st, int bf3 = 0, const int* live = nullptr, const int* live_mul = nullptr);
+                      hipStream_t st, int bf3 = 0, const int* live = nullptr, const int* live_mul = nullptr,
+                      const int* live_sub = nullptr);
 int cn_wgrad_nsplit(int64_t Mp);
 int64_t cn_param_floats(const NetGeom& g);
 
@@ -30,6 +31,7 @@ struct BwdLevel {
   float* G;
   int64_t M, Mp;
   int64_t live_mul;   // points per ray of this level (with BwdArgs::live), 0 = no gating
+  int64_t live_sub;   // rays in front of this level's arrays that are not part of the launch (first_ray of the _live calls)
 };
 
 struct BwdArgs {
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(64) void mlp_dgrad_k(BwdArgs args_by_value) {
   const int64_t p = p0 + m;
   const int nvalid = a.M - p0 < 32 ? (int)(a.M - p0) : 32;
   const int64_t pc = p < a.M ? p : a.M - 1;
-  if (args.live != nullptr && a.live_mul > 0 && p0 >= (int64_t)args.live[0] * a.live_mul) return;   // padding rays (cnerf_mlp_bwd_live)
+  if (args.live != nullptr && a.live_mul > 0 && p0 >= ((int64_t)args.live[0] - a.live_sub) * a.live_mul) return;   // padding rays
   CN_TINIT(1)
   const APanel AP{make_rsrc(a.packed, (unsigned)(g.total * 4)), (m * 8 + 4 * hh) * 4};
   // this workgroup's stash tile row (sign bits) and gradient tile row (tile-major, mlp_common.hpp); lanes of padding
@@ -238,7 +240,7 @@ static int dgrad_one(const cnerf_net* net, const float* packed, const float* d_r
   if (rc) return rc;
   if (!packed || !d_raw || !stash || !workspace || B < 0 || S <= 0 || (live && S % 32 != 0)) return CNERF_E_ARG;
   if (B == 0) return CNERF_OK;
-  a.lv[0] = BwdLevel{packed, d_raw, stash, workspace, B * S, cn_round_up(B * S, 32), live ? S : 0};
+  a.lv[0] = BwdLevel{packed, d_raw, stash, workspace, B * S, cn_round_up(B * S, 32), live ? S : 0, 0};
   a.lv[1] = a.lv[0];
   a.nb0 = (unsigned)cn_div_up(B * S, 32);
   a.live = live;
@@ -303,7 +305,7 @@ extern "C" int cnerf_mlp_bwd_live(const cnerf_net* net, const float* packed, con
 // reductions into one gradient tensor would race).  Workspaces as for cnerf_mlp_bwd, one per network.
 static int dgrad_pair(const cnerf_net* net0, const float* packed0, const float* d_raw0, int64_t B0, int S0, const float* stash0,
                       float* workspace0, const cnerf_net* net1, const float* packed1, const float* d_raw1, int64_t B1, int S1,
-                      const float* stash1, float* workspace1, const int32_t* live, void* stream);
+                      const float* stash1, float* workspace1, const int32_t* live, void* stream, int64_t first0 = 0, int64_t first1 = 0);
 extern "C" int cnerf_mlp_dgrad_pair(const cnerf_net* net0, const float* packed0, const float* d_raw0, int64_t B0, int S0,
                                     const float* stash0, float* workspace0, const cnerf_net* net1, const float* packed1,
                                     const float* d_raw1, int64_t B1, int S1, const float* stash1, float* workspace1,
@@ -313,7 +315,7 @@ extern "C" int cnerf_mlp_dgrad_pair(const cnerf_net* net0, const float* packed0,
 }
 static int dgrad_pair(const cnerf_net* net0, const float* packed0, const float* d_raw0, int64_t B0, int S0, const float* stash0,
                       float* workspace0, const cnerf_net* net1, const float* packed1, const float* d_raw1, int64_t B1, int S1,
-                      const float* stash1, float* workspace1, const int32_t* live, void* stream) {
+                      const float* stash1, float* workspace1, const int32_t* live, void* stream, int64_t first0, int64_t first1) {
   BwdArgs a;
   NetGeom g1;
   int rc = cn_make_geom(net0, &a.g);
@@ -327,10 +329,15 @@ static int dgrad_pair(const cnerf_net* net0, const float* packed0, const float* 
                     net0->multires_views == net1->multires_views && net0->use_viewdirs == net1->use_viewdirs &&
                     net0->output_ch == net1->output_ch && net0->skip == net1->skip;
   if (live && (S0 % 32 != 0 || S1 % 32 != 0)) return CNERF_E_ARG;
+  if ((first0 || first1) && (!live || !same || first0 < 0 || first1 < 0 || first0 >= B0 || first1 >= B1)) return CNERF_E_ARG;
   if (same && M0 > 0 && M1 > 0) {
-    a.lv[0] = BwdLevel{packed0, d_raw0, stash0, workspace0, M0, cn_round_up(M0, 32), live ? S0 : 0};
-    a.lv[1] = BwdLevel{packed1, d_raw1, stash1, workspace1, M1, cn_round_up(M1, 32), live ? S1 : 0};
-    a.nb0 = (unsigned)cn_div_up(M0, 32);
+    // first_ray: the level's first `first` rays carry zero seeds and are left out — operands advanced past them (tile rows are
+    // 32 points: first * S is a multiple of 32), the device-side count reduced by the same
+    const int64_t o0 = first0 * S0, o1 = first1 * S1;
+    const int rc0 = a.g.viewdirs ? 4 : a.g.out_ch;      // floats per point of d_raw (same architecture: same for both levels)
+    a.lv[0] = BwdLevel{packed0, d_raw0 + o0 * rc0, stash0 + o0 * a.g.s_rows, workspace0, M0 - o0, cn_round_up(M0 - o0, 32), live ? S0 : 0, first0};
+    a.lv[1] = BwdLevel{packed1, d_raw1 + o1 * rc0, stash1 + o1 * g1.s_rows, workspace1, M1 - o1, cn_round_up(M1 - o1, 32), live ? S1 : 0, first1};
+    a.nb0 = (unsigned)cn_div_up(M0 - o0, 32);
     a.live = live;
     return dispatch(a, 2, cn_stream(stream));
   }
@@ -340,7 +347,8 @@ static int dgrad_pair(const cnerf_net* net0, const float* packed0, const float* 
 
 static int wgrad_two(const cnerf_net* net0, int64_t B0, int S0, const float* stash0, float* workspace0, const cnerf_ptrs* grads0,
                      const cnerf_net* net1, int64_t B1, int S1, const float* stash1, float* workspace1,
-                     const cnerf_ptrs* grads1, int accumulate, void* stream, int bf3, const int32_t* live = nullptr);
+                     const cnerf_ptrs* grads1, int accumulate, void* stream, int bf3, const int32_t* live = nullptr, int64_t first0 = 0,
+                     int64_t first1 = 0);
 extern "C" int cnerf_mlp_wgrad_pair(const cnerf_net* net0, int64_t B0, int S0, const float* stash0, float* workspace0,
                                     const cnerf_ptrs* grads0, const cnerf_net* net1, int64_t B1, int S1,
                                     const float* stash1, float* workspace1, const cnerf_ptrs* grads1, int accumulate,
@@ -355,10 +363,12 @@ extern "C" int cnerf_mlp_wgrad_bf_pair(const cnerf_net* net0, int64_t B0, int S0
 }
 static int wgrad_two(const cnerf_net* net0, int64_t B0, int S0, const float* stash0, float* workspace0, const cnerf_ptrs* grads0,
                      const cnerf_net* net1, int64_t B1, int S1, const float* stash1, float* workspace1,
-                     const cnerf_ptrs* grads1, int accumulate, void* stream, int bf3, const int32_t* live) {
+                     const cnerf_ptrs* grads1, int accumulate, void* stream, int bf3, const int32_t* live, int64_t first0,
+                     int64_t first1) {
   if (!grads0 || !grads1 || !stash0 || !stash1 || !workspace0 || !workspace1 || B0 < 0 || B1 < 0 || S0 <= 0 || S1 <= 0 ||
       (live && (S0 % 32 != 0 || S1 % 32 != 0)))
     return CNERF_E_ARG;
+  if ((first0 || first1) && (!live || first0 < 0 || first1 < 0 || first0 >= B0 || first1 >= B1)) return CNERF_E_ARG;
   if (B0 == 0) return wgrad_one(net1, B1, S1, stash1, workspace1, grads1, accumulate, stream, bf3, live);
   if (B1 == 0) return wgrad_one(net0, B0, S0, stash0, workspace0, grads0, accumulate, stream, bf3, live);
   for (int i = 0; i < CNERF_MAX_TENSORS; ++i)
@@ -367,7 +377,9 @@ static int wgrad_two(const cnerf_net* net0, int64_t B0, int S0, const float* sta
   int rc = cn_make_geom(net0, &g0);
   if (rc) return rc;
   if ((rc = cn_make_geom(net1, &g1))) return rc;
-  const int64_t Mp0 = cn_round_up(B0 * S0, 32), Mp1 = cn_round_up(B1 * S1, 32);
+  const int64_t Mp0 = cn_round_up((B0 - first0) * S0, 32), Mp1 = cn_round_up((B1 - first1) * S1, 32);
+  stash0 += first0 * S0 * g0.s_rows;      // (first_ray: see dgrad_pair; the gradient workspace holds only the launched rays' rows)
+  stash1 += first1 * S1 * g1.s_rows;
   const NetGeom* gs[2] = {&g0, &g1};
   const float* stashes[2] = {stash0, stash1};
   const float* Gs[2] = {workspace0, workspace1};
@@ -376,7 +388,9 @@ static int wgrad_two(const cnerf_net* net0, int64_t B0, int S0, const float* sta
   float* parts[2] = {workspace0 + (int64_t)g0.g_rows * Mp0, workspace1 + (int64_t)g1.g_rows * Mp1};
   const cnerf_ptrs* grs[2] = {grads0, grads1};
   const int muls[2] = {S0, S1};
-  return cn_wgrad_launch_n(2, gs, stashes, Gs, Mps, parts, ns, grs, accumulate, cn_stream(stream), bf3, live, live ? muls : nullptr);
+  const int subs[2] = {(int)first0, (int)first1};
+  return cn_wgrad_launch_n(2, gs, stashes, Gs, Mps, parts, ns, grs, accumulate, cn_stream(stream), bf3, live, live ? muls : nullptr,
+                           live ? subs : nullptr);
 }
 
 extern "C" int cnerf_mlp_bwd_pair(const cnerf_net* net0, const float* packed0, const float* d_raw0, int64_t B0, int S0,
@@ -394,19 +408,39 @@ extern "C" int cnerf_mlp_bwd_pair(const cnerf_net* net0, const float* packed0, c
                               stream);
 }
 
+// the two halves of cnerf_mlp_bwd_pair_live, separately launchable (cf. cnerf_mlp_dgrad_pair / cnerf_mlp_wgrad_pair)
+extern "C" int cnerf_mlp_dgrad_pair_live(const cnerf_net* net0, const float* packed0, const float* d_raw0, int64_t B0, int S0,
+                                         const float* stash0, float* workspace0, const cnerf_net* net1, const float* packed1,
+                                         const float* d_raw1, int64_t B1, int S1, const float* stash1, float* workspace1,
+                                         const int32_t* live_rays, int64_t first_ray0, int64_t first_ray1, void* stream) {
+  if (!live_rays || B0 != B1) return CNERF_E_ARG;
+  return dgrad_pair(net0, packed0, d_raw0, B0, S0, stash0, workspace0, net1, packed1, d_raw1, B1, S1, stash1, workspace1, live_rays,
+                    stream, first_ray0, first_ray1);
+}
+extern "C" int cnerf_mlp_wgrad_pair_live(const cnerf_net* net0, int64_t B0, int S0, const float* stash0, float* workspace0,
+                                         const cnerf_ptrs* grads0, const cnerf_net* net1, int64_t B1, int S1, const float* stash1,
+                                         float* workspace1, const cnerf_ptrs* grads1, int accumulate, const int32_t* live_rays,
+                                         int64_t first_ray0, int64_t first_ray1, void* stream) {
+  if (!live_rays || B0 != B1 || !grads0 || !grads1) return CNERF_E_ARG;
+  for (int i = 0; i < CNERF_MAX_TENSORS; ++i)
+    if (grads0->p[i] && grads0->p[i] == grads1->p[i]) return CNERF_E_ARG;
+  return wgrad_two(net0, B0, S0, stash0, workspace0, grads0, net1, B1, S1, stash1, workspace1, grads1, accumulate, stream, 0,
+                   live_rays, first_ray0, first_ray1);
+}
+
 // cnerf_mlp_bwd_pair of two levels of ONE ray batch padded to a fixed capacity (B0 == B1 rays) whose LIVE row count sits in device
 // memory: both levels' dgrad tiles and wgrad point ranges stop at live_rays * S of their level
 extern "C" int cnerf_mlp_bwd_pair_live(const cnerf_net* net0, const float* packed0, const float* d_raw0, int64_t B0, int S0,
                                        const float* stash0, float* workspace0, const cnerf_ptrs* grads0,
                                        const cnerf_net* net1, const float* packed1, const float* d_raw1, int64_t B1, int S1,
                                        const float* stash1, float* workspace1, const cnerf_ptrs* grads1, int accumulate,
-                                       const int32_t* live_rays, void* stream) {
+                                       const int32_t* live_rays, int64_t first_ray0, int64_t first_ray1, void* stream) {
   if (!grads0 || !grads1 || !live_rays || B0 != B1) return CNERF_E_ARG;
   for (int i = 0; i < CNERF_MAX_TENSORS; ++i)
     if (grads0->p[i] && grads0->p[i] == grads1->p[i]) return CNERF_E_ARG;
   int rc = dgrad_pair(net0, packed0, d_raw0, B0, S0, stash0, workspace0, net1, packed1, d_raw1, B1, S1, stash1, workspace1, live_rays,
-                      stream);
+                      stream, first_ray0, first_ray1);
   if (rc) return rc;
   return wgrad_two(net0, B0, S0, stash0, workspace0, grads0, net1, B1, S1, stash1, workspace1, grads1, accumulate, stream, 0,
-                   live_rays);
+                   live_rays, first_ray0, first_ray1);
 }

@@ -387,11 +387,12 @@ def mlp_backward(spec: NetSpec, packed: Tensor, d_raw: Tensor, B: int, S: int, s
 def mlp_backward_pair(spec0: NetSpec, packed0: Tensor, d_raw0: Tensor, B0: int, S0: int, stash0: Tensor, grads0: List[Tensor],
                       spec1: NetSpec, packed1: Tensor, d_raw1: Tensor, B1: int, S1: int, stash1: Tensor, grads1: List[Tensor],
                       accumulate: bool = False, packed_bf0: Optional[Tensor] = None, packed_bf1: Optional[Tensor] = None,
-                      live: Optional[Tensor] = None):
+                      live: Optional[Tensor] = None, first0: int = 0, first1: int = 0):
     """cnerf_mlp_bwd_pair: the backward of two independent networks (coarse / fine) as one dgrad grid, one wgrad grid and
     one reduction; gradients are written (or accumulated) into grads0 / grads1.  packed_bf0 AND packed_bf1: the dgrad grid runs
     in the opt-in bf16x3 arithmetic.  live: both levels belong to one ray batch whose live row count sits on the device
-    (mlp_forward(live=...)): cnerf_mlp_bwd_pair_live (exact fp32)."""
+    (mlp_forward(live=...)): cnerf_mlp_bwd_pair_live (exact fp32); first0 / first1: that level's first rays carry zero seeds and are
+    left out of its backward."""
     lib = _lib.load()
     n0, n1 = spec0.c(), spec1.c()
     d_raw0, d_raw1 = _chk(d_raw0, "d_raw0"), _chk(d_raw1, "d_raw1")
@@ -402,10 +403,16 @@ def mlp_backward_pair(spec0: NetSpec, packed0: Tensor, d_raw0: Tensor, B0: int, 
     if live is not None:
         if packed_bf0 is not None or packed_bf1 is not None:
             raise CnerfError("mlp_backward_pair(live=...) is an exact-fp32 path")
-        with _timed("mlp_bwd_live", B0 * S0 + B1 * S1):
-            _lib.check(lib.cnerf_mlp_bwd_pair_live(C.byref(n0), _p(packed0), _p(d_raw0), B0, S0, _p(stash0), _p(ws0), C.byref(p0),
-                                                   C.byref(n1), _p(packed1), _p(d_raw1), B1, S1, _p(stash1), _p(ws1), C.byref(p1),
-                                                   int(accumulate), _p(live), _stream()), "cnerf_mlp_bwd_pair_live")
+        # (the halves of cnerf_mlp_bwd_pair_live, launched separately so that bench.py's HIP events bracket each kernel; `units` is
+        #  the launch CAPACITY — the live point count is on the device — the bench rescales by the step's live rows)
+        with _timed("mlp_dgrad", B0 * S0 + B1 * S1):
+            _lib.check(lib.cnerf_mlp_dgrad_pair_live(C.byref(n0), _p(packed0), _p(d_raw0), B0, S0, _p(stash0), _p(ws0), C.byref(n1),
+                                                     _p(packed1), _p(d_raw1), B1, S1, _p(stash1), _p(ws1), _p(live), int(first0),
+                                                     int(first1), _stream()), "cnerf_mlp_dgrad_pair_live")
+        with _timed("mlp_wgrad", B0 * S0 + B1 * S1):
+            _lib.check(lib.cnerf_mlp_wgrad_pair_live(C.byref(n0), B0, S0, _p(stash0), _p(ws0), C.byref(p0), C.byref(n1), B1, S1,
+                                                     _p(stash1), _p(ws1), C.byref(p1), int(accumulate), _p(live), int(first0),
+                                                     int(first1), _stream()), "cnerf_mlp_wgrad_pair_live")
         return
     if packed_bf0 is not None and packed_bf1 is not None and DGRAD_BF3:
         with _timed("mlp_dgrad_bf3", B0 * S0 + B1 * S1):

@@ -30,9 +30,10 @@ class RayPoints:
     """Lazy stand-in for the [N_rays, N_samples, 3] point tensor of R:384: the fused kernel evaluates
     o + d*z itself, so the 9.4 MB/step point cloud is never written.  `.materialize()` gives the tensor."""
 
-    def __init__(self, rays, z_vals, live=None):
+    def __init__(self, rays, z_vals, live=None, skip=0):
         self.rays, self.z_vals = rays, z_vals
         self.live = live          # device int32 [1]: only the first live[0] rays are real (a batch padded to a fixed capacity)
+        self.skip = skip          # (with live) the first `skip` rays get zero seeds: the backward of this query may leave them out
         self.shape = torch.Size([z_vals.shape[0], z_vals.shape[1], 3])
         self.device = z_vals.device
 
@@ -282,7 +283,7 @@ class _MlpFn(torch.autograd.Function):
     """Fused gamma(x), gamma(d) + MLP (replaces R:37-52 + H:44-45 + H:107-130 and their autograd)."""
 
     @staticmethod
-    def forward(ctx, model, B, S, pts, rays, z, dirs, emb, live, *params):
+    def forward(ctx, model, B, S, pts, rays, z, dirs, emb, live, skip, *params):
         spec = model.spec()
         packed, gen = _packed_gen(model)
         if any(ctx.needs_input_grad[3:8]):
@@ -290,7 +291,7 @@ class _MlpFn(torch.autograd.Function):
             # sample positions (z is detached at R:397, rays come from the data), and the dgrad kernel stops at layer 0
             raise ops.CnerfError("gradients w.r.t. sample positions / rays / view directions / pre-embedded inputs are "
                                  "not implemented (only w.r.t. the network parameters)")
-        train = any(ctx.needs_input_grad[9:])
+        train = any(ctx.needs_input_grad[10:])
         if emb is not None:      # NeRF.forward(x) on pre-embedded inputs
             raw, stash = ops.mlp_forward_embedded(spec, packed, emb, want_stash=train)
         elif train and training_precision(model) == "bf16x3":
@@ -305,6 +306,8 @@ class _MlpFn(torch.autograd.Function):
             use_live = live if (train and pts is None and dirs is None and S % 32 == 0) else None
             raw, stash = ops.mlp_forward(spec, packed, B, S, pts=pts, rays=rays, z=z, dirs=dirs, want_stash=train, live=use_live)
             ctx.live = use_live
+            # `skip` (with live): this level's first `skip` rays will get zero seeds — the merged backward leaves them out
+            ctx.skip = int(skip) if (use_live is not None and skip) else 0
         if train:
             ctx.spec, ctx.B, ctx.S, ctx.stash, ctx.packed, ctx.packed_gen = spec, B, S, stash, packed, gen
             ctx.params, ctx.model = params, model
@@ -326,32 +329,33 @@ class _MlpFn(torch.autograd.Function):
         # step) and autograd gets no per-tensor gradients back.  Anything else — plain nn.Parameters, and
         # torch.autograd.grad() on FusedAdam-owned ones, where the engine captures gradients instead of accumulating them
         # — takes the tensor route and leaves the flat buffer untouched.
-        direct = _direct_ok(ctx.needs_input_grad[9:], params) and _engine_accumulates(params[0])
+        direct = _direct_ok(ctx.needs_input_grad[10:], params) and _engine_accumulates(params[0])
         pair = getattr(ctx, "pair", None)
-        nret = (None,) * (9 + len(params))
+        nret = (None,) * (10 + len(params))
         live = getattr(ctx, "live", None)
         if direct and pair is not None and pair.fine() is ctx and pair.parked is None:
             c = pair.coarse()
             # park only when the coarse node is certain to run in this very pass, on the direct route as well
-            if (c is not None and c.stash is not None and _direct_ok(c.needs_input_grad[9:], c.params)
+            if (c is not None and c.stash is not None and _direct_ok(c.needs_input_grad[10:], c.params)
                     and _ENGINE_QUERY(c)):
                 pair.parked = (ctx.spec, ctx.packed, g_raw.contiguous(), ctx.B, ctx.S, ctx.stash, [p.grad for p in params],
-                               ctx.model, getattr(ctx, "packed_bf", None), params, live)
+                               ctx.model, getattr(ctx, "packed_bf", None), params, live, getattr(ctx, "skip", 0))
                 ctx.stash = ctx.packed = ctx.params = ctx.model = None
                 return nret
         parked = None
         if pair is not None and pair.coarse() is ctx and pair.parked is not None:
             parked, pair.parked = pair.parked, None
         if parked is not None and direct and parked[10] is live and (live is None or parked[3] == ctx.B):
-            fs, fp, fg, fB, fS, fst, fgr, fmodel, fbf, fparams, _flive = parked
+            fs, fp, fg, fB, fS, fst, fgr, fmodel, fbf, fparams, _flive, fskip = parked
             ops.mlp_backward_pair(fs, fp, fg, fB, fS, fst, fgr, ctx.spec, ctx.packed, g_raw.contiguous(), ctx.B, ctx.S,
                                   ctx.stash, [p.grad for p in params], accumulate=not _take_dropped(fparams, params), packed_bf0=fbf,
-                                  packed_bf1=getattr(ctx, "packed_bf", None), live=live)
+                                  packed_bf1=getattr(ctx, "packed_bf", None), live=live, first0=fskip if live is not None else 0,
+                                  first1=getattr(ctx, "skip", 0) if live is not None else 0)
             _report_ready_pair(fmodel, ctx.model)
             ctx.stash = ctx.packed = ctx.params = ctx.model = None
             return nret
         if parked is not None:        # (cannot happen — the fine node checked this node's route — but never drop a gradient)
-            fs, fp, fg, fB, fS, fst, fgr, fmodel, fbf, fparams, flive = parked
+            fs, fp, fg, fB, fS, fst, fgr, fmodel, fbf, fparams, flive, _fskip = parked
             ops.mlp_backward(fs, fp, fg, fB, fS, fst, grads=fgr, accumulate=not _take_dropped(fparams), packed_bf=fbf, live=flive)
             _report_ready(fmodel, True)
         out = [p.grad for p in params] if direct else None
@@ -360,7 +364,7 @@ class _MlpFn(torch.autograd.Function):
                                  live=live)
         _report_ready(ctx.model, direct)
         ctx.stash = ctx.packed = ctx.params = ctx.model = None
-        return nret if direct else (None,) * 9 + tuple(grads)
+        return nret if direct else (None,) * 10 + tuple(grads)
 
 
 class _CompositeFn(torch.autograd.Function):
@@ -514,9 +518,10 @@ def run_network(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk=1024 * 64
         # inference pass would run the training kernel and write a 10 KB-per-point stash nobody reads
         params = [p.detach() for p in params]
     if isinstance(inputs, RayPoints):
-        return _MlpFn.apply(fn, B, S, None, inputs.rays, inputs.z_vals, dirs, None, getattr(inputs, "live", None), *params)
+        return _MlpFn.apply(fn, B, S, None, inputs.rays, inputs.z_vals, dirs, None, getattr(inputs, "live", None),
+                            getattr(inputs, "skip", 0), *params)
     pts = inputs.reshape(-1, 3).contiguous()
-    return _MlpFn.apply(fn, B, S, pts, None, None, dirs, None, None, *params)
+    return _MlpFn.apply(fn, B, S, pts, None, None, dirs, None, None, 0, *params)
 
 
 def _is_viewdir_columns(viewdirs, rays):
@@ -926,7 +931,13 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
     z_vals = ops.coarse_z(rays, N_samples, t_rand, lindisp, rng=rng)
     if N_importance > 0:
         _prepack_pair(network_fn, network_fine)
-    raw = network_query_fn(RayPoints(rays, z_vals, _live), viewdirs, network_fn)
+    skip_c = 0
+    if (_live is not None and isinstance(_target, ops.ClossSpec) and _target.seg_row and _target.ss_coins is not None and N_importance > 0
+            and not (_target.ss_coins[2] or (_target.prior is not None and _target.ss_coins[3]))):
+        # VT:959 / VT:966 with both coarse coins 0: no term of the PRIMARY segment depends on the coarse network (its colour term falls
+        # back to the fine rgb, its depth term is absent) — the coarse level's backward covers the second segment only
+        skip_c = int(_target.seg_row)
+    raw = network_query_fn(RayPoints(rays, z_vals, _live, skip_c), viewdirs, network_fn)
     noise = _density_noise((N_rays, N_samples), raw_noise_std, pytest, dev, _global_rows)
     loss = loss_c = terms = None
     if _target is None:

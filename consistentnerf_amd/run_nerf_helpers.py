@@ -162,7 +162,7 @@ class NeRF(nn.Module):
         params = self.kernel_tensors()
         if not torch.is_grad_enabled():     # (see run_network: no stash for inference)
             params = [p.detach() for p in params]
-        out = _MlpFn.apply(self, x2.shape[0], 1, None, None, None, None, x2, None, *params)
+        out = _MlpFn.apply(self, x2.shape[0], 1, None, None, None, None, x2, None, 0, *params)
         return out.reshape(*lead, out.shape[-1])
 
     def load_weights_from_keras(self, weights):

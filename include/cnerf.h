@@ -177,15 +177,27 @@ int cnerf_mlp_bwd_pair(const cnerf_net* net0, const float* packed0, const float*
                        const float* stash0, float* workspace0, const cnerf_ptrs* grads0,
                        const cnerf_net* net1, const float* packed1, const float* d_raw1, int64_t B1, int S1,
                        const float* stash1, float* workspace1, const cnerf_ptrs* grads1, int accumulate, void* stream);
-/* cnerf_mlp_bwd / cnerf_mlp_bwd_pair of a forward that ran through cnerf_mlp_fwd_live: activation-gradient tiles and weight-gradient
- * point ranges stop at live_rays[0] * S of their level (both levels of the pair belong to ONE ray batch: B0 == B1).  Exact fp32. */
+/* cnerf_mlp_bwd / cnerf_mlp_bwd_pair of a forward that ran through cnerf_mlp_fwd_live: activation-gradient tiles stop at
+ * live_rays[0] * S of their level, and the weight-gradient point ranges are cut over the live points only (both levels of the pair
+ * belong to ONE ray batch: B0 == B1).  first_rayN (pair forms; 0 = all): level N's first `first_rayN` rays carry zero seeds and are
+ * left out of its backward altogether — the primary rays of the one-render `--ss_loss` step on the coarse level when neither coarse
+ * coin selects it (run_nerf_view_test.py:959,966) — pass the level's arrays UNSHIFTED.  Exact fp32. */
 int cnerf_mlp_bwd_live(const cnerf_net* net, const float* packed, const float* d_raw, int64_t B, int S, const float* stash,
                        float* workspace, const cnerf_ptrs* grads, int accumulate, const int32_t* live_rays, void* stream);
 int cnerf_mlp_bwd_pair_live(const cnerf_net* net0, const float* packed0, const float* d_raw0, int64_t B0, int S0,
                             const float* stash0, float* workspace0, const cnerf_ptrs* grads0,
                             const cnerf_net* net1, const float* packed1, const float* d_raw1, int64_t B1, int S1,
                             const float* stash1, float* workspace1, const cnerf_ptrs* grads1, int accumulate,
-                            const int32_t* live_rays, void* stream);
+                            const int32_t* live_rays, int64_t first_ray0, int64_t first_ray1, void* stream);
+int cnerf_mlp_dgrad_pair_live(const cnerf_net* net0, const float* packed0, const float* d_raw0, int64_t B0, int S0,
+                              const float* stash0, float* workspace0, const cnerf_net* net1, const float* packed1,
+                              const float* d_raw1, int64_t B1, int S1, const float* stash1, float* workspace1,
+                              const int32_t* live_rays, int64_t first_ray0, int64_t first_ray1,
+                              void* stream);   /* the two halves of cnerf_mlp_bwd_pair_live */
+int cnerf_mlp_wgrad_pair_live(const cnerf_net* net0, int64_t B0, int S0, const float* stash0, float* workspace0,
+                              const cnerf_ptrs* grads0, const cnerf_net* net1, int64_t B1, int S1, const float* stash1,
+                              float* workspace1, const cnerf_ptrs* grads1, int accumulate, const int32_t* live_rays,
+                              int64_t first_ray0, int64_t first_ray1, void* stream);
 /* Its two halves (cf. cnerf_mlp_dgrad / cnerf_mlp_wgrad). */
 int cnerf_mlp_dgrad_pair(const cnerf_net* net0, const float* packed0, const float* d_raw0, int64_t B0, int S0,
                          const float* stash0, float* workspace0, const cnerf_net* net1, const float* packed1,

@@ -514,3 +514,206 @@ def test_c3_teacher_forced_step(dev, monkeypatch):
         assert row["clip_set_differences"] <= 4 and row["clip_set_difference_max_distance"] <= 1e-5, s_ + "clipped element set"
         assert row["adam_same_grad_dw"] <= 2e-7 + 2 * 6e-8 * 4.0, s_ + "Adam kernel (clip 0.1) on the same gradient"
         assert row["dw_beyond_conditioning_bound"] == 0 and row["dw_frac_beyond_2e-6"] <= 1e-3, s_ + "updated weights"
+
+
+# ------------------------------------------------------------------------------------------------ the in-loop consistency step
+class _SSLoss:
+    """The loss of one `--ss_loss --with_depth_loss` step in the ORACLE's functions, on the combined batch of the one-render form
+    (rows [0, N) the primary rays, [N, N + M) the warped rays): the second render's four terms (VT:930-938: O.mse on rgb / depth of the
+    fine, then of the coarse level) and then the primary render's four coin-gated terms (VT:941-969: O.ss_primary_losses, pinned on the
+    reference's fixture `ssloss_primary` in the CPU suite), accumulated in the reference's order.  _oracle_step calls it per level
+    (coarse first): the coarse level's maps are kept and the whole loss is formed at the fine level."""
+
+    def __init__(self, N, mask_bound, mask, prior, depth_ref_tgt, coins):
+        self.N, self.mask_bound, self.mask, self.prior, self.dref, self.coins = N, mask_bound, mask, prior, depth_ref_tgt, coins
+        self.c0 = None
+
+    def to(self, device):
+        return _SSLoss(self.N, self.mask_bound.to(device), self.mask.to(device), self.prior.to(device), self.dref.to(device), self.coins)
+
+    def __call__(self, k, comp, tg, dtype):
+        if k == 0:
+            self.c0 = comp
+            return 0.0
+        N = self.N
+        rgb, depth, rgb0, depth0 = comp[0], comp[4], self.c0[0], self.c0[4]
+        dref = self.dref.to(dtype)
+        loss = O.mse(rgb[N:], tg[N:])
+        loss = loss + O.mse(depth[N:], dref)
+        loss = loss + O.mse(rgb0[N:], tg[N:])
+        loss = loss + O.mse(depth0[N:], dref)
+        lp, _, _ = O.ss_primary_losses(rgb[:N], depth[:N], rgb0[:N], depth0[:N], tg[:N], self.prior.to(dtype), self.mask_bound, self.mask,
+                                       True, list(self.coins))
+        return loss + lp
+
+
+C3SS_SNAPSHOTS = (0, 50)
+
+
+def test_c3ss_teacher_forced_step(dev, monkeypatch):
+    """the chaos-free step parity of the C2 / C3 tests for the IN-LOOP CONSISTENCY step (a15, VT:899-969) at the
+    bench's `c3_ss` size.  The HIP path trains bench.c3_ss_step_fn's rig through the product surface — raybank.sample_patch_rays,
+    run_nerf_view.ss_step_loss (ONE render of the 8192-row combined batch: 4096 primary rays + ~3700 warped rays + padding, the
+    device-side live-row count, the two-segment folded loss), run_nerf.backward, FusedAdam with the value clip 0.1 — and at steps
+    {0, 50} ONE oracle step is run from the snapshotted state on the kernel's branch:
+
+        O.ss_block (VT:905-925; here its result is first compared with the step's own batch assembly: masks, compaction, threshold,
+        targets bit for bit) -> O.query / O.composite of both levels on the live rows at the kernel's depths, ReLU sign bits and
+        sigma signs -> the second render's four O.mse terms + O.ss_primary_losses with the step's coins -> autograd ->
+        O.adam_step(clip = 0.1)
+
+    in float64 (exact) and in fp32 on the CPU (the reference arithmetic).  Bounds of test_c3_teacher_forced_step: loss 1e-6 relative;
+    every gradient tensor within 1e-5 * A_max of the exact one; d loss / d raw of the LIVE rows 2e-5 rel-L2 (and exactly zero on the
+    padding rows); pattern differences only at the discontinuities; clipped element sets equal up to 1e-5; the Adam kernel 2e-7."""
+    sys.path.insert(0, ROOT)
+    import json
+    import bench
+    from consistentnerf_amd import ops, raybank as RB, run_nerf as R, run_nerf_view as V
+    sc = bench.c3_scene(dev)
+    H, W, K, kw, opt = sc["H"], sc["W"], sc["K"], sc["kw"], sc["opt"]
+    nets = [kw["network_fn"], kw["network_fine"]]
+    names = [[n for n, _ in m.named_parameters()] for m in nets]
+    sizes = [[p.numel() for _, p in m.named_parameters()] for m in nets]
+    seen = {}
+    orig_pair = ops.mlp_backward_pair
+
+    def spy(*a, **k):
+        seen["args"], seen["kw"] = a, k
+        return orig_pair(*a, **k)
+    monkeypatch.setattr(ops, "mlp_backward_pair", spy)
+    ncfg = O.NetCfg(8, 256, output_ch=5)
+    torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
+    torch.manual_seed(7)
+    np.random.seed(7)
+    rs = np.random.RandomState(3)
+    N, report = 4096, []
+    for i in range(max(C3SS_SNAPSHOTS) + 1):
+        v, r = i % 3, (i + 1 + int(rs.randint(0, 2))) % 3
+        snap = i in C3SS_SNAPSHOTS
+        rays, target, sel_px, (d_prior,) = RB.sample_patch_rays(sc["img_t"][v], sc["poses"][v], H, W, K, N, None,
+                                                                extras=(sc["dep_ss_t"][v],), render_kwargs=kw)
+        coins = [int(c) for c in rs.randint(0, 2, 4)]
+        if snap:
+            coins = [1, 1, 0, 1] if i == 0 else [0, 1, 1, 0]       # (both branches of every term across the two snapshots)
+            torch.cuda.synchronize()
+            w0 = [{k: t.detach().cpu().clone() for k, t in mdl.state_dict().items()} for mdl in nets]
+            m0, v0, p0 = opt.exp_avg.cpu().clone(), opt.exp_avg_sq.cpu().clone(), opt.flat_param.cpu().clone()
+            lr_i, step_i = opt.param_groups[0]["lr"], opt._step + 1
+        loss, info = V.ss_step_loss(H, W, K, rays, target, d_prior, sc["poses"][r], sc["img_t"][r], sc["dep_ss_t"][r],
+                                    dict(kw, pytest=True, _debug=snap), chunk=32768, occlusion_threshold=0.1, with_depth_loss=True,
+                                    coins=coins, route="one_render")
+        opt.zero_grad()
+        seen.pop("args", None)
+        R.backward(loss)
+        if snap:
+            assert "args" in seen and seen["kw"].get("live") is info["live"], "the step did not take the merged live backward"
+            fs, fp, fg, fB, fS, fst, fgr, cs, cp, cg, cB, cS, cst, cgr = seen.pop("args")
+            assert fB == cB == 2 * N
+            live = int(info["live"].item())
+            M = live - N
+            g_hip = opt.flat_grad.cpu().clone()
+            # (tile-major stash: the first live * S points are its first live * S * s_rows floats; the rest was never written)
+            masks_f = _masks_from_stash(fst[:live * fS * (fst.numel() // (fB * fS))], live * fS)
+            masks_c = _masks_from_stash(cst[:live * cS * (cst.numel() // (cB * cS))], live * cS)
+            d_raw_all = (cg.detach().reshape(cB, cS, -1), fg.detach().reshape(fB, fS, -1))
+            pad_d_raw = max(float(d[live:].abs().max()) for d in d_raw_all)
+            d_raw_hip = tuple(d[:live].cpu() for d in d_raw_all)
+            del fst, cst, fg, cg, d_raw_all
+            both = lambda k: torch.cat([info["extras"][k], info["extras_ref"][k]], 0)[:live].detach().cpu()   # noqa: E731
+            z_f, z_c = both("_z_vals"), both("_z_coarse")
+            raw_k = (both("_raw_coarse"), both("raw"))
+            rows_c, tgt2 = info["rows"][:live].cpu(), info["_target2"][:live].cpu()
+            # the step's own batch assembly against the oracle's block (pinned on the reference's fixture)
+            blk = O.ss_block(rays[0].cpu(), rays[1].cpu(), d_prior.cpu(), torch.from_numpy(sc["poses"][r]).float(),
+                             torch.from_numpy(np.asarray(K, np.float32)), sc["img_t"][r].cpu().permute(2, 0, 1), sc["dep_ss_t"][r].cpu(), 0.1)
+            hv = V.ss_host_view(info)
+            ok_block = (M == int(blk["mask_bound"].sum()) and torch.equal(hv["mask_bound"].cpu(), blk["mask_bound"])
+                        and torch.equal(hv["mask"].cpu(), blk["mask"]) and float(hv["threshold"]) == np.float32(blk["thr"])
+                        and torch.equal(info["sel"].cpu(), blk["sel"]) and torch.equal(tgt2[N:], blk["rgb_target_ref"][0].t())
+                        and torch.equal(info["_prior2"][N:live].cpu(), blk["rays_depth_ref"].reshape(-1)))
+            rays_err = float((hv["batch_rays_ref"].cpu() - blk["rays_ref"]).abs().max())
+        opt.step()
+        if not snap:
+            continue
+        torch.cuda.synchronize()
+        loss_hip, p1_hip = float(loss), opt.flat_param.cpu().clone()
+        # (the oracle's loss takes the ORACLE's masks / targets: they were just checked against the step's own, bit for bit)
+        mk = lambda: _SSLoss(N, blk["mask_bound"], blk["mask"], d_prior.cpu(), blk["rays_depth_ref"].reshape(-1), coins)  # noqa: E731
+        common = (w0, names, rows_c, tgt2, z_c, z_f, masks_c, masks_f, raw_k, ncfg)
+        ex = _oracle_step(torch.float64, *common, want_abs=True, device=dev, loss_fn=mk())
+        r32 = _oracle_step(torch.float32, *common, loss_fn=mk())
+        del masks_c, masks_f
+        row = {"step": i, "coins": coins, "live_rows": live, "M": M, "threshold": float(hv["threshold"]), "block_equals_oracle": bool(ok_block),
+               "rays_ref_max_err": rays_err, "padding_d_raw_max": pad_d_raw,
+               "loss_hip": loss_hip, "loss_oracle_f32": r32["loss"], "loss_oracle_f64": ex["loss"],
+               "loss_rel_f32": abs(loss_hip - r32["loss"]) / abs(r32["loss"]), "loss_rel_f64": abs(loss_hip - ex["loss"]) / abs(ex["loss"]),
+               "terms_hip": {k: float(t) for k, t in info["terms"].items()}}
+        for tag, res in (("f64", ex), ("f32", r32)):
+            row[f"relu_flips_{tag}"] = int(sum(n for n, _ in res["flips"]))
+            row[f"relu_flip_max_abs_z_{tag}"] = max(z for _, z in res["flips"])
+            row[f"sigma_sign_substitutions_{tag}"] = int(sum(t[1] for t in res["tail"]))
+            row[f"tail_substitution_max_abs_sigma_{tag}"] = max(t[2] for t in res["tail"])
+        row["relu_flip_frac"] = max(row["relu_flips_f64"], row["relu_flips_f32"]) / (live * 256 * (8 * 256 + 128))
+        for k, tag in ((0, "coarse"), (1, "fine")):
+            e_, h_, r_ = ex["d_raw"][k], d_raw_hip[k].double(), r32["d_raw"][k].double()
+            row[f"d_raw_{tag}_hip_vs_exact_rel_l2"] = float((h_ - e_).norm() / e_.norm())
+            row[f"d_raw_{tag}_ref32_vs_exact_rel_l2"] = float((r_ - e_).norm() / e_.norm())
+        g_ex, g_32, A = ex["grad"], r32["grad"], ex["A"]
+        off, bad, dg_flat = 0, [], torch.zeros_like(g_hip)
+        row["K_hip_worst"] = row["K_ref32_worst"] = row["grad_hip_vs_exact_rel_max_worst"] = row["grad_ref32_vs_exact_rel_max_worst"] = 0.0
+        for k in (0, 1):
+            for nme, n in zip(names[k], sizes[k]):
+                a, b, e, aa = g_hip[off:off + n].double(), g_32[off:off + n].double(), g_ex[off:off + n], A[off:off + n]
+                dg_flat[off:off + n] = float((a - b).abs().max())
+                off += n
+                scale = float(e.abs().max())
+                if scale == 0:
+                    assert float(a.abs().max()) == 0 and float(b.abs().max()) == 0
+                    continue
+                amax = float(aa.max())
+                d_ex, r_ex = float((a - e).abs().max()), float((b - e).abs().max())
+                row["K_hip_worst"] = max(row["K_hip_worst"], d_ex / amax)
+                row["K_ref32_worst"] = max(row["K_ref32_worst"], r_ex / amax)
+                row["grad_hip_vs_exact_rel_max_worst"] = max(row["grad_hip_vs_exact_rel_max_worst"], d_ex / scale)
+                row["grad_ref32_vs_exact_rel_max_worst"] = max(row["grad_ref32_vs_exact_rel_max_worst"], r_ex / scale)
+                if d_ex > 1e-5 * amax:
+                    bad.append((("coarse." if k == 0 else "fine.") + nme, d_ex / amax, d_ex / scale))
+        assert off == g_hip.numel()
+        row["grad_bad"] = bad
+        clipped_hip, clipped_ex = g_hip.abs() > 0.1, g_ex.abs() > 0.1
+        diff = clipped_hip != clipped_ex
+        row["clipped_elements_hip"], row["clipped_elements_exact"] = int(clipped_hip.sum()), int(clipped_ex.sum())
+        row["clip_set_differences"] = int(diff.sum())
+        row["clip_set_difference_max_distance"] = float((g_ex[diff].abs() - 0.1).abs().max()) if bool(diff.any()) else 0.0
+        p_same, m_same, v_same = p0.clone(), m0.clone(), v0.clone()
+        O.adam_step(p_same, g_hip, m_same, v_same, step_i, lr_i, clip=0.1)
+        row["adam_same_grad_dw"] = float((p_same - p1_hip).abs().max())
+        p_or, m_or, v_or = p0.clone(), m0.clone(), v0.clone()
+        O.adam_step(p_or, g_32, m_or, v_or, step_i, lr_i, clip=0.1)
+        dw = (p_or - p1_hip).abs()
+        bound = 2e-6 + 2.0 * _adam_first_order_bound(dg_flat, g_32.clamp(-0.1, 0.1), m0, v0, step_i, lr_i)
+        row["dw_max"], row["dw_frac_beyond_2e-6"] = float(dw.max()), float((dw > 2e-6).float().mean())
+        row["dw_beyond_conditioning_bound"] = int((dw > bound).sum())
+        report.append(row)
+        print("  " + " ".join(f"{k}={t:.3e}" if isinstance(t, float) else f"{k}={t}" for k, t in row.items() if k != "grad_bad"), flush=True)
+        del ex, r32
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "teacher_forced_c3ss.json"), "w") as f:
+        json.dump({"what": "tests/test_gpu_training_parity.py::test_c3ss_teacher_forced_step", "snapshots": list(C3SS_SNAPSHOTS),
+                   "rows": report}, f, indent=1)
+    for row in report:
+        s_ = f"step {row['step']}: "
+        assert row["block_equals_oracle"] and row["rays_ref_max_err"] <= 1e-6 * 4.0, s_ + "batch assembly vs O.ss_block"
+        assert row["padding_d_raw_max"] == 0.0, s_ + "padding rows must get a zero gradient"
+        assert row["loss_rel_f32"] <= 1e-6 and row["loss_rel_f64"] <= 1e-6, s_ + "loss on the kernel's branch"
+        for tag, zb in (("f64", 1e-4), ("f32", 1e-5)):
+            assert row[f"relu_flip_max_abs_z_{tag}"] < zb, s_ + "ReLU pattern differs away from zero"
+            assert row[f"tail_substitution_max_abs_sigma_{tag}"] < 1e-5, s_ + "sigma branch differs away from zero"
+        assert row["relu_flip_frac"] < 1e-5, s_ + "too many ReLU pattern differences"
+        assert not row["grad_bad"], s_ + f"gradient [tensor, |d| / A_max, |d| / max|g|]: {row['grad_bad']}"
+        for lv in ("coarse", "fine"):
+            assert row[f"d_raw_{lv}_hip_vs_exact_rel_l2"] <= 2e-5, s_ + f"d loss / d raw ({lv})"
+        assert row["clip_set_differences"] <= 4 and row["clip_set_difference_max_distance"] <= 1e-5, s_ + "clipped element set"
+        assert row["adam_same_grad_dw"] <= 2e-7 + 2 * 6e-8 * 4.0, s_ + "Adam kernel (clip 0.1) on the same gradient"
+        assert row["dw_beyond_conditioning_bound"] == 0 and row["dw_frac_beyond_2e-6"] <= 1e-3, s_ + "updated weights"
