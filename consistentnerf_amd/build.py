@@ -33,6 +33,26 @@ def _stale(out, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _check_ticket_isa(verbose):
+    """composite.hip publishes a per-workgroup partial and then takes a ticket; correctness rests on an `s_waitcnt vmcnt(0)` between
+    the two in the generated ISA (a compiler-version property): asserted HERE, whenever the file is (re)compiled, so that a toolchain
+    that reorders them cannot produce a library at all (the check used to live only in a skippable test)."""
+    import importlib.util
+    asm = os.path.join(OBJ, "composite.s")
+    cmd = [HIPCC] + FLAGS + ["--cuda-device-only", "-S", os.path.join(CSRC, "composite.hip"), "-o", asm]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc -S failed on composite.hip:\n" + r.stdout + r.stderr)
+    spec = importlib.util.spec_from_file_location("isa_ticket_check", os.path.join(ROOT, "scripts", "isa_ticket_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad = mod.check(asm, need_sites=6)
+    if bad:
+        raise RuntimeError("ticket publish order check failed (composite.hip):\n" + "\n".join(bad))
+    if verbose:
+        print("[isa] composite.hip: ticket publish order ok (partial store -> s_waitcnt vmcnt(0) -> ticket atomic)")
+
+
 def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
@@ -56,6 +76,8 @@ def build(force=False, verbose=True):
                 print(f"[hipcc] {os.path.basename(src)} rc={rc}")
             if rc != 0:
                 raise RuntimeError(f"hipcc failed on {src}:\n{out}")
+    if any(os.path.basename(src) == "composite.hip" for src, _ in jobs):
+        _check_ticket_isa(verbose)
     objs = [os.path.join(OBJ, s[:-4] + ".o") for s in sources()]
     if force or jobs or _stale(LIB, objs):
         r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs,

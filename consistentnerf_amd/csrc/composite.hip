@@ -260,7 +260,12 @@ __global__ __launch_bounds__(WV * 64) void composite_fwd_k(const float* __restri
 #if defined(CN_MSE_HEAVY_FENCE)
       __threadfence();
 #elif !defined(CN_MSE_RELEASE_TICKET)
-      __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): the sc1 store has been acknowledged by the memory side
+      // vmcnt(0): the sc1 store has been acknowledged by the memory side.  Written as inline assembly with a "memory" clobber
+      // (ADVICE r05): the mnemonic carries no architecture-specific immediate (the builtin's 0x0f70 is the gfx9 encoding), and the
+      // clobber is a compiler-level barrier on BOTH sides — the partial's store cannot sink below the wait, the ticket RMW cannot be
+      // hoisted above it — which the s_waitcnt builtin (IntrNoMem) + a sched_barrier after it did not state.  The order in the ISA
+      // is asserted at BUILD time (consistentnerf_amd/build.py -> scripts/isa_ticket_check.py), not only by a test.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
 #endif
       // Two-level ticket: same-address atomics at agent scope serialise at ~40 ns each (measured: 8192 workgroups on ONE counter

@@ -60,7 +60,10 @@ __global__ void sample_pixels_k(PixDev p, int64_t B, const int64_t* __restrict__
     const int64_t k = b - p.n_patch_rays;
     uint32_t g;
     if (select) {
-      g = (uint32_t)select[k];
+      // caller-supplied indices address the image and the priors: clamp (a negative or too large index must not become an
+      // out-of-bounds read; raybank._sample range-checks them and raises / asserts — ADVICE r05)
+      const int64_t sv = select[k];
+      g = sv < 0 ? 0u : (sv >= (int64_t)p.n_grid ? (uint32_t)(p.n_grid - 1) : (uint32_t)sv);
     } else {
       const uint64_t seed = rk.dev ? rk.dev[0] : rk.seed;
       g = perm_index((uint32_t)k, p.n_grid, p.bits_a, p.bits_b, seed ^ 0x636e6572665f7078ull /* "cnerf_px" */,

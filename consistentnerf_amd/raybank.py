@@ -21,15 +21,21 @@ class PackedRays:
     """The [B, 8|11] rows render() would assemble from a (rays_o, rays_d) batch (R:100-125), written by the sampler's own launch
     for the camera / bounds named here; attached to the `batch_rays` tensor as `_cnerf_packed`, taken by run_nerf._ray_batch when
     the render() call asks for exactly these bounds (otherwise the rays are packed again, as for any caller's batch)."""
-    __slots__ = ("rows", "H", "W", "focal", "near", "far", "use_viewdirs", "ndc")
+    __slots__ = ("rows", "H", "W", "focal", "near", "far", "use_viewdirs", "ndc", "src_ptr", "src_version")
 
-    def __init__(self, rows, H, W, focal, near, far, use_viewdirs, ndc):
+    def __init__(self, rows, H, W, focal, near, far, use_viewdirs, ndc, src=None):
         self.rows, self.H, self.W, self.focal = rows, int(H), int(W), float(focal)
         self.near, self.far, self.use_viewdirs, self.ndc = float(near), float(far), bool(use_viewdirs), bool(ndc)
+        # the tensor the rows were packed FROM, as it was then: an in-place change of it afterwards (buf.copy_(new_rays), a scaled or
+        # perturbed direction) bumps its version counter and the packed rows are no longer taken (ADVICE r05)
+        self.src_ptr = None if src is None else src.data_ptr()
+        self.src_version = None if src is None else src._version
 
-    def matches(self, H, W, K, near, far, use_viewdirs, ndc, device):
+    def matches(self, H, W, K, near, far, use_viewdirs, ndc, device, src=None):
         if torch.is_tensor(near) or torch.is_tensor(far):
             return False
+        if src is not None and self.src_ptr is not None and (src.data_ptr() != self.src_ptr or src._version != self.src_version):
+            return False         # the batch tensor was modified in place since its rows were packed: pack its current contents
         return (self.rows.device == torch.device(device) and float(near) == self.near and float(far) == self.far
                 and bool(use_viewdirs) == self.use_viewdirs and bool(ndc) == self.ndc
                 and (not self.ndc or (int(H) == self.H and int(W) == self.W and float(K[0][0]) == self.focal)))
@@ -57,7 +63,21 @@ def _sample(target, pose, H, W, K, N_rand, patch_starts, patch_size, select_inds
     pk = _pack_args(render_kwargs)
     near, far, vd, ndc = pk if pk is not None else (0., 1., False, False)
     coef = ndc_coefficients(H, W, K[0][0]) if ndc else (0., 0.)
-    sel = None if select_inds is None else torch.as_tensor(select_inds, device=dev, dtype=torch.long)
+    sel = None
+    if select_inds is not None:
+        # caller-supplied pixel indices go straight into image / prior addresses: range-checked here (the kernel clamps as well) —
+        # on the host when they are host data, by a device-side assertion (no synchronisation) when they already live on the GPU
+        n_grid = crop[2] * crop[3]
+        if isinstance(select_inds, torch.Tensor) and select_inds.is_cuda:
+            sel = select_inds.to(device=dev, dtype=torch.long)
+            if sel.numel():
+                torch._assert_async(((sel >= 0) & (sel < n_grid)).all())
+        else:
+            arr = np.asarray(select_inds.cpu() if isinstance(select_inds, torch.Tensor) else select_inds).astype(np.int64).reshape(-1)
+            if arr.size and (arr.min() < 0 or arr.max() >= n_grid):
+                raise IndexError(f"select_inds must lie in [0, {n_grid}) (the {crop[2]} x {crop[3]} pixel grid); got "
+                                 f"[{arr.min()}, {arr.max()}]")
+            sel = torch.as_tensor(arr, device=dev, dtype=torch.long)
     n_rand = int(N_rand) if sel is None else int(sel.numel())
     rng = ops.rng_draw(dev) if sel is None and n_rand > 0 else None
     ex = [torch.as_tensor(e, dtype=torch.float32).to(dev) for e in extras]
@@ -65,7 +85,7 @@ def _sample(target, pose, H, W, K, N_rand, patch_starts, patch_size, select_inds
                                                       near, far, vd, ndc, coef, crop, patch_starts, patch_size, n_rand, sel, rng,
                                                       image, ex, want_rows=pk is not None)
     if rows is not None:
-        od._cnerf_packed = PackedRays(rows, H, W, K[0][0], near, far, vd, ndc)
+        od._cnerf_packed = PackedRays(rows, H, W, K[0][0], near, far, vd, ndc, src=od)
     return od, tgt, coords, ([ex_out[i] for i in range(len(ex))] if ex else [])
 
 

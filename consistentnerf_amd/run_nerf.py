@@ -640,7 +640,7 @@ def _ray_batch(H, W, K, rays, c2w, ndc, near, far, use_viewdirs, c2w_staticcam, 
             batch = ops.gen_rays(H, W, K, c2w, near_s, far_s, use_viewdirs, ndc, device, coef)
     else:
         pk = getattr(rays, "_cnerf_packed", None)
-        if pk is not None and pk.matches(H, W, K, near, far, use_viewdirs, ndc, device):
+        if pk is not None and pk.matches(H, W, K, near, far, use_viewdirs, ndc, device, src=rays if torch.is_tensor(rays) else None):
             # raybank's one-launch sampler already wrote the [B, 8|11] rows this call would assemble (same arithmetic: raygen.hpp)
             return pk.rows, (pk.rows.shape[0],)
         rays_o, rays_d = rays

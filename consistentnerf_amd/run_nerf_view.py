@@ -285,7 +285,7 @@ def _ss_rays(rays_o, rays_d, depth_cas_s, pose_ref, K, image_ref, depth_ref, H, 
     batch_rays_ref = o["rays_od"]
     if o["rows"] is not None:
         from .raybank import PackedRays
-        batch_rays_ref._cnerf_packed = PackedRays(o["rows"], H, W, K[0][0], near, far, vd, ndc)
+        batch_rays_ref._cnerf_packed = PackedRays(o["rows"], H, W, K[0][0], near, far, vd, ndc, src=batch_rays_ref)
     tgt = o["target"]
     return dict(mask_bound=o["inb"].view(torch.bool)[None], mask=o["mask"].view(torch.bool)[:, None], sel=o["sel"],
                 threshold=torch.tensor(o["thr"], dtype=torch.float32), batch_rays_ref=batch_rays_ref,
