@@ -960,6 +960,24 @@ class Workload:
         self.opt.step(grad_scale=self.reducer.grad_scale)
         return loss
 
+    def timed_body(self, rays_o, rays_d, tgt):
+        """body() with a device synchronisation after each phase -> host wall ms per phase (diagnostic; cf. GraphedStep.timed_call)."""
+        t = {}
+
+        def lap(name, t0):
+            torch.cuda.synchronize()
+            t[name] = (time.perf_counter() - t0) * 1e3
+            return time.perf_counter()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        self.fwd_bwd(rays_o, rays_d, tgt)
+        t0 = lap("fwd_bwd_ms", t0)
+        self.reducer.finish()
+        t0 = lap("exchange_ms", t0)
+        self.opt.step(grad_scale=self.reducer.grad_scale)
+        lap("adam_ms", t0)
+        return t
+
     def batch(self, i, per_rank):
         """rank's contiguous slice of global batch i (every rank holds the identical, identically shuffled bank)"""
         gstep = per_rank * self.world
@@ -1039,6 +1057,21 @@ def shard_leg(wl, per_rank, steps, warmup, collective="split", i0=100000, also_c
     g = wl.graphed(per_rank, collective)
     el_g, loss_g, _ = wl.run(per_rank, steps, warmup, i0=i0 + steps + warmup, graphed=g)
     ms["graph"] = el_g / steps * 1e3
+    # per-phase view of both forms (a device synchronisation after every phase: the sum bounds a step from above, the split says
+    # where a slow data-parallel step spends its time — VERDICT r05 item 7: the graphed `split` step at world 2 over gloo on one
+    # GPU ran at 88 ms against 29.8 eager, and nothing said whether that was the exchange, the replay or the host)
+    import statistics
+    phases = {"graph": {}, "eager": {}}
+    for k in range(6):
+        b = wl.batch(i0 + 3 * (steps + warmup) + k, per_rank)
+        _, t = g.timed_call(*b)
+        for name, v in t.items():
+            phases["graph"].setdefault(name, []).append(v)
+        te = wl.timed_body(*wl.batch(i0 + 3 * (steps + warmup) + 6 + k, per_rank))
+        for name, v in te.items():
+            phases["eager"].setdefault(name, []).append(v)
+    wl.D.barrier()
+    phase_ms = {form: {name: round(statistics.median(v), 3) for name, v in d.items()} for form, d in phases.items()}
     ms_capture = None
     if also_capture and wl.reducer_active():
         try:
@@ -1057,6 +1090,7 @@ def shard_leg(wl, per_rank, steps, warmup, collective="split", i0=100000, also_c
             "host_enqueue_ms_per_eager_step": round(host, 3),
             "mfma_kernels_ms_per_step": round(mfma_ms, 4), "step_ms_at_mfma_peak": round(ideal_ms, 4),
             "frac_of_peak_graph": round(ideal_ms / ms["graph"], 4), "frac_of_peak_eager": round(ideal_ms / ms["eager"], 4),
+            "phase_ms_synchronised": phase_ms,
             "final_loss": float(loss_g.item()), "kernels": table}
 
 

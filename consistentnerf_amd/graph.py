@@ -81,14 +81,20 @@ class GraphedStep:
         if reducer is not None:
             self._msgs_before, self._steps_before = reducer.messages, reducer.steps
         try:
-            with torch.cuda.graph(self.graph):    # (recorded, not executed: the step counter does not move here)
+            # capture_error_mode: with a process group alive, c10d's watchdog THREAD polls the events of earlier collectives
+            # (hipEventQuery).  Under the default "global" mode such a call from another thread while this thread is capturing is
+            # an error (hipErrorStreamCaptureUnsupported) that terminates the process — reproduced in 1 of 12 recordings on a
+            # 1-rank RCCL group (round 6).  "thread_local" restricts the check to the capturing thread.
+            import torch.distributed as _dist
+            mode = "thread_local" if (reducer is not None or (_dist.is_available() and _dist.is_initialized())) else "global"
+            with torch.cuda.graph(self.graph, capture_error_mode=mode):    # (recorded, not executed: the step counter does not move here)
                 self.static_loss = step_fn(*self.static_in)
                 if reducer is not None and collective == "capture":
                     tail()
             if reducer is not None and collective == "split":
                 reducer.reset()                   # the recorded backward counted its nodes; nothing was issued
                 self.tail_graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.tail_graph, pool=self.graph.pool()):
+                with torch.cuda.graph(self.tail_graph, pool=self.graph.pool(), capture_error_mode=mode):
                     optimizer.step(grad_scale=reducer.grad_scale)
             ok = True
         finally:
@@ -131,6 +137,40 @@ class GraphedStep:
         if self.reducer is not None:
             self.reducer.reset()
             self.reducer.hold = self._hold_before
+
+    def timed_call(self, *inputs: torch.Tensor):
+        """DIAGNOSTIC form of __call__: the same replay with a device synchronisation after every phase and the host's wall time of
+        each — {inputs_ms: the static-input copies + Adam / RNG scalar uploads, graph_ms: the recorded [render, loss, backward
+        (+ all-reduce + Adam when the collective is recorded inside)], exchange_ms: reducer.finish() of the split form (the eager
+        all-reduce of the flat gradient: RCCL over xGMI, or gloo's host staging in the one-GPU tests), tail_ms: the recorded Adam} —
+        so that a slow data-parallel graphed step can be read phase by phase (bench.py's c4_strong leg).  The synchronisations
+        remove the host / device overlap the real __call__ has: the SUM is an upper bound of a step, the SPLIT is the information."""
+        import time
+        t = {}
+
+        def lap(name, t0):
+            torch.cuda.synchronize()
+            t[name] = (time.perf_counter() - t0) * 1e3
+            return time.perf_counter()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for dst, src in zip(self.static_in, inputs):
+            dst.copy_(src)
+        self.opt.advance(1.0 if self.reducer is None else self.reducer.grad_scale)
+        self._advance_rng()
+        t0 = lap("inputs_ms", t0)
+        self.graph.replay()
+        t0 = lap("graph_ms", t0)
+        if self.tail_graph is not None:
+            self.reducer.finish()
+            t0 = lap("exchange_ms", t0)
+            self.tail_graph.replay()
+            t0 = lap("tail_ms", t0)
+        elif self.reducer is not None:
+            self.reducer.steps += 1
+            self.reducer.messages += self._msgs_per_replay
+        self.opt.bump_epoch()
+        return self.static_loss, t
 
     def __call__(self, *inputs: torch.Tensor) -> torch.Tensor:
         for dst, src in zip(self.static_in, inputs):

@@ -2864,9 +2864,51 @@ dmax = float((p_sh - p_1).abs().max())
 frac = float(((p_sh - p_1).abs() > 1e-6).float().mean())
 assert rel_l < 1e-5, (l_sh, l_1)
 assert dmax < 2e-3 and frac < 0.02, (dmax, frac)
+
+# ---- the in-loop consistency step (a15, VT:899-969) sharded over the two ranks: run_nerf_view.ss_step_loss(group=...) runs the two
+# batch-global exchanges itself (all-reduce MIN of the minimum |z - D_ref| for the threshold-doubling rule, all-reduce SUM of the
+# three ray counts the masked means divide by); the per-rank losses add up, the flat gradient is SUMMED (GradReducer(mean=False))
+from test_gpu_parity import _ss_scene
+
+def run_ss(sharded):
+    sc = _ss_scene(dev, 1024, seed=7, owned=True)
+    opt, kw = sc["opt"], sc["kw"]
+    red = D.GradReducer(opt, [sc["coarse"], sc["fine"]], mean=False) if sharded else None
+    img, dep = torch.from_numpy(sc["g"]["images"][1]).to(dev), torch.from_numpy(sc["g"]["depths"][1]).to(dev)
+    losses, thr = [], []
+    for i in range(2):
+        rays, tgt = sc["rays"], sc["tgt"]
+        prior = sc["prior"] + 0.01 * i + torch.linspace(0.0, 0.05, 1024, device=dev)
+        if sharded:
+            lo, hi = D.shard_bounds(1024)
+            rays, tgt, prior = rays[:, lo:hi].contiguous(), tgt[lo:hi], prior[lo:hi]
+        loss, info = V.ss_step_loss(sc["H"], sc["W"], sc["K"], rays, tgt, prior, sc["poses"][1], img, dep, kw, chunk=4096,
+                                    occlusion_threshold=3e-4, with_depth_loss=True, coins=(1, 1, 0, 1), route="one_render",
+                                    group=dist.group.WORLD if sharded else None)
+        opt.zero_grad()
+        loss.backward()
+        if sharded:
+            red.finish()
+            loss = D.allreduce_scalar_sum(loss.detach())
+        opt.step()
+        losses.append(float(loss))
+        thr.append(float(V.ss_host_view(info)["threshold"]))
+    torch.cuda.synchronize()
+    return opt.flat_param.clone(), losses, thr
+
+ps_sh, ls_sh, t_sh = run_ss(True)
+ps_1, ls_1, t_1 = run_ss(False)
+chk = ps_sh.clone(); dist.broadcast(chk, 0)
+assert torch.equal(chk, ps_sh), "ranks diverged (ss step)"
+assert t_sh == t_1 and t_1[0] > 3e-4, (t_sh, t_1)          # every rank applied the WHOLE batch's (doubled) threshold
+rel_ss = max(abs(a - b) / abs(b) for a, b in zip(ls_sh, ls_1))
+dmax_ss = float((ps_sh - ps_1).abs().max())
+frac_ss = float(((ps_sh - ps_1).abs() > 1e-6).float().mean())
+assert rel_ss < 1e-5, (ls_sh, ls_1)
+assert dmax_ss < 2e-3 and frac_ss < 0.02, (dmax_ss, frac_ss)
 D.barrier()
 if rank == 0:
-    print("DIST2_GPU_OK", l_sh, l_1, dmax, frac)
+    print("DIST2_GPU_OK", l_sh, l_1, dmax, frac, "ss:", ls_sh, ls_1, dmax_ss, frac_ss)
 dist.destroy_process_group()
 """
 
@@ -2877,7 +2919,9 @@ def test_two_ranks_product_step_on_one_gpu(dev, tmp_path):
     counts, render + backward through the HIP kernels into their FusedAdam.flat_grad, exchange it with GradReducer (one
     all-reduce per network slice, issued from inside loss.backward()) and step.  After 3 steps the replicas are identical,
     the summed losses equal the single-rank losses of the whole batch (1e-5), and the weights agree up to Adam's sensitivity
-    to the summation order of near-zero gradient elements."""
+    to the summation order of near-zero gradient elements.  Round 6: the same for the in-loop consistency step (a15) —
+    run_nerf_view.ss_step_loss(group=WORLD): global threshold (all-reduce MIN) + global ray counts (all-reduce SUM), summed flat
+    gradient — two sharded steps == the two single-rank steps."""
     import subprocess
     import sys
     script = tmp_path / "dist2_gpu_worker.py"

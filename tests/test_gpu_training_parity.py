@@ -112,6 +112,26 @@ def _oracle_step(dtype, w0, names, rays, tgt, z_c, z_f, masks_c, masks_f, raw_k,
     return _oracle_step_impl(dtype, w0, names, rays, tgt, z_c, z_f, masks_c, masks_f, raw_k, ncfg, want_abs, loss_fn)
 
 
+def _oracle_step_cpu32(*common, loss_fn_factory=None):
+    """The reference arithmetic itself: the oracle's step in fp32 ON THE CPU.  One full suite run of round 6 saw this evaluation —
+    and only it: the HIP step and the float64 evaluation of the same inputs were bit-identical to every other run — come back with
+    NaNs in four sample points on one box of the pool (stock ATen addmm on 32 threads; not reproducible on that test alone or in
+    two further suite runs).  A non-finite CHECKER value is therefore recomputed once, single-threaded, and the row says so
+    (`cpu_ref32_retried`); a second non-finite result fails the test as before."""
+    mk = loss_fn_factory if loss_fn_factory is not None else (lambda: None)
+    res = _oracle_step(torch.float32, *common, loss_fn=mk())
+    res["retried"] = False
+    if not (np.isfinite(res["loss"]) and bool(torch.isfinite(res["grad"]).all())):
+        n = torch.get_num_threads()
+        torch.set_num_threads(1)
+        try:
+            res = _oracle_step(torch.float32, *common, loss_fn=mk())
+        finally:
+            torch.set_num_threads(n)
+        res["retried"] = True
+    return res
+
+
 def _oracle_step_impl(dtype, w0, names, rays, tgt, z_c, z_f, masks_c, masks_f, raw_k, ncfg, want_abs=False, loss_fn=None):
     """The oracle's training step on the KERNEL'S BRANCH (module docstring) in `dtype`: O.query -> O.composite on both levels ->
     mse + mse -> autograd.  raw_k = the kernel's (coarse, fine) raw outputs (fp32, CPU) for the tail-branch substitution.
@@ -232,7 +252,7 @@ def test_c2_teacher_forced_training_steps(dev, monkeypatch):
         rays_c, tgt_c = bank[lo:hi], target[lo:hi]
         common = (w0, names, rays_c, tgt_c, z_c, z_f, masks_c, masks_f, raw_k, ncfg)
         ex = _oracle_step(torch.float64, *common, want_abs=True, device=dev)
-        r32 = _oracle_step(torch.float32, *common)
+        r32 = _oracle_step_cpu32(*common)
         del masks_c, masks_f
         with torch.no_grad():      # the oracle running free: its own depths, ReLU patterns, tail signs
             osd = [{k: v.clone() for k, v in d.items()} for d in w0]
@@ -240,7 +260,7 @@ def test_c2_teacher_forced_training_steps(dev, monkeypatch):
             loss_free = float(O.mse(fr["rgb_map"], tgt_c) + O.mse(fr["rgb0"], tgt_c))
             dz = (fr["z_vals"] - z_f).abs().flatten()
         sig_last = raw_k[1][:, -1, 3]
-        row = {"step": i, "loss_hip": loss_hip, "loss_oracle_f32": r32["loss"], "loss_oracle_f64": ex["loss"],
+        row = {"step": i, "cpu_ref32_retried": r32["retried"], "loss_hip": loss_hip, "loss_oracle_f32": r32["loss"], "loss_oracle_f64": ex["loss"],
                "loss_oracle_free_running": loss_free,
                "loss_rel_f32": abs(loss_hip - r32["loss"]) / abs(r32["loss"]),
                "loss_rel_f64": abs(loss_hip - ex["loss"]) / abs(ex["loss"]),
@@ -441,9 +461,9 @@ def test_c3_teacher_forced_step(dev, monkeypatch):
         lf = _C3Loss(m.cpu(), d_prior.cpu(), mono_s.cpu(), far)
         common = (w0, names, rows_c, target.cpu(), z_c, z_f, masks_c, masks_f, raw_k, ncfg)
         ex = _oracle_step(torch.float64, *common, want_abs=True, device=dev, loss_fn=lf)
-        r32 = _oracle_step(torch.float32, *common, loss_fn=lf)
+        r32 = _oracle_step_cpu32(*common, loss_fn_factory=lambda: lf)
         del masks_c, masks_f
-        row = {"step": i, "loss_hip": loss_hip, "loss_oracle_f32": r32["loss"], "loss_oracle_f64": ex["loss"],
+        row = {"step": i, "cpu_ref32_retried": r32["retried"], "loss_hip": loss_hip, "loss_oracle_f32": r32["loss"], "loss_oracle_f64": ex["loss"],
                "loss_rel_f32": abs(loss_hip - r32["loss"]) / abs(r32["loss"]), "loss_rel_f64": abs(loss_hip - ex["loss"]) / abs(ex["loss"]),
                "terms_hip": {k: float(t) for k, t in terms.items()}}
         for tag, res in (("f64", ex), ("f32", r32)):
@@ -641,9 +661,9 @@ def test_c3ss_teacher_forced_step(dev, monkeypatch):
         mk = lambda: _SSLoss(N, blk["mask_bound"], blk["mask"], d_prior.cpu(), blk["rays_depth_ref"].reshape(-1), coins)  # noqa: E731
         common = (w0, names, rows_c, tgt2, z_c, z_f, masks_c, masks_f, raw_k, ncfg)
         ex = _oracle_step(torch.float64, *common, want_abs=True, device=dev, loss_fn=mk())
-        r32 = _oracle_step(torch.float32, *common, loss_fn=mk())
+        r32 = _oracle_step_cpu32(*common, loss_fn_factory=mk)
         del masks_c, masks_f
-        row = {"step": i, "coins": coins, "live_rows": live, "M": M, "threshold": float(hv["threshold"]), "block_equals_oracle": bool(ok_block),
+        row = {"step": i, "cpu_ref32_retried": r32["retried"], "coins": coins, "live_rows": live, "M": M, "threshold": float(hv["threshold"]), "block_equals_oracle": bool(ok_block),
                "rays_ref_max_err": rays_err, "padding_d_raw_max": pad_d_raw,
                "loss_hip": loss_hip, "loss_oracle_f32": r32["loss"], "loss_oracle_f64": ex["loss"],
                "loss_rel_f32": abs(loss_hip - r32["loss"]) / abs(r32["loss"]), "loss_rel_f64": abs(loss_hip - ex["loss"]) / abs(ex["loss"]),
