@@ -159,6 +159,7 @@ SIGNATURES = {
                             _vp, _vp, _vp]),
     "cnerf_mse": (_i, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "cnerf_mse_ws_floats": (_i64, [_i64]),
+    "cnerf_soft_lp_loss": (_i, [_vp, _vp, _i64, _f, _vp, _vp, _vp]),
     "cnerf_mse_ws": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "cnerf_loss_ws_floats": (_i64, []),
     "cnerf_masked_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _vp, _f, _vp, _vp, _vp, _vp, _vp]),

@@ -375,6 +375,43 @@ extern "C" int cnerf_mse(const float* x, const float* y, int64_t n, float* loss,
   return CNERF_OK;
 }
 
+// img2mse_softLpmask (V:58; the `--softLpmask` branch of the loss, V:1663-1664 / V:1760-1761): every squared residual weighted by
+// w = |d|^coef + 1, normalised by the DETACHED sum of the weights:  loss = sum(w d^2) / sum(w).  Gradient w.r.t. x (the denominator
+// carries none): (dw/dd d^2 + 2 w d) / sum(w) with dw/dd = coef |d|^(coef - 1) sign(d)  ->  d (coef |d|^coef + 2 w) / sum(w).
+// One workgroup, two sweeps (sums in fp64, fixed order), value + gradient seed in one launch like mse_k.
+namespace {
+__global__ __launch_bounds__(T) void soft_lp_k(const float* __restrict__ x, const float* __restrict__ y, int64_t n, float coef,
+                                               float* __restrict__ loss, float* __restrict__ d_x) {
+  __shared__ double sh[T / 64];
+  __shared__ double tot[2];
+  double num = 0, den = 0;
+  for (int64_t i = threadIdx.x; i < n; i += T) {
+    const float d = x[i] - y[i];
+    const float w = powf(fabsf(d), coef) + 1.f;
+    num += (double)(w * (d * d));
+    den += (double)w;
+  }
+  num = block_sum(num, sh);
+  den = block_sum(den, sh);
+  if (threadIdx.x == 0) { tot[0] = num; tot[1] = den; loss[0] = (float)(num / den); }
+  __syncthreads();
+  if (!d_x) return;
+  const float inv = (float)(1.0 / tot[1]);
+  for (int64_t i = threadIdx.x; i < n; i += T) {
+    const float d = x[i] - y[i];
+    const float p = powf(fabsf(d), coef);
+    d_x[i] = (d * (coef * p + 2.f * (p + 1.f))) * inv;
+  }
+}
+}  // namespace
+
+extern "C" int cnerf_soft_lp_loss(const float* x, const float* y, int64_t n, float coef, float* loss, float* d_x, void* stream) {
+  if (!x || !y || !loss || n <= 0 || !(coef > 0.f)) return CNERF_E_ARG;
+  hipLaunchKernelGGL(soft_lp_k, dim3(1), dim3(T), 0, cn_stream(stream), x, y, n, coef, loss, d_x);
+  CN_CHECK_LAUNCH();
+  return CNERF_OK;
+}
+
 // Large inputs (whole images: img2mse of a rendered 756 x 1008 frame is 2.3 M elements): one workgroup per MSE_CHUNK elements writes
 // its fp64 partial, a second single-workgroup stage sums the partials in index order — the value does not depend on the grid the
 // first stage ran on or on the order its workgroups finished in.

@@ -964,6 +964,17 @@ def mse(x: Tensor, y: Tensor, want_grad: bool = True):
     return loss[0], d_x
 
 
+def soft_lp_loss(x: Tensor, y: Tensor, coef: float, want_grad: bool = True):
+    """cnerf_soft_lp_loss (V:58): (sum(w d^2) / sum(w) with w = |d|^coef + 1 and a detached denominator, d loss / d x | None)."""
+    x, y = _chk(x, "x"), _chk(y, "y")
+    if x.shape != y.shape or x.numel() == 0:
+        raise CnerfError("soft_lp_loss: x and y must be non-empty tensors of one shape")
+    loss = torch.empty(1, device=x.device)
+    d_x = torch.empty_like(x) if want_grad else None
+    _lib.check(_lib.load().cnerf_soft_lp_loss(_p(x), _p(y), x.numel(), float(coef), _p(loss), _p(d_x), _stream()), "cnerf_soft_lp_loss")
+    return loss[0], d_x
+
+
 def patch_depth_loss(depth_pred: Tensor, mono: Tensor, P: int, n: int, g_scale: float = 1.0, want_grad: bool = True):
     """f-5 (V:1678-1720): (loss[1], d_depth[P*n] | None) over the first P*n rays."""
     depth_pred, mono = _chk(depth_pred, "depth_pred"), _chk(mono, "mono")

@@ -179,6 +179,67 @@ class _PatchDepthLossFn(torch.autograd.Function):
         return out.reshape(ctx.shape), None, None, None
 
 
+class _SoftLpFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, coef):
+        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        loss, d_x = ops.soft_lp_loss(x, y, coef, need)
+        if need:
+            ctx.save_for_backward(d_x)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        d_x, = ctx.saved_tensors
+        gx = d_x * g
+        return (gx if ctx.needs_input_grad[0] else None), (-gx if ctx.needs_input_grad[1] else None), None
+
+
+def img2mse_softLpmask(x, y, coef):
+    """V:58, the `--softLpmask` branch of the loss (V:1663-1664 on colours, V:1760-1761 on depths / far): every squared residual
+    weighted by |x - y|^coef + 1, normalised by the detached sum of the weights.  One launch (value + gradient seed) for same-shape
+    fp32 GPU tensors; the reference's expression on ATen otherwise.  One deliberate difference: where x == y exactly and coef < 1 the
+    reference's autograd returns NaN (inf * 0 in the derivative of |d|^coef); the kernel returns the limit, 0."""
+    if (torch.is_tensor(x) and torch.is_tensor(y) and x.is_cuda and y.is_cuda and x.shape == y.shape and x.numel() > 0
+            and x.dtype == torch.float32 and y.dtype == torch.float32):
+        return _SoftLpFn.apply(x.contiguous(), y.contiguous(), float(coef))
+    d = x - y
+    w = d.abs() ** coef + 1
+    return torch.sum(w * d ** 2) / torch.sum(w).detach()
+
+
+class Temp_Scheduler:
+    """V:80-100 — the linear schedule of the pseudo-label noise level (`std_scheduler = Temp_Scheduler(total_iters, 0.2, 0.05,
+    temp_min=0.05)`, V:1420): step() -> (1 - epoch / total) (base - min) + min, floored at min; epoch counts the calls (the
+    constructor already makes one)."""
+
+    def __init__(self, total_epochs, curr_temp, base_temp, temp_min=0.33, last_epoch=-1):
+        self.curr_temp, self.base_temp, self.temp_min = curr_temp, base_temp, temp_min
+        self.last_epoch, self.total_epochs = last_epoch, total_epochs
+        self.step(last_epoch + 1)
+
+    def step(self, epoch=None):
+        # (the reference's step() ignores its argument and always advances by one: kept)
+        self.last_epoch += 1
+        self.curr_temp = max((1 - self.last_epoch / self.total_epochs) * (self.base_temp - self.temp_min) + self.temp_min,
+                             self.temp_min)
+        return self.curr_temp
+
+
+def add_label_noise(rgb, depth_pred, extras, std, far, generator=None):
+    """The `--use_noise` block (V:1633-1638): N(0, std) added to the rendered colours of both levels, far * N(0, std) to their depths,
+    before the losses.  Returns (rgb, depth_pred, extras) — `extras` is updated in place like the reference's dict.  The draws come
+    from the device generator (the reference draws on the CPU and copies: same distribution, another stream)."""
+    n = lambda t, s: torch.randn(t.shape, device=t.device, dtype=t.dtype, generator=generator) * s  # noqa: E731
+    rgb = rgb + n(rgb, std)
+    depth_pred = depth_pred + far * n(depth_pred, std)
+    if 'rgb0' in extras:
+        extras['rgb0'] = extras['rgb0'] + n(extras['rgb0'], std)
+    if 'depth0' in extras:
+        extras['depth0'] = extras['depth0'] + far * n(extras['depth0'], std)
+    return rgb, depth_pred, extras
+
+
 def midas_patch_loss(depth_pred, mono_dpt_s, patch_num=4, patch_size=16):
     """`mono_depth_mses` of V:1678-1720 (the monocular-depth patch term; its SSIM / LPIPS neighbours are out of scope):
     the first patch_num * patch_size^2 rays of the batch are the sampled patches (raybank.sample_patch_rays)."""

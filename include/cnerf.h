@@ -505,6 +505,9 @@ int cnerf_mse(const float* x, const float* y, int64_t n, float* loss, float* d_x
 /* The same for whole images (H:9 on a rendered frame, R:836-845): `workspace` of cnerf_mse_ws_floats(n) floats (8-byte aligned) holds
  * one fp64 partial per 16384 elements, summed in index order by a second stage; n <= 16384 or workspace == NULL: cnerf_mse. */
 int64_t cnerf_mse_ws_floats(int64_t n);
+/* img2mse_softLpmask (run_nerf_view.py:58; the `--softLpmask` loss branch, :1663-1664, :1760-1761): loss[0] = sum(w d^2) / sum(w),
+ * d = x - y, w = |d|^coef + 1 with the denominator detached; d_x (nullable) = the gradient w.r.t. x.  One launch, fixed order. */
+int cnerf_soft_lp_loss(const float* x, const float* y, int64_t n, float coef, float* loss, float* d_x, void* stream);
 int cnerf_mse_ws(const float* x, const float* y, int64_t n, float* loss, float* d_x, float* workspace, void* stream);
 
 /* ---- a14: masked photometric / depth losses  (V:1645-1648, V:1737, V:1786-1788, V:1865) --------- */

@@ -445,6 +445,20 @@ def psnr_from_mse(m: Tensor) -> Tensor:
     return -10.0 * torch.log(m) / torch.log(torch.tensor([10.0]))
 
 
+def mse_soft_lp(x: Tensor, y: Tensor, coef: float) -> Tensor:
+    """img2mse_softLpmask (run_nerf_view.py V:58): squared residuals weighted by |d|^coef + 1, over the DETACHED weight sum."""
+    d = x - y
+    w = torch.pow(torch.abs(d), coef) + 1
+    return torch.sum(w * (d * d)) / torch.sum(w).detach()
+
+
+def noise_level(total_iters: int, calls: int, base: float = 0.05, floor: float = 0.05) -> float:
+    """What the `calls`-th step() of `Temp_Scheduler(total_iters, 0.2, base, temp_min=floor)` returns (V:80-100, V:1420): the
+    constructor itself advances the counter once (to epoch 0), every step() by one more."""
+    epoch = calls            # epoch 0 is consumed by the constructor: the first step() sees epoch 1
+    return max((1 - epoch / total_iters) * (base - floor) + floor, floor)
+
+
 def masked_rgb_loss(rgb: Tensor, target: Tensor, m: Tensor, coef: float) -> Tensor:
     loss = mse(rgb[m == 1], target[m == 1])
     if m.sum() != m.shape[0]:

@@ -918,6 +918,28 @@ def fx_ssloss_primary():
     save("ssloss_primary", **out)
 
 
+def fx_altlosses():
+    """The alternative photometric loss of run_nerf_view.py — img2mse_softLpmask (V:58; `--softLpmask`, V:1663-1664 on colours,
+    V:1760-1761 on depth / far) — called on seeded colours and depths for three exponents, with its gradients; and the noise-level
+    schedule of `--use_noise` (Temp_Scheduler V:80-100 as constructed at V:1420)."""
+    rs = np.random.RandomState(91)
+    x3, y3 = rs.uniform(size=(517, 3)).astype(np.float32), rs.uniform(size=(517, 3)).astype(np.float32)
+    x1, y1 = rs.uniform(0.2, 1.0, size=(517,)).astype(np.float32), rs.uniform(0.2, 1.0, size=(517,)).astype(np.float32)
+    y3[:5] = x3[:5]                                        # exact zeros of the residual (|d|^coef at 0)
+    out = dict(x3=x3, y3=y3, x1=x1, y1=y1)
+    for coef in (2.0, 1.0, 0.5):
+        for tag, (x, y) in (("rgb", (x3, y3)), ("depth", (x1, y1))):
+            xt = T(x).requires_grad_(True)
+            loss = V.img2mse_softLpmask(xt, T(y), coef)
+            loss.backward()
+            out[f"{tag}.c{coef}.loss"] = loss.detach()
+            out[f"{tag}.c{coef}.d_x"] = xt.grad
+    for total, base, floor in ((200000, 0.05, 0.05), (50, 0.2, 0.05)):
+        sch = V.Temp_Scheduler(total, 0.2, base, temp_min=floor)
+        out[f"sched.{total}"] = np.array([sch.step() for _ in range(60)], np.float64)
+    save("altlosses", **out)
+
+
 def fx_trained():
     """A WELL-CONDITIONED end-to-end fixture: the reference itself trains the C2 networks (D=8/W=256, viewdirs,
     64 + 128 samples) for 200 steps of its vanilla loop (run_nerf.py:764-788, pytest RNG, 1024-ray batches) on the analytic
@@ -992,7 +1014,7 @@ def fx_trained():
     save("render_rays_trained", **arrays)
 
 
-ALL = dict(trained=fx_trained, train_v=fx_train_v, ssloss_primary=fx_ssloss_primary, ssloss=fx_ssloss, poses=fx_poses, patch=fx_patch, formats=fx_formats, raybank=fx_raybank, embed=fx_embed, mlp=fx_mlp, raw2outputs=fx_raw2outputs, sample_pdf=fx_sample_pdf, sample_pdf_bulk=fx_sample_pdf_bulk,
+ALL = dict(trained=fx_trained, altlosses=fx_altlosses, train_v=fx_train_v, ssloss_primary=fx_ssloss_primary, ssloss=fx_ssloss, poses=fx_poses, patch=fx_patch, formats=fx_formats, raybank=fx_raybank, embed=fx_embed, mlp=fx_mlp, raw2outputs=fx_raw2outputs, sample_pdf=fx_sample_pdf, sample_pdf_bulk=fx_sample_pdf_bulk,
            render_rays=fx_render_rays, render_full=fx_render_full, warp=fx_warp, hardmask=fx_hardmask,
            losses=fx_losses, train=fx_train, pairs=fx_pairs)
 

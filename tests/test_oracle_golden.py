@@ -393,3 +393,20 @@ def test_render_rays_trained_network():
                        ("z_std", 1e-5 * far)):
             d = float((out[k] - T(g[tag + k])[::4]).abs().max())
             assert d <= tol, (tag, k, d)
+
+
+def test_alt_losses_golden():
+    """img2mse_softLpmask (V:58) and the `--use_noise` level schedule (V:80-100, V:1420) against the reference's own objects
+    (fixture `altlosses`): value and gradient for three exponents incl. exact-zero residuals; 60 scheduler steps, two settings."""
+    g = golden("altlosses")
+    for coef in (2.0, 1.0, 0.5):
+        for tag, (xk, yk) in (("rgb", ("x3", "y3")), ("depth", ("x1", "y1"))):
+            x = T(g[xk]).requires_grad_(True)
+            loss = O.mse_soft_lp(x, T(g[yk]), coef)
+            loss.backward()
+            eq(loss, g[f"{tag}.c{coef}.loss"])
+            eq(x.grad, g[f"{tag}.c{coef}.d_x"], f"{tag} c={coef}")
+    for total, base, floor in ((200000, 0.05, 0.05), (50, 0.2, 0.05)):
+        want = g[f"sched.{total}"]
+        got = np.array([O.noise_level(total, k + 1, base, floor) for k in range(60)])
+        assert np.array_equal(got, want), (total, got[:5], want[:5])
