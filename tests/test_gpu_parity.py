@@ -1625,8 +1625,9 @@ def test_ss_step_one_render_equals_two_renders(dev, coins, with_depth, thr):
     assert torch.equal(h["rgb_ref"], i2["rgb_ref"]) and torch.equal(h["depth_pred_ref"], i2["depth_pred_ref"])
     for k in ("rgb0", "depth0", "raw"):
         assert torch.equal(i1["extras"][k], i2["extras"][k]) and torch.equal(h["extras_ref"][k], i2["extras_ref"][k]), k
-    # padding rows: zero raw outputs (the gated tiles), nothing else depends on them
-    assert not i1["extras_ref"]["raw"][M:].any()
+    # padding rows: zero raw outputs (the gated tiles), nothing else depends on them.  (The opt-in bf16x3 training forward has no
+    # gate: it evaluates the padding rays like any other — valid rays of weight 0 — so its padding outputs are not zero.)
+    assert BF3 or not i1["extras_ref"]["raw"][M:].any()
     a, b = l1.item(), l2.item()
     print(f"  coins {coins} thr {thr}: M={M} loss one render {a:.8f} two renders {b:.8f}")
     assert abs(a - b) <= 2e-6 * abs(b)
@@ -1644,6 +1645,7 @@ def test_ss_step_one_render_equals_two_renders(dev, coins, with_depth, thr):
     assert worst <= 3e-6
 
 
+@fp32_only
 @pytest.mark.parametrize("coins", [(0, 1, 0, 0), (1, 1, 1, 1), (1, 0, 0, 0)])
 def test_ss_step_one_render_merged_backward_with_skip(dev, coins):
     """The production route of the one-render step: both networks owned by FusedAdam -> ONE dgrad grid + ONE wgrad grid for both levels
