@@ -189,6 +189,16 @@ RN._report_ready_pair(mods[1], mods[0])
 assert red._done == {id(mods[1])} and red.messages == 2
 red.finish()
 assert red.messages == 3
+# the two exchanges of a sharded `--ss_loss` step (run_nerf_view.ss_global_stats; VT:917-921 threshold rule, VT:941-966 means):
+# all-reduce MIN of the ranks' minimum |z - D_ref| (carried as float bits in meta[4]), all-reduce SUM of the three ray counts
+from consistentnerf_amd.run_nerf_view import ss_global_stats
+amin_r = np.float32(0.75 - 0.25 * rank)
+meta = torch.tensor([100 + rank, 2, 0, 0, int(np.float32(amin_r).view(np.int32)), 40 + rank, 0, 0], dtype=torch.int32)
+amin_g, counts_fn = ss_global_stats(meta, 256 + 8 * rank, None)
+assert float(amin_g) == 0.75 - 0.25 * (world - 1) and meta[4] == int(np.float32(amin_r).view(np.int32))      # (input untouched)
+c3 = counts_fn(meta)
+assert c3.tolist() == [float(sum(40 + r for r in range(world))), float(sum(256 + 8 * r for r in range(world))),
+                       float(sum(100 + r for r in range(world)))], c3
 D.barrier()
 if rank == 0: print("DIST_OK", world, err)
 dist.destroy_process_group()
