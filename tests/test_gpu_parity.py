@@ -1645,6 +1645,61 @@ def test_ss_step_one_render_equals_two_renders(dev, coins, with_depth, thr):
     assert worst <= 3e-6
 
 
+@pytest.mark.parametrize("case", ["single_level", "single_level_no_depth", "ndc", "too_big_for_one_chunk"])
+def test_ss_step_one_render_other_shapes(dev, case):
+    """The one-render route off its main shape, each against the two-render route (loss 2e-6, gradients 3e-6, maps of the live rows
+    bit-identical): a render WITHOUT a fine network (one level: cnerf_closs_finish_ss2 with one workspace, cnerf_mlp_bwd_live on the
+    one network), the same without the depth terms, NDC rays (the rows of both segments go through the NDC warp in the batch
+    assembly); and a batch whose 2N rows do not fit one chunk: route=None falls back to two renders, route="one_render" raises."""
+    from consistentnerf_amd import ops, run_nerf_view as V
+    sc = _ss_scene(dev, 512, seed=3)
+    H, W, K, kw, rays, tgt, prior, g = sc["H"], sc["W"], sc["K"], dict(sc["kw"]), sc["rays"], sc["tgt"], sc["prior"], sc["g"]
+    nets = [sc["coarse"], sc["fine"]]
+    with_depth, coins, chunk = True, (1, 1, 1, 0), 4096
+    if case.startswith("single_level"):
+        kw.update(network_fine=None, N_importance=0)
+        nets = [sc["coarse"]]
+        with_depth, coins = case == "single_level", (1, 1, 0, 0)
+    elif case == "ndc":
+        kw.update(ndc=True, near=0.0, far=1.0)
+        # forward-facing rays for the NDC warp (d_z < 0, origins behind the near plane at z = -1)
+        rays = torch.stack([rays[0] * 0.1 + torch.tensor([0.0, 0.0, 0.5], device=dev), torch.cat([rays[1][:, :2] * 0.3, -torch.ones(512, 1, device=dev)], 1)], 0)
+        prior = prior * 0.2
+    elif case == "too_big_for_one_chunk":
+        chunk = 768
+    params = [p for m in nets for p in m.parameters()]
+    args = (H, W, K, rays, tgt, prior, sc["poses"][1], g["images"][1], g["depths"][1], kw)
+    if case == "too_big_for_one_chunk":
+        with pytest.raises(ops.CnerfError):
+            V.ss_step_loss(*args, chunk=chunk, with_depth_loss=True, coins=coins, route="one_render")
+        _, info = V.ss_step_loss(*args, chunk=chunk, with_depth_loss=True, coins=coins)
+        assert info["route"] == "two_renders"
+        return
+    l2, i2 = V.ss_step_loss(*args, chunk=chunk, occlusion_threshold=0.1, with_depth_loss=with_depth, coins=coins, route="two_renders")
+    l2.backward()
+    g2 = _grads_of(params)
+    l1, i1 = V.ss_step_loss(*args, chunk=chunk, occlusion_threshold=0.1, with_depth_loss=with_depth, coins=coins)
+    assert i1["route"] == "one_render"
+    l1.backward()
+    g1 = _grads_of(params)
+    h = V.ss_host_view(i1)
+    M = h["M"]
+    assert M == i2["batch_rays_ref"].shape[1] and M > 0
+    assert torch.equal(i1["rgb"], i2["rgb"]) and torch.equal(h["rgb_ref"], i2["rgb_ref"]) and torch.equal(h["depth_pred_ref"], i2["depth_pred_ref"])
+    assert torch.equal(h["mask"], i2["mask"]) and torch.equal(i1["sel"], i2["sel"])
+    if case == "ndc":
+        assert torch.equal(i1["rows"][512:512 + M], i2["batch_rays_ref"]._cnerf_packed.rows), "NDC rows of the second segment"
+    print(f"  {case}: M={M} loss one render {l1.item():.8f} two renders {l2.item():.8f}")
+    assert abs(l1.item() - l2.item()) <= 2e-6 * abs(l2.item())
+    worst = 0.0
+    for x, y in zip(g1, g2):
+        assert (x is None) == (y is None)
+        if x is not None and float(y.abs().max()) > 0:
+            worst = max(worst, (x - y).abs().max().item() / y.abs().max().item())
+    print(f"  worst relative gradient difference {worst:.2e}")
+    assert worst <= 3e-6
+
+
 @fp32_only
 @pytest.mark.parametrize("coins", [(0, 1, 0, 0), (1, 1, 1, 1), (1, 0, 0, 0)])
 def test_ss_step_one_render_merged_backward_with_skip(dev, coins):
