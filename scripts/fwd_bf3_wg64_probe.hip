@@ -34,7 +34,7 @@ __device__ __forceinline__ f32x16 mfma(const u32x4& a, const u32x4& b, const f32
 }
 
 // weights: [layer][kstep][wave][tile 2][plane 3][64 lanes][16 B]
-template <bool STASH>
+template <bool STASH, int PD>
 __global__ __launch_bounds__(256) void probe(const u32x4* __restrict__ wts, float* __restrict__ stash, float* __restrict__ out, int tiles_per_wg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tile[];
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n = lane & 31, hh = lane >> 5;
@@ -57,9 +57,13 @@ __global__ __launch_bounds__(256) void probe(const u32x4* __restrict__ wts, floa
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[t][h2][r] = 0.f;
       const u32x4* wl = wts + ((size_t)l * KS * 4 + w) * 6 * 64 + lane;      // + s * 4 * 6 * 64, + (t * 3 + p) * 64
-      u32x4 A[2][6], B[2][6];
+      // weight fragments run PD K-steps ahead of their MFMAs (a K-step is 24 MFMAs = 768 matrix-pipe cycles; an L2 round trip is of
+      // that order), activation fragments one K-step ahead (LDS)
+      u32x4 A[PD + 1][6], B[2][6];
 #pragma unroll
-      for (int q = 0; q < 6; ++q) A[0][q] = wl[q * 64];
+      for (int d = 0; d < PD; ++d)
+#pragma unroll
+        for (int q = 0; q < 6; ++q) A[d][q] = wl[(size_t)d * 4 * 6 * 64 + q * 64];
 #pragma unroll
       for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
@@ -67,10 +71,12 @@ __global__ __launch_bounds__(256) void probe(const u32x4* __restrict__ wts, floa
           B[0][h2 * 3 + p] = *reinterpret_cast<const u32x4*>(tile + p * PLANE + (32 * h2 + n) * ROWB + hh * 16);
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
-        const int cur = s & 1, nxt = cur ^ 1;
-        if (s + 1 < KS) {
+        const int cur = s & 1, nxt = cur ^ 1, ca = s % (PD + 1);
+        if (s + PD < KS) {
 #pragma unroll
-          for (int q = 0; q < 6; ++q) A[nxt][q] = wl[(size_t)(s + 1) * 4 * 6 * 64 + q * 64];
+          for (int q = 0; q < 6; ++q) A[(s + PD) % (PD + 1)][q] = wl[(size_t)(s + PD) * 4 * 6 * 64 + q * 64];
+        }
+        if (s + 1 < KS) {
 #pragma unroll
           for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
@@ -82,7 +88,7 @@ __global__ __launch_bounds__(256) void probe(const u32x4* __restrict__ wts, floa
 #pragma unroll
           for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) acc[t][h2] = mfma(A[cur][t * 3 + IA[k]], B[cur][h2 * 3 + IB[k]], acc[t][h2]);
+            for (int h2 = 0; h2 < 2; ++h2) acc[t][h2] = mfma(A[ca][t * 3 + IA[k]], B[cur][h2 * 3 + IB[k]], acc[t][h2]);
       }
       __syncthreads();          // every wave has read the old tile
       // epilogue: ReLU, 3-plane split, write the next layer's B operand; lane (n, hh) holds of tile t / half h2 the channels
@@ -116,21 +122,21 @@ __global__ __launch_bounds__(256) void probe(const u32x4* __restrict__ wts, floa
   out[blockIdx.x * 256 + threadIdx.x] = sink + reinterpret_cast<float*>(tile)[threadIdx.x];
 }
 
-template <bool STASH>
+template <bool STASH, int PD>
 void run(const u32x4* wts, float* stash, float* out, int wgs, int tiles_per_wg) {
-  hipFuncSetAttribute(reinterpret_cast<const void*>(probe<STASH>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(probe<STASH, PD>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  hipLaunchKernelGGL((probe<STASH>), dim3(wgs), dim3(256), LDS_BYTES, 0, wts, stash, out, 1);
+  hipLaunchKernelGGL((probe<STASH, PD>), dim3(wgs), dim3(256), LDS_BYTES, 0, wts, stash, out, 1);
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  hipLaunchKernelGGL((probe<STASH>), dim3(wgs), dim3(256), LDS_BYTES, 0, wts, stash, out, tiles_per_wg);
+  hipLaunchKernelGGL((probe<STASH, PD>), dim3(wgs), dim3(256), LDS_BYTES, 0, wts, stash, out, tiles_per_wg);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   hipError_t e = hipGetLastError();
   const double mac = (double)wgs * tiles_per_wg * NL * PTS * (double)W * W;        // fp32-equivalent MACs
   const double bf = mac * 6 * 2;
-  printf("wg64 dataflow%s  %d workgroups x %d tiles: %.3f ms  %.0f TFLOP/s bf16 = %.3f of 2500;  fp32-equivalent %.1f TFLOP/s = %.3f of 416.7 "
-         "(product kernel mlp_fwd_train_bf3: 0.457)  [%s]\n", STASH ? " + stash stores" : "", wgs, tiles_per_wg, ms, bf / ms / 1e9,
+  printf("wg64 dataflow (weights %d K-steps ahead)%s  %d workgroups x %d tiles: %.3f ms  %.0f TFLOP/s bf16 = %.3f of 2500;  fp32-equivalent %.1f TFLOP/s = %.3f of 416.7 "
+         "(product kernel mlp_fwd_train_bf3: 0.457)  [%s]\n", PD, STASH ? " + stash stores" : "", wgs, tiles_per_wg, ms, bf / ms / 1e9,
          bf / ms / 1e9 / 2500.0, mac * 2 / ms / 1e9, mac * 2 / ms / 1e9 / 416.7, hipGetErrorString(e));
 }
 
@@ -146,9 +152,12 @@ int main() {
   hipMalloc(&stash, (size_t)wgs * tiles * NL * PTS * W * 4);
   hipMalloc(&out, (size_t)wgs * 256 * 4);
   for (int r = 0; r < 2; ++r) {
-    run<false>(wts, stash, out, wgs, tiles);
-    run<true>(wts, stash, out, wgs, tiles);
+    run<false, 1>(wts, stash, out, wgs, tiles);
+    run<false, 2>(wts, stash, out, wgs, tiles);
+    run<false, 3>(wts, stash, out, wgs, tiles);
+    run<true, 1>(wts, stash, out, wgs, tiles);
+    run<true, 3>(wts, stash, out, wgs, tiles);
   }
-  run<false>(wts, stash, out, 512, 24);      // two workgroups per CU cannot co-reside (101 KB each): same rate expected
+  run<false, 3>(wts, stash, out, 512, 24);      // two workgroups per CU cannot co-reside (101 KB each): same rate expected
   return 0;
 }
