@@ -239,43 +239,50 @@ __global__ __launch_bounds__(T) void closs_tail_k(ClossTail a) {
     const double M = a.counts3 ? (double)a.counts3[2] : seg[0][1][3];
     float loss = 0.f;
     float ref_t[4] = {0.f, 0.f, 0.f, 0.f};
+    // M == 0 (no point of the batch projects into the reference view; the reference's `while mask.sum() == 0` never ends there, and the
+    // two-render route raises): the second render has no rays — its terms and seed weights are 0 instead of 0 / 0, terms[7] = 0 tells
+    // the caller, and with no in-bounds ray `sel` is empty too: the primary terms below fall to their un-masked branch.
+    const bool have2 = M > 0.0;
     for (int lv = 0; lv < levels; ++lv) {          // level 0 = the last (fine) level: its terms come first in the reference
-      const float il = (float)(seg[lv][1][0] / (3.0 * M));
+      const float il = have2 ? (float)(seg[lv][1][0] / (3.0 * M)) : 0.f;
       loss = loss + il;
       ref_t[2 * lv] = il;
       float dl = 0.f;
-      if (a.has_depth) { dl = (float)(seg[lv][1][2] / M); loss = loss + dl; }
+      if (a.has_depth && have2) { dl = (float)(seg[lv][1][2] / M); loss = loss + dl; }
       ref_t[2 * lv + 1] = dl;
       float* st = a.stats + 8 * lv + 4;            // segment 2 of this level: live rows weigh 2 / (3 M) and 2 / M, padding rows 0
-      st[0] = (float)(2.0 / (3.0 * M)); st[1] = 0.f; st[2] = a.has_depth ? (float)(2.0 / M) / a.far : 0.f; st[3] = 0.f;
+      st[0] = have2 ? (float)(2.0 / (3.0 * M)) : 0.f; st[1] = 0.f;
+      st[2] = (a.has_depth && have2) ? (float)(2.0 / M) / a.far : 0.f; st[3] = 0.f;
     }
     const double s1 = seg[0][0][0], s0 = seg[0][0][1];
     const double N1 = a.counts3 ? (double)a.counts3[0] : seg[0][0][3];
     const double Nall = a.counts3 ? (double)a.counts3[1] : seg[0][0][3] + seg[0][0][4];
     const float plain = (float)((s1 + s0) / (3.0 * Nall));
-    const float wall = (float)(2.0 / (3.0 * Nall)), wsel = (float)(2.0 / (3.0 * N1));
-    const float il = a.coin[0] ? (float)(s1 / (3.0 * N1)) : plain;
-    float w1 = a.coin[0] ? wsel : wall, w0 = a.coin[0] ? 0.f : wall;
+    const bool anysel = N1 > 0.0;                 // (false only with M == 0, see above: the coins then have nothing to select)
+    const bool c0 = a.coin[0] && anysel, c2 = a.coin[2] && anysel;
+    const float wall = (float)(2.0 / (3.0 * Nall)), wsel = anysel ? (float)(2.0 / (3.0 * N1)) : 0.f;
+    const float il = c0 ? (float)(s1 / (3.0 * N1)) : plain;
+    float w1 = c0 ? wsel : wall, w0 = c0 ? 0.f : wall;
     loss = loss + il;
     float dl = 0.f;
-    const bool dep = a.has_depth && a.coin[1];
+    const bool dep = a.has_depth && a.coin[1] && anysel;
     if (dep) { dl = (float)(seg[0][0][2] / N1); loss = loss + dl; }
     a.terms[1] = il; a.terms[2] = dl; a.terms[3] = 0.f;
     a.stats[2] = dep ? (float)(2.0 / N1) / a.far : 0.f;
     a.stats[3] = 0.f;
     a.terms[4] = a.terms[5] = a.terms[6] = 0.f;
     if (levels == 2) {
-      const float il0 = a.coin[2] ? (float)(seg[1][0][0] / (3.0 * N1)) : plain;
+      const float il0 = c2 ? (float)(seg[1][0][0] / (3.0 * N1)) : plain;
       loss = loss + il0;
       float dl0 = 0.f;
-      const bool dep0 = a.has_depth && a.coin[3];
+      const bool dep0 = a.has_depth && a.coin[3] && anysel;
       if (dep0) { dl0 = (float)(seg[1][0][2] / N1); loss = loss + dl0; }
       a.terms[4] = il0; a.terms[5] = dl0;
-      a.stats[8] = a.coin[2] ? (float)(2.0 / (3.0 * N1)) : 0.f;
+      a.stats[8] = c2 ? (float)(2.0 / (3.0 * N1)) : 0.f;
       a.stats[9] = 0.f;
       a.stats[10] = dep0 ? (float)(2.0 / N1) / a.far : 0.f;
       a.stats[11] = 0.f;
-      if (!a.coin[2]) { w1 += wall; w0 += wall; }
+      if (!c2) { w1 += wall; w0 += wall; }
     }
     a.stats[0] = w1; a.stats[1] = w0;
     a.terms[0] = loss;

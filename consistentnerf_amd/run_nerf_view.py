@@ -562,7 +562,9 @@ def ss_step_loss(H, W, K, batch_rays, target_s, depth_cas_s, pose_ref, image_ref
     it in the warp launch; rows past N + M are padding) with a two-segment loss tail (cnerf_closs_finish_ss2), the loss accumulated
     in the reference's own order: half the MFMA launches, 15 launches in all, and NO host synchronisation — M lives on the device
     only, so `info` holds capacity-N tensors (`ss_host_view(info)` gives the reference's shapes at the cost of a sync) and the step
-    can be recorded as a hipGraph; "two_renders" — round 5's form described above (one 16-byte read-back).  None: one_render when
+    can be recorded as a hipGraph (a batch of which NOTHING projects into the reference view — M = 0, where the reference never
+    leaves its threshold loop and the two-render route raises — yields the un-masked primary terms only; `info["terms"]["M"]` says
+    so); "two_renders" — round 5's form described above (one 32-byte read-back).  None: one_render when
     the batch qualifies (_ss_one_render_ok), else two_renders.
     Sharded batches: `group` = the process group whose ranks each hold a slice of the batch (two small all-reduces: MIN
     of the minimum |z - D_ref| for the threshold rule, SUM of the three ray counts the means divide by), or `global_stats` =

@@ -305,7 +305,8 @@ int cnerf_closs_finish_ss(const cnerf_closs_sum* t, const int32_t* coins4, float
  *   first segment   (:941-969)  the four coin-gated terms of cnerf_closs_finish_ss
  * accumulated in the reference's order (second render's terms first).  M is the device-side count of mask-1 rows of the second
  * segment — the host never needs it; counts3 (nullable, device) = the GLOBAL (selected primary rays, primary rays, warped rays) of a
- * batch sharded over ranks.  terms12 = the 8 of cnerf_closs_finish_ss (terms12[7] = M as a float) + img_ref, depth_ref, img0_ref,
+ * batch sharded over ranks.  M == 0 (nothing projects into the reference view: the reference never leaves its threshold loop): the
+ * second segment's terms and seed weights are 0, the primary terms take their un-masked branch.  terms12 = the 8 of cnerf_closs_finish_ss (terms12[7] = M as a float) + img_ref, depth_ref, img0_ref,
  * depth0_ref;  stats16 = per level [2 segments][4]: (w1, w0, wd, -) — level l passes stats16 + 8 l to cnerf_composite_bwd_closs. */
 int cnerf_closs_finish_ss2(const cnerf_closs_sum* t, const int32_t* coins4, int64_t seg_row, const float* counts3, float* terms12,
                            float* stats16, void* stream);

@@ -1700,6 +1700,41 @@ def test_ss_step_one_render_other_shapes(dev, case):
     assert worst <= 3e-6
 
 
+def test_ss_step_one_render_with_no_ray_in_view(dev):
+    """M == 0: no point of the batch projects into the reference view (here: every depth-prior point sits in the reference camera's
+    z = 0 plane).  The reference's `while mask.sum() == 0` (VT:921) never ends there and the two-render route raises; the one-render
+    route cannot know on the host — the tail kernel drops the second render's terms (0 instead of 0 / 0), nothing is selected, so the
+    coin-gated primary terms take their un-masked branch: loss == 2 x img2mse(rgb, target) (VT:942 + the fallback of VT:959), finite,
+    terms['M'] == 0 tells the caller, and the gradient is that loss's."""
+    from consistentnerf_amd import ops, run_nerf as R, run_nerf_view as V
+    sc = _ss_scene(dev, 256, seed=6)
+    H, W, K, kw, tgt, g = sc["H"], sc["W"], sc["K"], sc["kw"], sc["tgt"], sc["g"]
+    pose = sc["poses"][1]
+    ro = T(np.tile(pose[:3, 3], (256, 1)).astype(np.float32), dev)
+    rd = T(np.tile(pose[:3, 0], (256, 1)).astype(np.float32), dev) * torch.linspace(0.5, 2.0, 256, device=dev)[:, None]
+    rays, prior = torch.stack([ro, rd], 0), torch.ones(256, device=dev)
+    params = [p for m in (sc["coarse"], sc["fine"]) for p in m.parameters()]
+    args = (H, W, K, rays, tgt, prior, pose, g["images"][1], g["depths"][1], kw)
+    with pytest.raises(ops.CnerfError):
+        V.ss_step_loss(*args, chunk=4096, with_depth_loss=True, coins=(1, 1, 1, 1), route="two_renders")
+    loss, info = V.ss_step_loss(*args, chunk=4096, with_depth_loss=True, coins=(1, 1, 1, 1), route="one_render")
+    loss.backward()
+    g1 = _grads_of(params)
+    t = {k: float(v) for k, v in info["terms"].items()}
+    assert t["M"] == 0.0 and int(info["live"].item()) == 256 and not info["sel"].any()
+    assert t["img_loss_ref"] == t["depth_loss_ref"] == t["img_loss0_ref"] == t["depth_loss0_ref"] == 0.0 and t["depth_loss"] == 0.0
+    rgb, _, _, _, _ = V.render(H, W, K, chunk=4096, rays=rays, retraw=True, **kw)
+    want = 2.0 * R.img2mse(rgb, tgt)
+    want.backward()
+    g0 = _grads_of(params)
+    assert np.isfinite(loss.item()) and abs(loss.item() - want.item()) <= 2e-6 * abs(want.item()), (loss.item(), want.item())
+    for x, y in zip(g1, g0):
+        if y is None or float(y.abs().max()) == 0:
+            assert x is None or float(x.abs().max()) == 0
+        else:
+            assert float((x - y).abs().max()) <= 3e-6 * float(y.abs().max())
+
+
 @fp32_only
 @pytest.mark.parametrize("coins", [(0, 1, 0, 0), (1, 1, 1, 1), (1, 0, 0, 0)])
 def test_ss_step_one_render_merged_backward_with_skip(dev, coins):
