@@ -1645,12 +1645,13 @@ def test_ss_step_one_render_equals_two_renders(dev, coins, with_depth, thr):
     assert worst <= 3e-6
 
 
-@pytest.mark.parametrize("case", ["single_level", "single_level_no_depth", "ndc", "too_big_for_one_chunk"])
+@pytest.mark.parametrize("case", ["single_level", "single_level_no_depth", "ndc", "too_big_for_one_chunk", "n_not_a_multiple_of_8"])
 def test_ss_step_one_render_other_shapes(dev, case):
     """The one-render route off its main shape, each against the two-render route (loss 2e-6, gradients 3e-6, maps of the live rows
     bit-identical): a render WITHOUT a fine network (one level: cnerf_closs_finish_ss2 with one workspace, cnerf_mlp_bwd_live on the
     one network), the same without the depth terms, NDC rays (the rows of both segments go through the NDC warp in the batch
-    assembly); and a batch whose 2N rows do not fit one chunk: route=None falls back to two renders, route="one_render" raises."""
+    assembly); and batches that do not qualify — 2N rows that do not fit one chunk, N not a multiple of 8: route=None falls back to
+    two renders, route="one_render" raises."""
     from consistentnerf_amd import ops, run_nerf_view as V
     sc = _ss_scene(dev, 512, seed=3)
     H, W, K, kw, rays, tgt, prior, g = sc["H"], sc["W"], sc["K"], dict(sc["kw"]), sc["rays"], sc["tgt"], sc["prior"], sc["g"]
@@ -1669,7 +1670,10 @@ def test_ss_step_one_render_other_shapes(dev, case):
         chunk = 768
     params = [p for m in nets for p in m.parameters()]
     args = (H, W, K, rays, tgt, prior, sc["poses"][1], g["images"][1], g["depths"][1], kw)
-    if case == "too_big_for_one_chunk":
+    if case == "n_not_a_multiple_of_8":      # (a compositing workgroup's loss partial must belong to one segment)
+        rays, tgt, prior = rays[:, :509].contiguous(), tgt[:509], prior[:509]
+        args = (H, W, K, rays, tgt, prior, sc["poses"][1], g["images"][1], g["depths"][1], kw)
+    if case in ("too_big_for_one_chunk", "n_not_a_multiple_of_8"):
         with pytest.raises(ops.CnerfError):
             V.ss_step_loss(*args, chunk=chunk, with_depth_loss=True, coins=coins, route="one_render")
         _, info = V.ss_step_loss(*args, chunk=chunk, with_depth_loss=True, coins=coins)
