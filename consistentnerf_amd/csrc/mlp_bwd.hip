@@ -234,13 +234,18 @@ extern "C" int64_t cnerf_mlp_bwd_ws_floats(const cnerf_net* net, int64_t M) {
 }
 
 static int dgrad_one(const cnerf_net* net, const float* packed, const float* d_raw, int64_t B, int S, const float* stash,
-                     float* workspace, const int32_t* live, void* stream) {
+                     float* workspace, const int32_t* live, void* stream, int64_t first = 0) {
   BwdArgs a;
   int rc = cn_make_geom(net, &a.g);
   if (rc) return rc;
   if (!packed || !d_raw || !stash || !workspace || B < 0 || S <= 0 || (live && S % 32 != 0)) return CNERF_E_ARG;
+  if (first && (!live || first < 0 || first >= B)) return CNERF_E_ARG;
   if (B == 0) return CNERF_OK;
-  a.lv[0] = BwdLevel{packed, d_raw, stash, workspace, B * S, cn_round_up(B * S, 32), live ? S : 0, 0};
+  const int64_t o = first * S;      // (first_ray: operands advanced past the rays that are left out, see dgrad_pair)
+  d_raw += o * (a.g.viewdirs ? 4 : a.g.out_ch);
+  stash += o * a.g.s_rows;
+  B -= first;
+  a.lv[0] = BwdLevel{packed, d_raw, stash, workspace, B * S, cn_round_up(B * S, 32), live ? S : 0, first};
   a.lv[1] = a.lv[0];
   a.nb0 = (unsigned)cn_div_up(B * S, 32);
   a.live = live;
@@ -329,7 +334,7 @@ static int dgrad_pair(const cnerf_net* net0, const float* packed0, const float* 
                     net0->multires_views == net1->multires_views && net0->use_viewdirs == net1->use_viewdirs &&
                     net0->output_ch == net1->output_ch && net0->skip == net1->skip;
   if (live && (S0 % 32 != 0 || S1 % 32 != 0)) return CNERF_E_ARG;
-  if ((first0 || first1) && (!live || !same || first0 < 0 || first1 < 0 || first0 >= B0 || first1 >= B1)) return CNERF_E_ARG;
+  if ((first0 || first1) && (!live || first0 < 0 || first1 < 0 || first0 >= B0 || first1 >= B1)) return CNERF_E_ARG;
   if (same && M0 > 0 && M1 > 0) {
     // first_ray: the level's first `first` rays carry zero seeds and are left out — operands advanced past them (tile rows are
     // 32 points: first * S is a multiple of 32), the device-side count reduced by the same
@@ -341,8 +346,9 @@ static int dgrad_pair(const cnerf_net* net0, const float* packed0, const float* 
     a.live = live;
     return dispatch(a, 2, cn_stream(stream));
   }
-  if ((rc = dgrad_one(net0, packed0, d_raw0, B0, S0, stash0, workspace0, live, stream))) return rc;
-  return dgrad_one(net1, packed1, d_raw1, B1, S1, stash1, workspace1, live, stream);
+  // (two architectures: one dgrad launch per network)
+  if ((rc = dgrad_one(net0, packed0, d_raw0, B0, S0, stash0, workspace0, live, stream, first0))) return rc;
+  return dgrad_one(net1, packed1, d_raw1, B1, S1, stash1, workspace1, live, stream, first1);
 }
 
 static int wgrad_two(const cnerf_net* net0, int64_t B0, int S0, const float* stash0, float* workspace0, const cnerf_ptrs* grads0,

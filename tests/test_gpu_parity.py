@@ -1562,7 +1562,7 @@ def test_ss_step_loss_one_call_equals_the_lines(dev, coins, with_depth):
     assert worst <= 2e-6
 
 
-def _ss_scene(dev, N, seed=0, D=4, W=128, Nc=64, Nf=128, perturb=0.0, owned=False):
+def _ss_scene(dev, N, seed=0, D=4, W=128, Nc=64, Nf=128, perturb=0.0, owned=False, coarse_arch=None):
     """The `ssloss` fixture's 3-view scene with N rays drawn (with replacement) from view 0, two seeded networks and render kwargs at
     sample counts the live-row gate applies to (multiples of 32)."""
     g = golden("ssloss")
@@ -1571,7 +1571,7 @@ def _ss_scene(dev, N, seed=0, D=4, W=128, Nc=64, Nf=128, perturb=0.0, owned=Fals
     ro, rd = O.get_rays_np(Hh, Ww, K, poses[0][:3, :4])
     rs = np.random.RandomState(seed)
     pix = rs.randint(0, Hh * Ww, N)
-    coarse, _ = make_model(D, W, True, 5, 31 + seed, dev)
+    coarse, _ = make_model(*(coarse_arch or (D, W)), True, 5, 31 + seed, dev)
     fine, _ = make_model(D, W, True, 5, 32 + seed, dev)
     kw = _kwargs(coarse, fine, Nc, Nf, perturb, False, 0.0, False)
     kw.update(near=2.0, far=far, ndc=False, use_viewdirs=True)
@@ -1740,8 +1740,9 @@ def test_ss_step_one_render_with_no_ray_in_view(dev):
 
 
 @fp32_only
-@pytest.mark.parametrize("coins", [(0, 1, 0, 0), (1, 1, 1, 1), (1, 0, 0, 0)])
-def test_ss_step_one_render_merged_backward_with_skip(dev, coins):
+@pytest.mark.parametrize("coins,coarse_arch", [((0, 1, 0, 0), None), ((1, 1, 1, 1), None), ((1, 0, 0, 0), None), ((0, 1, 0, 0), (2, 64)),
+                                               ((1, 1, 0, 1), (2, 64))])
+def test_ss_step_one_render_merged_backward_with_skip(dev, coins, coarse_arch):
     """The production route of the one-render step: both networks owned by FusedAdam -> ONE dgrad grid + ONE wgrad grid for both levels
     (cnerf_mlp_dgrad_pair_live / cnerf_mlp_wgrad_pair_live: tiles / re-cut point ranges stop at the device-side live-row count),
     accumulating straight into the flat gradient.  With both coarse coins 0 (VT:959, VT:966) the primary rays' coarse level is left
@@ -1756,9 +1757,9 @@ def test_ss_step_one_render_merged_backward_with_skip(dev, coins):
         return orig(*a, **k)
     grads = {}
     for route in ("two_renders", "one_render"):
-        sc = _ss_scene(dev, 1024, seed=4, owned=True)
+        sc = _ss_scene(dev, 1024, seed=4, owned=True, coarse_arch=coarse_arch)     # (coarse_arch: two architectures -> the merged
         args = (sc["H"], sc["W"], sc["K"], sc["rays"], sc["tgt"], sc["prior"], sc["poses"][1], sc["g"]["images"][1], sc["g"]["depths"][1],
-                sc["kw"])
+                sc["kw"])                                                              #  backward is two dgrad launches + one wgrad grid)
         ops.mlp_backward_pair = spy
         try:
             loss, info = V.ss_step_loss(*args, chunk=4096, occlusion_threshold=0.1, with_depth_loss=True, coins=coins, route=route)
